@@ -1,0 +1,340 @@
+"""TEST INFRASTRUCTURE - CPU oracle, never imported by the product path.
+
+NumPy restatement of the reference's near-field synthesis,
+``nearfield.build_nearfield`` (reference nearfield.py:66-480),
+``build_nearfield_big`` (nearfield.py:482-516) and ``good_fft_number``
+(nearfield.py:30-36).  It is organised per aperture sample (the way the HIP
+kernel is) rather than per diffraction order with boolean-mask scatter, but
+every real-valued quantity that feeds a large-argument phase is computed with
+the reference's operation order so that the two agree to rounding
+(tests/test_oracle_golden.py pins it to fixtures produced by the reference
+itself in the build container, tests/golden/gen/make_golden.py).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg
+may import this module.
+"""
+from math import pi
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+from . import rgi
+
+inf = float('inf')
+nm = 1e-9
+
+# defaults = metalens_amd.constants (kept literal so the oracle stands alone)
+C0 = 299792458.0
+Z0_DEFAULT = 1.25663706212e-6 * C0
+
+_N_GLASS = {450: 1.466, 500: 1.462, 525: 1.461, 550: 1.46, 575: 1.459,
+            580: 1.459, 600: 1.458, 625: 1.457, 650: 1.457}
+
+
+def good_fft_number(goal):
+    """Smallest 2^a 3^b 5^c >= goal (reference nearfield.py:30-36)."""
+    assert goal < 1e5
+    best = None
+    p2 = 1
+    for _ in range(17):
+        p3 = p2
+        for _ in range(11):
+            p5 = p3
+            for _ in range(8):
+                if p5 >= goal and (best is None or p5 < best):
+                    best = p5
+                p5 *= 5
+            p3 *= 3
+        p2 *= 2
+    return best
+
+
+def tabulated_n_glass(wavelength_in_nm):
+    """reference grating.py:1274-1288"""
+    if wavelength_in_nm not in _N_GLASS:
+        raise ValueError('bad wavelength' + repr(wavelength_in_nm))
+    return _N_GLASS[wavelength_in_nm]
+
+
+def _check_axis(pts, wavelength):
+    """uniform, ascending, finer than half a wavelength (nearfield.py:106-109)"""
+    d = np.diff(np.asarray(pts, dtype=float))
+    assert 0 < d[0] < wavelength / 2
+    assert d.max() - d.min() <= 1e-9 * np.abs(d).max()
+
+
+def _orders_of(grating_list):
+    return sorted({(e['ox'], e['oy']) for g in grating_list for e in g.data})
+
+
+def _accumulate(acc, E_w, H_w, a_fy, a_fx, kx, ky, kz, k_glass, n_glass, phase):
+    """Add one diffraction order for one incident polarisation to the four
+    tangential field accumulators (reference nearfield.py:312-327 /
+    426-441; derivation S4conventions.py:94-97).  Left-to-right operation order
+    of the reference is kept."""
+    Ex, Ey, Hx, Hy = acc
+    denom = k_glass * kz
+    Ex += E_w * a_fy * kx * ky / denom / n_glass * phase
+    Ey += E_w * a_fy * (-kx ** 2 - kz ** 2) / denom / n_glass * phase
+    Hx += H_w * a_fy * phase
+    Ex += E_w * a_fx * (ky ** 2 + kz ** 2) / denom / n_glass * phase
+    Ey += E_w * a_fx * -kx * ky / denom / n_glass * phase
+    Hy += H_w * a_fx * phase
+
+
+def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
+                    lens_periphery_summary, lens_center_summary, hexgridset,
+                    x_pts=None, y_pts=None, dipole_moment=1e-30, c0=C0, Z0=Z0_DEFAULT,
+                    decisions=None):
+    """Same signature and return tuple as the reference (nearfield.py:66-68,480)
+    plus explicit ``c0`` / ``Z0``.  If ``decisions`` is a dict it
+    receives the per-sample discrete decisions (ring, sector, nearest cell) for
+    parity diagnostics."""
+    assert source_z < 0
+    assert source_pol in ('x', 'y', 'z')
+    S = lens_periphery_summary
+    wavelength_in_nm = int(round(wavelength / nm))
+    r_min = np.asarray(S['r_min_list'], dtype=float)
+    r_max = np.asarray(S['r_max_list'], dtype=float)
+    r_center_list = np.asarray(S['r_center_list'], dtype=float)
+    gc_of_ring = np.asarray(S['gratingcollection_index_here_list'])
+    num_around = np.asarray(S['num_around_circle_list'])
+    period_list = np.asarray(S['grating_period_list'], dtype=float)
+    gc_list = S['gratingcollection_list']
+    lens_max_r = r_max[-1]
+    if x_pts is None:
+        x_pts = np.linspace(-lens_max_r, lens_max_r,
+                            num=good_fft_number(2 * lens_max_r / (wavelength / 2.2)))
+    if y_pts is None:
+        y_pts = np.linspace(-lens_max_r, lens_max_r,
+                            num=good_fft_number(2 * lens_max_r / (wavelength / 2.2)))
+    _check_axis(x_pts, wavelength)
+    _check_axis(y_pts, wavelength)
+    nx, ny = len(x_pts), len(y_pts)
+
+    n_glass = gc_list[0].grating_list[0].n_glass
+    if n_glass == 0:
+        n_glass = tabulated_n_glass(wavelength_in_nm)
+    k_glass = 2 * pi * n_glass / wavelength
+    kvac = 2 * pi / wavelength
+
+    # ---- a1: geometry (nearfield.py:117-205) ------------------------------
+    X, Y = np.meshgrid(np.asarray(x_pts, dtype=float), np.asarray(y_pts, dtype=float),
+                       indexing='ij')
+    lens_r = (X ** 2 + Y ** 2) ** 0.5
+    lens_phi = np.arctan2(Y, X)
+    ring = np.searchsorted(np.hstack((r_min, lens_max_r)), lens_r) - 1
+    in_center = ring == -1
+    ring[ring == len(r_min)] = -1
+    zeros_c = np.zeros((nx, ny), dtype=complex)
+    if ring.max() == -1 and not in_center.any():
+        return zeros_c, zeros_c, zeros_c, zeros_c, x_pts, y_pts, 0, n_glass
+    which_gc = gc_of_ring[ring]
+    which_gc[ring == -1] = -1
+
+    period = period_list[ring]
+    dphi = 2 * pi / num_around[ring]
+    r_c = r_center_list[ring]
+    lateral = r_c * dphi
+    sector = (lens_phi / dphi).round()
+    rot = sector * dphi
+    cosr, sinr = np.cos(rot), np.sin(rot)
+    dx = X - source_x
+    dy = Y - source_y
+    dz = 0 - source_z
+    plane_wave = source_z == -inf
+    if plane_wave:
+        ux = np.zeros_like(X)
+        uy = np.zeros_like(X)
+        uz = np.ones_like(X)
+        dist = None
+    else:
+        dist = (dx ** 2 + dy ** 2 + dz ** 2) ** 0.5
+        ux, uy, uz = dx / dist, dy / dist, dz / dist
+    uxp = ux * cosr + uy * sinr
+    uyp = -ux * sinr + uy * cosr
+    xp = X * cosr + Y * sinr - r_c
+    yp = -X * sinr + Y * cosr
+
+    # ---- a2: incident field (nearfield.py:208-247) -------------------------
+    H_coef = c0 * (2 * pi / wavelength) ** 2 * dipole_moment / (4 * pi)
+    px, py, pz = {'x': (1, 0, 0), 'y': (0, 1, 0), 'z': (0, 0, 1)}[source_pol]
+    if not plane_wave:
+        Hx_inc = (uy * pz - uz * py) * H_coef * uz ** 0.5 / dist
+        Hy_inc = (uz * px - ux * pz) * H_coef * uz ** 0.5 / dist
+        Hz_inc = (ux * py - uy * px) * H_coef * uz ** 0.5 / dist
+        Ex_inc = (Hy_inc * uz - Hz_inc * uy) * Z0
+        Ey_inc = (Hz_inc * ux - Hx_inc * uz) * Z0
+    else:
+        assert source_pol != 'z'
+        one = np.ones((nx, ny))
+        Ex_inc = px * dipole_moment * one
+        Ey_inc = py * dipole_moment * one
+        Hx_inc = -py * dipole_moment / Z0 * one
+        Hy_inc = px * dipole_moment / Z0 * one
+    Hxp_inc = Hx_inc * cosr + Hy_inc * sinr
+    Hyp_inc = -Hx_inc * sinr + Hy_inc * cosr
+    # x-polarised table <=> H along y' (nearfield.py:246-247)
+    Hw_periph = {'x': Hyp_inc, 'y': Hxp_inc}
+
+    # ---- a3: periphery, per collection, per order (nearfield.py:263-327) ---
+    Exp = np.zeros((nx, ny), dtype=complex)
+    Eyp = np.zeros((nx, ny), dtype=complex)
+    Hxp = np.zeros((nx, ny), dtype=complex)
+    Hyp = np.zeros((nx, ny), dtype=complex)
+    for gc_index, gc in enumerate(gc_list):
+        here = which_gc == gc_index
+        if not here.any():
+            continue
+        b = gc.interpolator_bounds
+        for ox, oy in _orders_of(gc.grating_list):
+            kxp_all = kvac * uxp + ox * 2 * pi / period
+            kyp_all = kvac * uyp + oy * 2 * pi / lateral
+            sel = np.logical_and(kxp_all ** 2 + kyp_all ** 2 <= kvac ** 2, here)
+            if not sel.any():
+                continue
+            kxp, kyp = kxp_all[sel], kyp_all[sel]
+            kzp = (k_glass ** 2 - kxp ** 2 - kyp ** 2) ** 0.5
+            phase = np.exp(1j * (kxp * xp[sel] + kyp * yp[sel]))
+            u, v, g = uxp[sel], uyp[sel], period[sel]
+            if u.min() < b[0]:
+                raise ValueError('need to calculate at smaller ux!', u.min(), b[0])
+            if u.max() > b[1]:
+                raise ValueError('need to calculate at bigger ux!', u.max(), b[1])
+            if v.min() < b[2]:
+                raise ValueError('need to calculate at smaller uy!', v.min(), b[2])
+            if v.max() > b[3]:
+                raise ValueError('need to calculate at bigger uy!', v.max(), b[3])
+            if g.min() < b[4]:
+                raise ValueError('need to calculate at smaller grating_period!', g.min() / nm, b[4] / nm)
+            if g.max() > b[5]:
+                raise ValueError('need to calculate at bigger grating_period!', g.max() / nm, b[5] / nm)
+            acc = [Exp[sel], Eyp[sel], Hxp[sel], Hyp[sel]]
+            for pol in ('x', 'y'):
+                H_w = Hw_periph[pol][sel]
+                E_w = H_w * Z0
+                fy = gc.interpolators[(wavelength_in_nm, (ox, oy), pol, 'ampfy')]
+                fx = gc.interpolators[(wavelength_in_nm, (ox, oy), pol, 'ampfx')]
+                a_fy = rgi.trilinear(fy.grid, fy.values, u, v, g)
+                a_fx = rgi.trilinear(fx.grid, fx.values, u, v, g)
+                _accumulate(acc, E_w, H_w, a_fy, a_fx, kxp, kyp, kzp, k_glass, n_glass, phase)
+            Exp[sel] = acc[0]
+            Eyp[sel] = acc[1]
+            Hxp[sel] = acc[2]
+            Hyp[sel] = acc[3]
+
+    # ---- a4: propagation phase from the grating centre + rotate back
+    #          (nearfield.py:337-354) ----------------------------------------
+    if not plane_wave:
+        gcx = r_c * cosr
+        gcy = r_c * sinr
+        air = ((gcx - source_x) ** 2 + (gcy - source_y) ** 2 + source_z ** 2) ** 0.5
+        eikr = np.exp(1j * kvac * air)
+        Exp *= eikr
+        Eyp *= eikr
+        Hxp *= eikr
+        Hyp *= eikr
+    Ex = Exp * cosr - Eyp * sinr
+    Ey = Exp * sinr + Eyp * cosr
+    Hx = Hxp * cosr - Hyp * sinr
+    Hy = Hxp * sinr + Hyp * cosr
+
+    # ---- a5: centre, nearest hex cell (nearfield.py:359-466) ---------------
+    xc, yc = X[in_center], Y[in_center]
+    nearest = None
+    if xc.size:
+        cells = np.asarray(lens_center_summary, dtype=float)
+        nearest = cKDTree(cells[:, 0:2]).query(np.column_stack((xc, yc)))[1]
+        cx, cy = cells[nearest, 0], cells[nearest, 1]
+        which = cells[nearest, 2].astype(int)
+        if not plane_wave:
+            dxc = xc - source_x
+            dyc = yc - source_y
+            distc = (dxc ** 2 + dyc ** 2 + dz ** 2) ** 0.5
+            uxc, uyc = dxc / distc, dyc / distc
+        else:
+            uxc = np.zeros_like(xc)
+            uyc = np.zeros_like(xc)
+        # un-rotated weights: x-polarised table <=> H along y (nearfield.py:375-376)
+        Hw_center = {'x': Hy_inc[in_center], 'y': Hx_inc[in_center]}
+        g0 = hexgridset.grating_list[0]
+        b = hexgridset.interpolator_bounds
+        accc = [np.zeros(xc.shape, dtype=complex) for _ in range(4)]
+        for ox, oy in _orders_of(hexgridset.grating_list):
+            kx_all = kvac * uxc + ox * 2 * pi / g0.grating_period
+            ky_all = kvac * uyc + oy * 2 * pi / g0.lateral_period
+            sel = kx_all ** 2 + ky_all ** 2 <= kvac ** 2
+            if not sel.any():
+                continue
+            kx, ky = kx_all[sel], ky_all[sel]
+            kz = (k_glass ** 2 - kx ** 2 - ky ** 2) ** 0.5
+            phase = np.exp(1j * (kx * (xc[sel] - cx[sel]) + ky * (yc[sel] - cy[sel])))
+            u, v, w = uxc[sel], uyc[sel], which[sel]
+            if u.min() < b[0]:
+                raise ValueError('need to calculate at smaller ux!', u.min(), b[0])
+            if u.max() > b[1]:
+                raise ValueError('need to calculate at bigger ux!', u.max(), b[1])
+            if v.min() < b[2]:
+                raise ValueError('need to calculate at smaller uy!', v.min(), b[2])
+            if v.max() > b[3]:
+                raise ValueError('need to calculate at bigger uy!', v.max(), b[3])
+            part = [a[sel] for a in accc]
+            for pol in ('x', 'y'):
+                H_w = Hw_center[pol][sel]
+                E_w = H_w * Z0
+                fy = hexgridset.interpolators[(wavelength_in_nm, (ox, oy), pol, 'ampfy')]
+                fx = hexgridset.interpolators[(wavelength_in_nm, (ox, oy), pol, 'ampfx')]
+                a_fy = rgi.trilinear(fy.grid, fy.values, u, v, w)
+                a_fx = rgi.trilinear(fx.grid, fx.values, u, v, w)
+                _accumulate(part, E_w, H_w, a_fy, a_fx, kx, ky, kz, k_glass, n_glass, phase)
+            for a, p in zip(accc, part):
+                a[sel] = p
+        if not plane_wave:
+            air = ((cx - source_x) ** 2 + (cy - source_y) ** 2 + source_z ** 2) ** 0.5
+            eikr = np.exp(1j * kvac * air)
+            for a in accc:
+                a *= eikr
+        Ex[in_center] += accc[0]
+        Ey[in_center] += accc[1]
+        Hx[in_center] += accc[2]
+        Hy[in_center] += accc[3]
+
+    # ---- a7: incident power through the lens (nearfield.py:474-477) --------
+    Sz = Ex_inc * Hy_inc - Ey_inc * Hx_inc
+    in_lens = np.logical_or(which_gc != -1, in_center)
+    power = Sz[in_lens].sum() * (x_pts[1] - x_pts[0]) * (y_pts[1] - y_pts[0])
+
+    if decisions is not None:
+        decisions['ring'] = ring
+        decisions['in_center'] = in_center
+        decisions['sector'] = sector
+        decisions['nearest'] = nearest
+    return Ex, Ey, Hx, Hy, x_pts, y_pts, power, n_glass
+
+
+def build_nearfield_big(source_x, source_y, source_z, source_pol, wavelength,
+                        lens_periphery_summary, lens_center_summary, hexgridset,
+                        x_pts=None, y_pts=None, dipole_moment=1e-30, c0=C0, Z0=Z0_DEFAULT,
+                        pts_at_a_time=1e7):
+    """y-strip driver (reference nearfield.py:482-516): strips of
+    ``int(pts_at_a_time / len(x_pts))`` y-samples, results concatenated and the
+    strip powers added.  Needs explicit ``x_pts`` / ``y_pts`` like the reference."""
+    strip = int(pts_at_a_time / x_pts.size)
+    Ex = np.zeros((x_pts.size, y_pts.size), dtype=complex)
+    Ey = np.zeros_like(Ex)
+    Hx = np.zeros_like(Ex)
+    Hy = np.zeros_like(Ex)
+    power = 0
+    n_glass = None
+    for start in range(0, y_pts.size, strip):
+        end = min(start + strip, y_pts.size)
+        ex, ey, hx, hy, _, _, p, n_glass = build_nearfield(
+            source_x, source_y, source_z, source_pol, wavelength, lens_periphery_summary,
+            lens_center_summary, hexgridset, x_pts=x_pts, y_pts=y_pts[start:end],
+            dipole_moment=dipole_moment, c0=c0, Z0=Z0)
+        Ex[:, start:end] = ex
+        Ey[:, start:end] = ey
+        Hx[:, start:end] = hx
+        Hy[:, start:end] = hy
+        power += p
+    return Ex, Ey, Hx, Hy, x_pts, y_pts, power, n_glass

@@ -1,0 +1,1 @@
+"""Inert stand-in (module-level import in design_collimator.py only)."""
