@@ -1,0 +1,208 @@
+/*
+ * metalens_hip.h - C ABI of libmetalens_hip.so, the MI355X (gfx950) implementation of
+ * the metalens near-field synthesis + near-to-far-field hot path.
+ *
+ * The reference (sbyrnes321/metalens) has no FFI or plugin interface for this path
+ * (SURVEY.md D6): the boundary is three plain Python functions working on NumPy arrays
+ * and duck-typed table objects.  The entry points below are therefore what a ctypes
+ * binding of those functions needs - each one cites the reference lines it replaces -
+ * and INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ML_E* code on failure;
+ *     ml_last_error() gives the message of the calling thread's last failure;
+ *   - all pointers are HOST pointers owned by the caller unless a name ends in _dev;
+ *     complex arrays are interleaved (re, im) float64 pairs = numpy complex128;
+ *   - 2-D arrays are C-ordered [nx][ny] with y fastest, as numpy.meshgrid(indexing='ij')
+ *     gives in the reference (nearfield.py:117);
+ *   - one ml_ctx per GPU and per host thread; calls on one context are stream-ordered
+ *     on the context's own HIP stream and return after the work is complete unless the
+ *     function is documented as asynchronous.
+ */
+#ifndef METALENS_HIP_H
+#define METALENS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ML_ABI_VERSION 1
+
+enum {
+    ML_OK = 0,
+    ML_EINVAL = -1,   /* bad argument (shape, null pointer, order of calls)          */
+    ML_EHIP = -2,     /* a HIP runtime call failed; message carries hipGetErrorString */
+    ML_ENOMEM = -3,   /* device allocation failed                                     */
+    ML_ESTATE = -4,   /* required upload / plan missing                               */
+    ML_ERCCL = -5     /* RCCL failure or librccl not loadable                         */
+};
+
+typedef struct ml_ctx ml_ctx;
+
+/* ---- context -------------------------------------------------------------------- */
+int ml_abi_version(void);
+const char *ml_last_error(void);
+int ml_device_count(int *count);
+int ml_ctx_create(int device, ml_ctx **out);
+void ml_ctx_destroy(ml_ctx *ctx);
+/* name[] receives the gcnArchName; cu_count / hbm_bytes may be NULL */
+int ml_device_info(ml_ctx *ctx, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- tables: GratingCollection.interpolators / HexGridSet.interpolators ------------
+ * Replaces the scipy RegularGridInterpolator objects built by the reference at
+ * grating.py:1186-1232 and lens_center.py:188-226 and evaluated at nearfield.py:310-311
+ * and :424-425.  slot >= 0 is the index in lens_periphery_summary['gratingcollection_list'],
+ * slot == -1 is the HexGridSet of the lens centre.
+ *   axis0[n0], axis1[n1], axis2[n2] : ux, uy and grating-period (or cell-index) nodes
+ *   orders[n_orders][2]             : (ox, oy), in the order the host wants them summed
+ *   order_k[n_orders][2]            : ox*2*pi and oy*2*pi as evaluated by the host
+ *   values[n_orders][n0][n1][n2][4] : complex128; last index = (x,ampfy) (x,ampfx)
+ *                                     (y,ampfy) (y,ampfx) for incident polarisation x|y
+ *   bounds[6]                       : interpolator_bounds (only [0..3] used for slot -1)
+ *   center_periods[2]               : slot -1 only: grating_list[0].grating_period,
+ *                                     .lateral_period (nearfield.py:391-392)            */
+int ml_upload_table(ml_ctx *ctx, int slot,
+                    const double *axis0, int n0, const double *axis1, int n1,
+                    const double *axis2, int n2,
+                    const int32_t *orders, const double *order_k, int n_orders,
+                    const double *values, const double *bounds, const double *center_periods);
+
+/* ---- layout: lens_periphery_summary + lens_center_summary --------------------------
+ * Replaces the per-call geometry set-up of nearfield.py:87-94,125-128,148-167,363-367.
+ *   ring_boundaries[n_rings+1] = hstack(r_min_list, r_max_list[-1])  (nearfield.py:125)
+ *   ring_r_center, ring_period, ring_dphi (= 2*pi/num_around_circle), ring_lateral
+ *   (= r_center * dphi), all [n_rings] float64 evaluated by the host in the reference's
+ *   operation order; ring_gc[n_rings] = gratingcollection_index_here_list.
+ *   cells[n_cells][3] = lens_center_summary rows (x, y, index into the HexGridSet).     */
+int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *ring_boundaries,
+                     const double *ring_r_center, const double *ring_period,
+                     const double *ring_dphi, const double *ring_lateral,
+                     const int32_t *ring_gc, int n_cells, const double *cells);
+
+/* ---- near-field synthesis: nearfield.build_nearfield (nearfield.py:66-480) ---------
+ * Scalars are evaluated by the host with the reference's own expressions so that they
+ * are bit-identical to what the reference would use.                                   */
+typedef struct ml_nearfield_params {
+    double source_x, source_y;
+    double source_z;          /* < 0; -inf selects the normally incident plane wave     */
+    double dz;                /* 0 - source_z                               (:174)      */
+    double dz2;               /* dz**2                                      (:175)      */
+    double source_z2;         /* source_z**2                                (:340)      */
+    double pol[3];            /* unit dipole / field vector for 'x','y','z' (:215)      */
+    double kvac, kvac2;       /* 2*pi/wavelength and its square             (:115,279)  */
+    double k_glass, k_glass2; /* 2*pi*n_glass/wavelength and its square     (:114,287)  */
+    double n_glass;
+    double Z0;                /* impedance of free space used by the caller (:221,308)  */
+    double H_coef;            /* c0*(2*pi/wavelength)**2*dipole_moment/(4*pi) (:213)    */
+    double dipole_moment;     /* plane wave: |E| of the incident wave       (:225-228)  */
+    int32_t plane_wave;       /* 1 if source_z == -inf                                  */
+    int32_t reserved;
+} ml_nearfield_params;
+
+/* Bound-check report, one entry per (slot, order, check) that was violated; the host
+ * turns the first one (in the reference's check order) into the reference's ValueError
+ * (nearfield.py:294-305,412-419).                                                       */
+typedef struct ml_bound_violation {
+    int32_t slot;      /* collection index, -1 = centre                                 */
+    int32_t order;     /* index into the slot's orders                                  */
+    int32_t check;     /* 0 ux<min 1 ux>max 2 uy<min 3 uy>max 4 period<min 5 period>max */
+    int32_t reserved;
+    double value;      /* extreme offending value                                       */
+    double bound;
+} ml_bound_violation;
+
+/* Synthesise Ex,Ey,Hx,Hy on the tensor grid x_pts[nx] x y_pts[ny] into the context's
+ * resident field set (device memory).  power receives the incident power through the
+ * lens (nearfield.py:474-477).  On return *n_violations is the number of entries written
+ * to violations[0..max_violations).                                                    */
+int ml_nearfield(ml_ctx *ctx, const ml_nearfield_params *p,
+                 const double *x_pts, int nx, const double *y_pts, int ny,
+                 double *power, ml_bound_violation *violations, int max_violations,
+                 int *n_violations);
+
+/* Copy the resident field set to / from host complex128 [nx][ny] arrays.  Any output
+ * pointer may be NULL.  ml_fields_upload makes caller-supplied fields resident (for the
+ * far-field entry points when the near field was produced elsewhere).                   */
+int ml_fields_download(ml_ctx *ctx, double *Ex, double *Ey, double *Hx, double *Hy);
+int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double *Ey,
+                     const double *Hx, const double *Hy);
+int ml_fields_shape(ml_ctx *ctx, int *nx, int *ny);
+
+/* ---- far field on the FFT lattice: nearfield_farfield.farfield_from_nearfield_helper
+ * (nearfield_farfield.py:77-191).  Inputs are the caller's fft2(fftshift(F)) arrays,
+ * ux_list[nx] / uy_list[ny] the un-shifted direction cosines of :35-39; P[nx][ny] is
+ * P_here_times_r2_over_uz before the caller's fftshift.                                 */
+int ml_farfield_lattice_power(ml_ctx *ctx, int nx, int ny,
+                              const double *fftEx, const double *fftEy,
+                              const double *fftHx, const double *fftHy,
+                              const double *ux_list, const double *uy_list,
+                              double dxp, double dyp, double wavelength, double n_glass,
+                              double Z0, double *P);
+
+/* ---- far field by direct aperture -> direction summation --------------------------
+ * Evaluates N(ux,uy) = dx'dy' sum J exp(-ik(x'ux + y'uy)) (nearfield_farfield.py:111-120)
+ * for an arbitrary tensor grid ux[mx] x uy[my] (or a list of mx direction pairs if
+ * pair_list != 0, then my must equal mx) as dense complex GEMMs on the fp64 matrix
+ * cores, instead of the caller-side fft2(fftshift(F)) of nearfield_farfield.py:18-20.
+ *
+ * The resident field set is rows [row0, row0+nx_local) of an nx_total x ny aperture
+ * (row0 = 0, nx_total = nx_local for a single GPU); sample j of an axis of n samples
+ * sits at (j - ceil(n/2)) * step, which is what fftshift + FFT imply on the lattice.
+ *
+ *   ml_farfield_plan      : set the geometry and directions, build the twiddle matrices
+ *   ml_farfield_transform : radiation vectors Nx,Ny,Lx,Ly [mx][my] of the resident rows
+ *                           (a partial sum when the aperture is sharded); accumulate != 0
+ *                           adds to the previous result instead of overwriting
+ *   ml_farfield_allreduce : sum the partial radiation vectors over all ranks (RCCL)
+ *   ml_farfield_project   : projection + power of :153-189 on the (reduced) vectors
+ * Any host output pointer may be NULL.                                                  */
+int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp,
+                     double wavelength, double n_glass,
+                     const double *ux, int mx, const double *uy, int my, int pair_list);
+int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate);
+int ml_farfield_allreduce(ml_ctx *ctx);
+int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi);
+int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
+ * ml_comm_unique_id fills id[128] on rank 0; the host passes it to the other ranks by
+ * any side channel; every rank then calls ml_comm_init.  ml_comm_allreduce is exposed
+ * for the benchmark's barrier / max-over-ranks timing (op: 0 sum, 1 max).               */
+int ml_comm_unique_id(uint8_t id[128]);
+int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank);
+int ml_comm_allreduce_host(ml_ctx *ctx, double *values, int count, int op);
+int ml_comm_barrier(ml_ctx *ctx);
+
+/* ---- measurement -----------------------------------------------------------------------
+ * Per-kernel HIP-event timing on the context's stream.  Kernel ids: */
+enum {
+    ML_K_NEARFIELD = 0,
+    ML_K_TWIDDLE = 1,
+    ML_K_ZGEMM_STAGE1 = 2,
+    ML_K_ZGEMM_STAGE2 = 3,
+    ML_K_PROJECT = 4,
+    ML_K_LATTICE_POWER = 5,
+    ML_K_COLDOT = 6,
+    ML_K_COUNT = 7
+};
+int ml_profile_enable(ml_ctx *ctx, int on);
+int ml_profile_reset(ml_ctx *ctx);
+int ml_profile_get(ml_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
+/* wait for everything queued on the context's stream */
+int ml_sync(ml_ctx *ctx);
+/* asynchronous variants used by the benchmark's timed region: queue the same work as
+ * ml_nearfield / ml_farfield_transform / ml_farfield_project without host copies or
+ * synchronisation (results stay resident; fetch them afterwards).                       */
+int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p,
+                       const double *x_pts, int nx, const double *y_pts, int ny);
+int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate);
+int ml_farfield_project_async(ml_ctx *ctx, double Z0);
+int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,
+                        int max_violations, int *n_violations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* METALENS_HIP_H */

@@ -1,0 +1,12 @@
+"""metalens_amd - MI355X-native near-field synthesis and near-to-far-field
+transform for the sbyrnes321/metalens design flow.
+
+Host code in Python (mirroring the reference's function and class names), compute
+in hand-written HIP for gfx950 behind the C ABI of include/metalens_hip.h.
+"""
+from . import constants, grating, interp, layout, lens_center, synthetic  # noqa: F401
+from .grating import Grating, GratingCollection  # noqa: F401
+from .lens_center import HexGridSet  # noqa: F401
+from .nearfield import build_nearfield, build_nearfield_big, good_fft_number  # noqa: F401
+from .nearfield_farfield import (FarfieldTransform, farfield_direct,  # noqa: F401
+                                 farfield_from_nearfield, fft_direction_cosines)

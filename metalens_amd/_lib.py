@@ -1,0 +1,208 @@
+"""ctypes binding of libmetalens_hip.so (include/metalens_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no MI355X is
+visible, every entry point of the package raises ``MetalensHipError``.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32, c_int64,
+                    c_uint8, c_void_p)
+
+import numpy as np
+
+LIB_NAME = 'libmetalens_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+K_NEARFIELD, K_TWIDDLE, K_ZGEMM_STAGE1, K_ZGEMM_STAGE2, K_PROJECT, K_LATTICE_POWER, K_COLDOT = range(7)
+KERNEL_NAMES = ('nearfield', 'twiddle', 'zgemm_stage1', 'zgemm_stage2', 'project',
+                'lattice_power', 'coldot')
+
+# every symbol include/metalens_hip.h declares (tests/test_cabi_symbols.py checks the header
+# against this list and the built library)
+SYMBOLS = (
+    'ml_abi_version', 'ml_last_error', 'ml_device_count', 'ml_ctx_create', 'ml_ctx_destroy',
+    'ml_device_info', 'ml_upload_table', 'ml_upload_layout', 'ml_nearfield',
+    'ml_fields_download', 'ml_fields_upload', 'ml_fields_shape', 'ml_farfield_lattice_power',
+    'ml_farfield_plan', 'ml_farfield_transform', 'ml_farfield_allreduce', 'ml_farfield_project',
+    'ml_farfield_download', 'ml_comm_unique_id', 'ml_comm_init', 'ml_comm_allreduce_host',
+    'ml_comm_barrier', 'ml_profile_enable', 'ml_profile_reset', 'ml_profile_get', 'ml_sync',
+    'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_project_async',
+    'ml_nearfield_result',
+)
+
+
+class MetalensHipError(RuntimeError):
+    pass
+
+
+class NearfieldParams(Structure):
+    _fields_ = [('source_x', c_double), ('source_y', c_double), ('source_z', c_double),
+                ('dz', c_double), ('dz2', c_double), ('source_z2', c_double),
+                ('pol', c_double * 3), ('kvac', c_double), ('kvac2', c_double),
+                ('k_glass', c_double), ('k_glass2', c_double), ('n_glass', c_double),
+                ('Z0', c_double), ('H_coef', c_double), ('dipole_moment', c_double),
+                ('plane_wave', c_int32), ('reserved', c_int32)]
+
+
+class BoundViolation(Structure):
+    _fields_ = [('slot', c_int32), ('order', c_int32), ('check', c_int32),
+                ('reserved', c_int32), ('value', c_double), ('bound', c_double)]
+
+
+_lib = None
+_dp = POINTER(c_double)
+_ip = POINTER(c_int32)
+
+
+def load():
+    """dlopen the library once and declare the argument types."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MetalensHipError(
+            '%s is not built; run `python -c "import __graft_entry__ as g; g.build()"` or '
+            '`make -C metalens_amd/csrc` (needs hipcc, cross-compiles for gfx950 without a GPU)'
+            % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    except OSError as e:
+        raise MetalensHipError('cannot load %s: %s' % (LIB_PATH, e))
+    lib.ml_last_error.restype = c_char_p
+    lib.ml_ctx_destroy.restype = None
+    lib.ml_ctx_create.argtypes = [c_int, POINTER(c_void_p)]
+    lib.ml_ctx_destroy.argtypes = [c_void_p]
+    lib.ml_device_count.argtypes = [POINTER(c_int)]
+    lib.ml_device_info.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]
+    lib.ml_upload_table.argtypes = [c_void_p, c_int, _dp, c_int, _dp, c_int, _dp, c_int, _ip, _dp,
+                                    c_int, _dp, _dp, _dp]
+    lib.ml_upload_layout.argtypes = [c_void_p, c_int, _dp, _dp, _dp, _dp, _dp, _ip, c_int, _dp]
+    lib.ml_nearfield.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int, _dp,
+                                 POINTER(BoundViolation), c_int, POINTER(c_int)]
+    lib.ml_nearfield_async.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int]
+    lib.ml_nearfield_result.argtypes = [c_void_p, _dp, POINTER(BoundViolation), c_int,
+                                        POINTER(c_int)]
+    lib.ml_fields_download.argtypes = [c_void_p, _dp, _dp, _dp, _dp]
+    lib.ml_fields_upload.argtypes = [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]
+    lib.ml_fields_shape.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.ml_farfield_lattice_power.argtypes = [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                              c_double, c_double, c_double, c_double, c_double, _dp]
+    lib.ml_farfield_plan.argtypes = [c_void_p, c_int, c_int, c_double, c_double, c_double,
+                                     c_double, _dp, c_int, _dp, c_int, c_int]
+    lib.ml_farfield_transform.argtypes = [c_void_p, c_int, c_int]
+    lib.ml_farfield_transform_async.argtypes = [c_void_p, c_int, c_int]
+    lib.ml_farfield_allreduce.argtypes = [c_void_p]
+    lib.ml_farfield_project.argtypes = [c_void_p, c_double, _dp, _dp, _dp]
+    lib.ml_farfield_project_async.argtypes = [c_void_p, c_double]
+    lib.ml_farfield_download.argtypes = [c_void_p, _dp, _dp, _dp, _dp]
+    lib.ml_comm_unique_id.argtypes = [POINTER(c_uint8)]
+    lib.ml_comm_init.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_int]
+    lib.ml_comm_allreduce_host.argtypes = [c_void_p, _dp, c_int, c_int]
+    lib.ml_comm_barrier.argtypes = [c_void_p]
+    lib.ml_profile_enable.argtypes = [c_void_p, c_int]
+    lib.ml_profile_reset.argtypes = [c_void_p]
+    lib.ml_profile_get.argtypes = [c_void_p, c_int, POINTER(c_int64), _dp]
+    lib.ml_sync.argtypes = [c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise MetalensHipError('libmetalens_hip error %d: %s'
+                               % (rc, load().ml_last_error().decode(errors='replace')))
+
+
+def dptr(a):
+    """pointer to a C-contiguous float64 / complex128 array (or NULL for None)"""
+    if a is None:
+        return None
+    assert a.flags['C_CONTIGUOUS'] and a.dtype in (np.float64, np.complex128)
+    return a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    assert a.flags['C_CONTIGUOUS'] and a.dtype == np.int32
+    return a.ctypes.data_as(_ip)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def c128(a):
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+class Context:
+    """One GPU.  Owns the device-resident tables, layout, field set and far-field
+    plan.  Not thread-safe; use one per host thread."""
+
+    def __init__(self, device=None):
+        lib = load()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0'))
+        n = c_int(0)
+        check(lib.ml_device_count(byref(n)))
+        if n.value < 1:
+            raise MetalensHipError('no HIP device visible: metalens_amd runs on MI355X (gfx950) '
+                                   'only and has no CPU path')
+        self._h = c_void_p()
+        check(lib.ml_ctx_create(device % n.value, byref(self._h)))
+        self.device = device % n.value
+        self.lib = lib
+        self.layout_token = None
+        self.tables_token = None
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self.lib.ml_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise MetalensHipError('context is closed')
+        return self._h
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(64)
+        cu = c_int(0)
+        mem = c_int64(0)
+        check(self.lib.ml_device_info(self.handle, name, 64, byref(cu), byref(mem)))
+        return {'arch': name.value.decode(), 'cu_count': cu.value, 'hbm_bytes': mem.value}
+
+    def sync(self):
+        check(self.lib.ml_sync(self.handle))
+
+    def profile(self, on=True):
+        check(self.lib.ml_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        check(self.lib.ml_profile_reset(self.handle))
+
+    def profile_get(self):
+        out = {}
+        for k, name in enumerate(KERNEL_NAMES):
+            n = c_int64(0)
+            ms = c_double(0)
+            check(self.lib.ml_profile_get(self.handle, k, byref(n), byref(ms)))
+            out[name] = {'launches': n.value, 'total_ms': ms.value}
+        return out
+
+
+_default = None
+
+
+def default_context():
+    """process-wide context on device LOCAL_RANK (or 0)"""
+    global _default
+    if _default is None or not _default._h:
+        _default = Context()
+    return _default

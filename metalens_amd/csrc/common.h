@@ -1,0 +1,206 @@
+// Internal declarations shared by the translation units of libmetalens_hip.so.
+// gfx950 (MI355X) only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "metalens_hip.h"
+
+namespace ml {
+
+void set_error(const char *fmt, ...);
+
+#define ML_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            ml::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                          __LINE__);                                                      \
+            return (e_ == hipErrorOutOfMemory) ? ML_ENOMEM : ML_EHIP;                     \
+        }                                                                                 \
+    } while (0)
+
+#define ML_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            ml::set_error(__VA_ARGS__);  \
+            return ML_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define ML_TRY(expr)          \
+    do {                      \
+        int rc_ = (expr);     \
+        if (rc_ != ML_OK) return rc_; \
+    } while (0)
+
+// A device allocation that only grows.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t want) {
+        if (want <= bytes) return ML_OK;
+        if (p) {
+            (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return ML_ENOMEM;
+        }
+        bytes = want;
+        return ML_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+constexpr int MAX_SLOTS = 32;      // grating collections per lens (+1 centre)
+constexpr int MAX_ORDERS = 32;     // diffraction orders per table
+
+// Device-side view of one packed table (GratingCollection or HexGridSet).
+struct TableDesc {
+    const double *axis0;   // ux nodes [n0]
+    const double *axis1;   // uy nodes [n1]
+    const double *values;  // complex [n_orders][n0][n1][n2][4]
+    const double *order_k; // [n_orders][2]  (ox*2*pi, oy*2*pi)
+    int n0, n1, n2, n_orders;
+    double bounds[6];
+    double center_kx[MAX_ORDERS];  // centre only: ox*2*pi/x_period, per order
+    double center_ky[MAX_ORDERS];
+};
+
+struct TableSlot {
+    bool present = false;
+    int n0 = 0, n1 = 0, n2 = 0, n_orders = 0;
+    DevBuf axis0, axis1, values, order_k;
+    std::vector<double> h_axis2;
+    std::vector<double> h_order_k;
+    double bounds[6] = {0, 0, 0, 0, 0, 0};
+    double center_periods[2] = {0, 0};
+};
+
+struct KernelTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+
+struct Profile {
+    bool on = false;
+    int64_t launches[ML_K_COUNT] = {0};
+    double total_ms[ML_K_COUNT] = {0};
+    // events are recorded around each launch and harvested lazily
+    struct Pending {
+        int kernel;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+struct FarfieldPlan {
+    bool ready = false;
+    int nx_total = 0, ny = 0, mx = 0, my = 0, pair_list = 0;
+    double dxp = 0, dyp = 0, wavelength = 0, n_glass = 0;
+    DevBuf ux, uy;       // direction cosines
+    DevBuf tw_x;         // complex [mx][nx_total]   exp(-i k x' ux)   (A operand of stage 2)
+    DevBuf tw_y;         // complex [ny][my]         exp(-i k y' uy)   (B operand of stage 1)
+    DevBuf stage1;       // complex [4][nx_local][my]
+    DevBuf vectors;      // complex [4][mx][my]  (Nx, Ny, Lx, Ly)  or [4][mx] for a pair list
+    DevBuf power;        // double  [mx][my]
+    DevBuf amplitudes;   // complex [2][mx][my]  (a_theta, a_phi)
+    bool have_vectors = false;
+};
+
+}  // namespace ml
+
+struct ml_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char arch[64] = {0};
+    int cu_count = 0;
+    int64_t hbm_bytes = 0;
+
+    // tables
+    ml::TableSlot slots[ml::MAX_SLOTS];
+    ml::TableSlot center;
+    ml::DevBuf table_desc;   // TableDesc[MAX_SLOTS + 1], last = centre
+    bool tables_dirty = true;
+
+    // layout
+    bool have_layout = false;
+    int n_rings = 0, n_cells = 0;
+    std::vector<double> h_ring_period;
+    std::vector<int32_t> h_ring_gc;
+    ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
+    ml::DevBuf ring_i2, ring_t2;     // per-ring location on the table's period axis
+    ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
+    int lut_buckets = 0;
+    double lut_inv_h = 0;
+    ml::DevBuf cell_x, cell_y, cell_which, cell_index, bin_start;
+    int bins_x = 0, bins_y = 0;
+    double bin_x0 = 0, bin_y0 = 0, bin_h = 0;
+
+    // resident field set: complex [4][nx][ny]
+    int nx = 0, ny = 0;
+    ml::DevBuf fields;
+    ml::DevBuf lattice_in;   // staging for ml_farfield_lattice_power
+
+    // near-field scratch
+    ml::DevBuf x_pts, y_pts, partial_power, power, violations;
+    int nf_blocks = 0;
+
+    ml::FarfieldPlan plan;
+    ml::Profile prof;
+
+    // RCCL
+    void *comm = nullptr;
+    int n_ranks = 1, rank = 0;
+    ml::DevBuf comm_scratch;
+};
+
+namespace ml {
+
+// profile helpers (ctx.hip)
+void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b);
+void prof_end(ml_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b);
+int prof_harvest(ml_ctx *ctx);
+
+struct ProfScope {
+    ml_ctx *ctx;
+    int kernel;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ml_ctx *c, int k) : ctx(c), kernel(k) { prof_begin(ctx, kernel, &a, &b); }
+    ~ProfScope() { prof_end(ctx, kernel, a, b); }
+};
+
+// zgemm.hip: C[M][N] (+)= alpha * A[M][K] * B[K][N], complex128 interleaved, row-major.
+// batch > 1 strides A, B, C by the given element (complex) strides.
+// alpha[batch] are real scale factors, one per batch entry (batch <= 4).
+int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const double *A,
+          int64_t lda, int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double *C,
+          int64_t ldc, int64_t strideC, int batch, int accumulate);
+// out[f][d] (+)= alpha[f] * sum_j TX[d][j0 + j] * G[f][j][d]   (pair-list stage 2)
+int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *alpha4,
+            const double *TX, int64_t ldtx, int j0, const double *G, double *out, int accumulate);
+// comm.hip
+void comm_release(ml_ctx *ctx);
+
+// nearfield.hip
+int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny);
+
+}  // namespace ml

@@ -1,0 +1,510 @@
+// Context, uploads (tables / layout / fields), near-field entry points, profiling.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+
+namespace ml {
+
+static thread_local std::string g_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+static int h2d(ml_ctx *ctx, DevBuf &dst, const void *src, size_t bytes) {
+    ML_TRY(dst.reserve(std::max<size_t>(bytes, 16)));
+    if (bytes) ML_HIP(hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return ML_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------
+static hipEvent_t take_event(ml_ctx *ctx) {
+    if (!ctx->prof.pool.empty()) {
+        hipEvent_t e = ctx->prof.pool.back();
+        ctx->prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b) {
+    (void)kernel;
+    if (!ctx->prof.on) return;
+    *a = take_event(ctx);
+    *b = take_event(ctx);
+    (void)hipEventRecord(*a, ctx->stream);
+}
+
+void prof_end(ml_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b) {
+    if (!ctx->prof.on || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof.pending.push_back({kernel, a, b});
+}
+
+int prof_harvest(ml_ctx *ctx) {
+    for (auto &pd : ctx->prof.pending) {
+        ML_HIP(hipEventSynchronize(pd.b));
+        float ms = 0.f;
+        ML_HIP(hipEventElapsedTime(&ms, pd.a, pd.b));
+        ctx->prof.launches[pd.kernel] += 1;
+        ctx->prof.total_ms[pd.kernel] += ms;
+        ctx->prof.pool.push_back(pd.a);
+        ctx->prof.pool.push_back(pd.b);
+    }
+    ctx->prof.pending.clear();
+    return ML_OK;
+}
+
+// ---- table descriptors ---------------------------------------------------------------------
+static int refresh_table_desc(ml_ctx *ctx) {
+    if (!ctx->tables_dirty) return ML_OK;
+    std::vector<TableDesc> h(MAX_SLOTS + 1);
+    memset(h.data(), 0, h.size() * sizeof(TableDesc));
+    for (int s = 0; s <= MAX_SLOTS; ++s) {
+        const TableSlot &t = (s == MAX_SLOTS) ? ctx->center : ctx->slots[s];
+        if (!t.present) continue;
+        TableDesc &d = h[s];
+        d.axis0 = t.axis0.as<double>();
+        d.axis1 = t.axis1.as<double>();
+        d.values = t.values.as<double>();
+        d.order_k = t.order_k.as<double>();
+        d.n0 = t.n0;
+        d.n1 = t.n1;
+        d.n2 = t.n2;
+        d.n_orders = t.n_orders;
+        for (int k = 0; k < 6; ++k) d.bounds[k] = t.bounds[k];
+        if (s == MAX_SLOTS) {
+            // nearfield.py:395-396: ox * 2*pi/x_period - a scalar in the reference
+            for (int o = 0; o < t.n_orders; ++o) {
+                d.center_kx[o] = t.h_order_k[2 * o] / t.center_periods[0];
+                d.center_ky[o] = t.h_order_k[2 * o + 1] / t.center_periods[1];
+            }
+        }
+    }
+    ML_TRY(h2d(ctx, ctx->table_desc, h.data(), h.size() * sizeof(TableDesc)));
+    ML_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    ctx->tables_dirty = false;
+    return ML_OK;
+}
+
+// Per-ring location on the period axis of the ring's own table: scipy's find_indices
+// arithmetic, evaluated once per ring instead of once per sample (the period is a
+// per-ring constant, nearfield.py:154).
+static int refresh_ring_locations(ml_ctx *ctx) {
+    std::vector<int32_t> i2(ctx->n_rings, 0);
+    std::vector<double> t2(ctx->n_rings, 0.0);
+    for (int r = 0; r < ctx->n_rings; ++r) {
+        const int slot = ctx->h_ring_gc[r];
+        if (slot < 0 || slot >= MAX_SLOTS || !ctx->slots[slot].present) {
+            set_error("ring %d uses grating collection %d, which has no uploaded table", r, slot);
+            return ML_ESTATE;
+        }
+        const std::vector<double> &ax = ctx->slots[slot].h_axis2;
+        const double x = ctx->h_ring_period[r];
+        int i = 0;
+        for (int a = 1; a < (int)ax.size() - 1; ++a)
+            if (ax[a] <= x) i = a;
+        i2[r] = i;
+        t2[r] = (x - ax[i]) / (ax[i + 1] - ax[i]);
+    }
+    ML_TRY(h2d(ctx, ctx->ring_i2, i2.data(), i2.size() * sizeof(int32_t)));
+    ML_TRY(h2d(ctx, ctx->ring_t2, t2.data(), t2.size() * sizeof(double)));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return ML_OK;
+}
+
+}  // namespace ml
+
+using namespace ml;
+
+extern "C" {
+
+int ml_abi_version(void) { return ML_ABI_VERSION; }
+
+const char *ml_last_error(void) { return g_error.c_str(); }
+
+int ml_device_count(int *count) {
+    ML_REQUIRE(count, "count is NULL");
+    ML_HIP(hipGetDeviceCount(count));
+    return ML_OK;
+}
+
+int ml_ctx_create(int device, ml_ctx **out) {
+    ML_REQUIRE(out, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    ML_HIP(hipGetDeviceCount(&n));
+    ML_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    ML_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    ML_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("libmetalens_hip is built for gfx950 (MI355X) only; device %d is %s", device,
+                  prop.gcnArchName);
+        return ML_EINVAL;
+    }
+    ml_ctx *ctx = new ml_ctx();
+    ctx->device = device;
+    snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return ML_EHIP;
+    }
+    *out = ctx;
+    return ML_OK;
+}
+
+void ml_ctx_destroy(ml_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
+    for (auto &s : ctx->slots) {
+        s.axis0.release();
+        s.axis1.release();
+        s.values.release();
+        s.order_k.release();
+    }
+    ctx->center.axis0.release();
+    ctx->center.axis1.release();
+    ctx->center.values.release();
+    ctx->center.order_k.release();
+    DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
+                      &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
+                      &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
+                      &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
+                      &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
+                      &ctx->violations, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
+                      &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
+                      &ctx->plan.amplitudes, &ctx->comm_scratch, &ctx->lattice_in};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &pd : ctx->prof.pending) {
+        (void)hipEventDestroy(pd.a);
+        (void)hipEventDestroy(pd.b);
+    }
+    for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int ml_device_info(ml_ctx *ctx, char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    if (name && name_len > 0) snprintf(name, name_len, "%s", ctx->arch);
+    if (cu_count) *cu_count = ctx->cu_count;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return ML_OK;
+}
+
+int ml_sync(ml_ctx *ctx) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return ML_OK;
+}
+
+int ml_upload_table(ml_ctx *ctx, int slot, const double *axis0, int n0, const double *axis1,
+                    int n1, const double *axis2, int n2, const int32_t *orders,
+                    const double *order_k, int n_orders, const double *values,
+                    const double *bounds, const double *center_periods) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(slot >= -1 && slot < MAX_SLOTS, "slot %d out of range [-1, %d)", slot, MAX_SLOTS);
+    ML_REQUIRE(axis0 && axis1 && axis2 && orders && order_k && values && bounds, "NULL argument");
+    ML_REQUIRE(n0 >= 2 && n1 >= 2 && n2 >= 2, "each table axis needs >= 2 nodes (%d,%d,%d)", n0,
+               n1, n2);
+    ML_REQUIRE(n_orders >= 1 && n_orders <= MAX_ORDERS, "n_orders %d out of range [1, %d]",
+               n_orders, MAX_ORDERS);
+    ML_REQUIRE(slot >= 0 || center_periods, "the centre table needs center_periods");
+    ML_HIP(hipSetDevice(ctx->device));
+    TableSlot &t = (slot < 0) ? ctx->center : ctx->slots[slot];
+    ML_TRY(h2d(ctx, t.axis0, axis0, n0 * sizeof(double)));
+    ML_TRY(h2d(ctx, t.axis1, axis1, n1 * sizeof(double)));
+    ML_TRY(h2d(ctx, t.order_k, order_k, 2 * n_orders * sizeof(double)));
+    ML_TRY(h2d(ctx, t.values, values, (size_t)n_orders * n0 * n1 * n2 * 4 * 2 * sizeof(double)));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    t.n0 = n0;
+    t.n1 = n1;
+    t.n2 = n2;
+    t.n_orders = n_orders;
+    t.h_axis2.assign(axis2, axis2 + n2);
+    t.h_order_k.assign(order_k, order_k + 2 * n_orders);
+    for (int k = 0; k < 6; ++k) t.bounds[k] = bounds[k];
+    if (center_periods) {
+        t.center_periods[0] = center_periods[0];
+        t.center_periods[1] = center_periods[1];
+    }
+    t.present = true;
+    ctx->tables_dirty = true;
+    return ML_OK;
+}
+
+int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_center,
+                     const double *period, const double *dphi, const double *lateral,
+                     const int32_t *ring_gc, int n_cells, const double *cells) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(n_rings >= 1 && B && r_center && period && dphi && lateral && ring_gc,
+               "ring arrays missing (n_rings=%d)", n_rings);
+    ML_REQUIRE(n_cells >= 0 && (n_cells == 0 || cells), "cell array missing");
+    for (int r = 0; r < n_rings; ++r)
+        ML_REQUIRE(B[r] <= B[r + 1], "ring boundaries must be ascending (ring %d)", r);
+    ML_HIP(hipSetDevice(ctx->device));
+    ctx->have_layout = false;
+    ctx->n_rings = n_rings;
+    ML_TRY(h2d(ctx, ctx->ring_boundaries, B, (n_rings + 1) * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_r_center, r_center, n_rings * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_period, period, n_rings * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_dphi, dphi, n_rings * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_lateral, lateral, n_rings * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_gc, ring_gc, n_rings * sizeof(int32_t)));
+    ctx->h_ring_period.assign(period, period + n_rings);
+    ctx->h_ring_gc.assign(ring_gc, ring_gc + n_rings);
+
+    // uniform-in-r lookup for searchsorted(boundaries, r, 'left'):
+    // lut[b] = number of boundaries strictly below the lower edge of bucket b
+    const int buckets = 16384;
+    const double r_max = B[n_rings];
+    ML_REQUIRE(r_max > 0, "outer lens radius must be positive");
+    const double h = r_max / buckets;
+    std::vector<int32_t> lut(buckets);
+    int idx = 0;
+    for (int b = 0; b < buckets; ++b) {
+        const double edge = b * h;
+        while (idx <= n_rings && B[idx] < edge) ++idx;
+        lut[b] = idx;
+    }
+    ML_TRY(h2d(ctx, ctx->ring_lut, lut.data(), lut.size() * sizeof(int32_t)));
+    ctx->lut_buckets = buckets;
+    ctx->lut_inv_h = 1.0 / h;
+
+    // centre cells -> uniform grid of bins (about one cell per bin), cells stored in bin
+    // order; within a bin the original order is kept (ties resolve to the lowest index)
+    ctx->n_cells = n_cells;
+    if (n_cells > 0) {
+        double x0 = cells[0], x1 = cells[0], y0 = cells[1], y1 = cells[1];
+        for (int c = 0; c < n_cells; ++c) {
+            x0 = std::min(x0, cells[3 * c]);
+            x1 = std::max(x1, cells[3 * c]);
+            y0 = std::min(y0, cells[3 * c + 1]);
+            y1 = std::max(y1, cells[3 * c + 1]);
+        }
+        double wx = x1 - x0, wy = y1 - y0;
+        double hbin = std::sqrt(std::max(wx * wy, 1e-300) / n_cells);
+        if (!(hbin > 0) || !std::isfinite(hbin)) hbin = 1.0;
+        if (wx <= 0 && wy <= 0) hbin = 1.0;
+        int bxn = (int)std::min<double>(std::floor(wx / hbin) + 1, 8192);
+        int byn = (int)std::min<double>(std::floor(wy / hbin) + 1, 8192);
+        bxn = std::max(bxn, 1);
+        byn = std::max(byn, 1);
+        // if the bin count was clipped, grow the bin so that the grid still covers the box
+        hbin = std::max(hbin, std::max(wx / bxn, wy / byn) * (1 + 1e-12));
+        std::vector<int32_t> bin_of(n_cells), start((size_t)bxn * byn + 1, 0);
+        for (int c = 0; c < n_cells; ++c) {
+            int bx = std::min(std::max((int)std::floor((cells[3 * c] - x0) / hbin), 0), bxn - 1);
+            int by = std::min(std::max((int)std::floor((cells[3 * c + 1] - y0) / hbin), 0), byn - 1);
+            bin_of[c] = bx * byn + by;
+            start[bin_of[c] + 1]++;
+        }
+        for (size_t b = 0; b < (size_t)bxn * byn; ++b) start[b + 1] += start[b];
+        std::vector<int32_t> fill(start.begin(), start.end() - 1);
+        std::vector<double> sx(n_cells), sy(n_cells);
+        std::vector<int32_t> sw(n_cells), si(n_cells);
+        for (int c = 0; c < n_cells; ++c) {
+            const int at = fill[bin_of[c]]++;
+            sx[at] = cells[3 * c];
+            sy[at] = cells[3 * c + 1];
+            sw[at] = (int32_t)cells[3 * c + 2];   // .astype(int): truncation (nearfield.py:367)
+            si[at] = c;
+        }
+        ML_TRY(h2d(ctx, ctx->cell_x, sx.data(), n_cells * sizeof(double)));
+        ML_TRY(h2d(ctx, ctx->cell_y, sy.data(), n_cells * sizeof(double)));
+        ML_TRY(h2d(ctx, ctx->cell_which, sw.data(), n_cells * sizeof(int32_t)));
+        ML_TRY(h2d(ctx, ctx->cell_index, si.data(), n_cells * sizeof(int32_t)));
+        ML_TRY(h2d(ctx, ctx->bin_start, start.data(), start.size() * sizeof(int32_t)));
+        ML_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->bins_x = bxn;
+        ctx->bins_y = byn;
+        ctx->bin_x0 = x0;
+        ctx->bin_y0 = y0;
+        ctx->bin_h = hbin;
+    }
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->have_layout = true;
+    ctx->tables_dirty = true;   // per-ring table locations depend on the ring periods
+    return ML_OK;
+}
+
+static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const double *x_pts,
+                             int nx, const double *y_pts, int ny) {
+    ML_REQUIRE(ctx && p && x_pts && y_pts, "NULL argument");
+    ML_REQUIRE(nx >= 1 && ny >= 1, "empty grid (%d x %d)", nx, ny);
+    if (!ctx->have_layout) {
+        set_error("ml_upload_layout has not been called");
+        return ML_ESTATE;
+    }
+    ML_HIP(hipSetDevice(ctx->device));
+    if (ctx->n_cells > 0 && !ctx->center.present) {
+        set_error("centre cells present but no HexGridSet table uploaded (slot -1)");
+        return ML_ESTATE;
+    }
+    if (ctx->tables_dirty) {
+        ML_TRY(refresh_table_desc(ctx));
+        ML_TRY(refresh_ring_locations(ctx));
+    }
+    ML_TRY(h2d(ctx, ctx->x_pts, x_pts, nx * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->y_pts, y_pts, ny * sizeof(double)));
+    const size_t plane = (size_t)nx * ny;
+    ML_TRY(ctx->fields.reserve(4 * plane * 2 * sizeof(double)));
+    ctx->nx = nx;
+    ctx->ny = ny;
+    const int blocks = ((ny + 255) / 256) * nx;
+    ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
+    ML_TRY(ctx->power.reserve(sizeof(double)));
+    const size_t viol_bytes = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
+    ML_TRY(ctx->violations.reserve(viol_bytes));
+    ML_HIP(hipMemsetAsync(ctx->violations.p, 0, viol_bytes, ctx->stream));
+    ctx->plan.have_vectors = false;
+    return nearfield_launch(ctx, p, nx, ny);
+}
+
+int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p, const double *x_pts, int nx,
+                       const double *y_pts, int ny) {
+    return nearfield_prepare(ctx, p, x_pts, nx, y_pts, ny);
+}
+
+static double decode_key(unsigned long long k, int check) {
+    if ((check & 1) == 0) k = ~k;
+    unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    double v;
+    memcpy(&v, &b, sizeof v);
+    return v;
+}
+
+int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,
+                        int max_violations, int *n_violations) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_HIP(hipSetDevice(ctx->device));
+    const size_t n_keys = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6;
+    std::vector<unsigned long long> keys(n_keys);
+    double pw = 0;
+    ML_HIP(hipMemcpyAsync(&pw, ctx->power.p, sizeof pw, hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipMemcpyAsync(keys.data(), ctx->violations.p, n_keys * sizeof(unsigned long long),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    ML_TRY(prof_harvest(ctx));
+    if (power) *power = pw;
+    int count = 0;
+    // reference check order: collections in list order, then the centre; per order; ux<, ux>,
+    // uy<, uy>, period<, period>
+    for (int s = 0; s <= MAX_SLOTS; ++s) {
+        const TableSlot &t = (s == MAX_SLOTS) ? ctx->center : ctx->slots[s];
+        if (!t.present) continue;
+        for (int o = 0; o < t.n_orders; ++o)
+            for (int c = 0; c < 6; ++c) {
+                const unsigned long long k = keys[((size_t)s * MAX_ORDERS + o) * 6 + c];
+                if (k == 0) continue;
+                if (violations && count < max_violations) {
+                    ml_bound_violation &v = violations[count];
+                    v.slot = (s == MAX_SLOTS) ? -1 : s;
+                    v.order = o;
+                    v.check = c;
+                    v.reserved = 0;
+                    v.value = decode_key(k, c);
+                    v.bound = t.bounds[c];
+                }
+                ++count;
+            }
+    }
+    if (n_violations) *n_violations = count;
+    return ML_OK;
+}
+
+int ml_nearfield(ml_ctx *ctx, const ml_nearfield_params *p, const double *x_pts, int nx,
+                 const double *y_pts, int ny, double *power, ml_bound_violation *violations,
+                 int max_violations, int *n_violations) {
+    ML_TRY(nearfield_prepare(ctx, p, x_pts, nx, y_pts, ny));
+    return ml_nearfield_result(ctx, power, violations, max_violations, n_violations);
+}
+
+int ml_fields_shape(ml_ctx *ctx, int *nx, int *ny) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    if (nx) *nx = ctx->nx;
+    if (ny) *ny = ctx->ny;
+    return ML_OK;
+}
+
+int ml_fields_download(ml_ctx *ctx, double *Ex, double *Ey, double *Hx, double *Hy) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->nx == 0 || ctx->ny == 0) {
+        set_error("no resident field set");
+        return ML_ESTATE;
+    }
+    ML_HIP(hipSetDevice(ctx->device));
+    const size_t plane_bytes = (size_t)ctx->nx * ctx->ny * 2 * sizeof(double);
+    double *dst[4] = {Ex, Ey, Hx, Hy};
+    for (int f = 0; f < 4; ++f)
+        if (dst[f])
+            ML_HIP(hipMemcpyAsync(dst[f], (char *)ctx->fields.p + f * plane_bytes, plane_bytes,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return ML_OK;
+}
+
+int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double *Ey,
+                     const double *Hx, const double *Hy) {
+    ML_REQUIRE(ctx && Ex && Ey && Hx && Hy, "NULL argument");
+    ML_REQUIRE(nx >= 1 && ny >= 1, "empty grid (%d x %d)", nx, ny);
+    ML_HIP(hipSetDevice(ctx->device));
+    const size_t plane_bytes = (size_t)nx * ny * 2 * sizeof(double);
+    ML_TRY(ctx->fields.reserve(4 * plane_bytes));
+    const double *src[4] = {Ex, Ey, Hx, Hy};
+    for (int f = 0; f < 4; ++f)
+        ML_HIP(hipMemcpyAsync((char *)ctx->fields.p + f * plane_bytes, src[f], plane_bytes,
+                              hipMemcpyHostToDevice, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->nx = nx;
+    ctx->ny = ny;
+    ctx->plan.have_vectors = false;
+    return ML_OK;
+}
+
+int ml_profile_enable(ml_ctx *ctx, int on) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ctx->prof.on = on != 0;
+    return ML_OK;
+}
+
+int ml_profile_reset(ml_ctx *ctx) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    ML_TRY(prof_harvest(ctx));
+    for (int k = 0; k < ML_K_COUNT; ++k) {
+        ctx->prof.launches[k] = 0;
+        ctx->prof.total_ms[k] = 0;
+    }
+    return ML_OK;
+}
+
+int ml_profile_get(ml_ctx *ctx, int kernel, int64_t *launches, double *total_ms) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(kernel >= 0 && kernel < ML_K_COUNT, "kernel id %d out of range", kernel);
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(prof_harvest(ctx));
+    if (launches) *launches = ctx->prof.launches[kernel];
+    if (total_ms) *total_ms = ctx->prof.total_ms[kernel];
+    return ML_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// Near-to-far-field transform on MI355X.
+//
+//   * twiddle_kernel        exp(-i k x' u) matrices, phase reduced mod one turn in
+//                           double-double before the sin/cos (phases reach ~1e4 rad)
+//   * ml_farfield_transform aperture -> direction sum as two complex GEMMs (zgemm.hip)
+//   * project_kernel        theta/phi projection and radiated power, elementwise,
+//                           restating nearfield_farfield.py:153-189 operation by operation
+//   * ml_farfield_lattice_power   the same projection on the caller's FFT'd fields
+//                           (drop-in for farfield_from_nearfield_helper)
+#include <cmath>
+
+#include "common.h"
+
+namespace ml {
+
+// 2*pi split into two doubles
+#define ML_TWO_PI_HI 6.283185307179586232e+00
+#define ML_TWO_PI_LO 2.449293598294706414e-16
+
+// out[r][c] = exp(-2 pi i * frac(s * (sample - center) * u[dir])),
+// (sample, dir) = (r, c) if sample_major else (c, r).
+__global__ __launch_bounds__(256) void twiddle_kernel(double2 *out, int rows, int cols,
+                                                      int sample_major, int center, double s_hi,
+                                                      double s_lo, const double *u) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    const int sample = sample_major ? r : c;
+    const int dir = sample_major ? c : r;
+    const double kk = (double)(sample - center);
+    const double uu = u[dir];
+    // p = kk * s  (double-double), q = p * u (double-double)
+    const double p_hi = kk * s_hi;
+    const double p_lo = fma(kk, s_hi, -p_hi) + kk * s_lo;
+    const double q_hi = p_hi * uu;
+    const double q_lo = fma(p_hi, uu, -q_hi) + p_lo * uu;
+    const double f = (q_hi - rint(q_hi)) + q_lo;   // turns, |f| <= 0.5 (+ tiny)
+    const double a_hi = f * ML_TWO_PI_HI;
+    const double ang = a_hi + (fma(f, ML_TWO_PI_HI, -a_hi) + f * ML_TWO_PI_LO);
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    out[(size_t)r * cols + c] = make_double2(cs, -sn);
+}
+
+struct ProjArgs {
+    const double2 *Nx, *Ny, *Lx, *Ly;   // each [mx][my]
+    const double *ux, *uy;
+    int mx, my, pair_list;
+    // N, L = sign * (fft * dxp) * dyp when from_fft (nearfield_farfield.py:135-138)
+    int from_fft;
+    double dxp, dyp;
+    double Z, coef;                      // Z0/n_glass and (2 pi n/lambda)^2 / (32 pi^2 Z)
+    double *P;
+    double2 *a_theta, *a_phi;            // may be null
+};
+
+__device__ __forceinline__ double2 cscale(double2 a, double s) {
+    return make_double2(a.x * s, a.y * s);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) {
+    return make_double2(a.x + b.x, a.y + b.y);
+}
+__device__ __forceinline__ double2 cneg(double2 a) { return make_double2(-a.x, -a.y); }
+
+__global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= a.my) return;
+    const size_t at = (size_t)i * a.my + j;
+    const double ux = a.ux[i];
+    const double uy = a.pair_list ? a.uy[i] : a.uy[j];
+    double2 Nx = a.Nx[at], Ny = a.Ny[at], Lx = a.Lx[at], Ly = a.Ly[at];
+    if (a.from_fft) {
+        // Nx = -fftHy*dxp*dyp, Ny = fftHx*dxp*dyp, Lx = fftEy*dxp*dyp, Ly = -fftEx*dxp*dyp
+        Nx = cscale(cscale(cneg(Nx), a.dxp), a.dyp);
+        Ny = cscale(cscale(Ny, a.dxp), a.dyp);
+        Lx = cscale(cscale(Lx, a.dxp), a.dyp);
+        Ly = cscale(cscale(cneg(Ly), a.dxp), a.dyp);
+    }
+    double uz = 1 - ux * ux - uy * uy;
+    uz = (uz < 0) ? NAN : sqrt(uz);
+    const double sintheta = sqrt(ux * ux + uy * uy);
+    const double scl = 1.0 / (sintheta + 1e-9);   // numpy: complex / real = multiply by 1/x
+    double2 Nth, Nph, Lth, Lph;
+    if (ux == 0 && uy == 0) {
+        Nth = Nx;
+        Nph = Ny;
+        Lth = Lx;
+        Lph = Ly;
+    } else {
+        Nth = cadd(cscale(cscale(cscale(Nx, ux), uz), scl), cscale(cscale(cscale(Ny, uy), uz), scl));
+        Nph = cadd(cscale(cscale(cneg(Nx), uy), scl), cscale(cscale(Ny, ux), scl));
+        Lth = cadd(cscale(cscale(cscale(Lx, ux), uz), scl), cscale(cscale(cscale(Ly, uy), uz), scl));
+        Lph = cadd(cscale(cscale(cneg(Lx), uy), scl), cscale(cscale(Ly, ux), scl));
+    }
+    const double2 at_ = cadd(Lph, cscale(Nth, a.Z));            // Lphi + Z*Ntheta
+    const double2 ap_ = cadd(Lth, cneg(cscale(Nph, a.Z)));      // Ltheta - Z*Nphi
+    const double m1 = hypot(at_.x, at_.y), m2 = hypot(ap_.x, ap_.y);
+    double P = (a.coef * (m1 * m1 + m2 * m2)) / (uz + 1e-5);
+    P *= 2;
+    a.P[at] = P;
+    if (a.a_theta) a.a_theta[at] = at_;
+    if (a.a_phi) a.a_phi[at] = ap_;
+}
+
+static int launch_twiddle(ml_ctx *ctx, double *out, int rows, int cols, int sample_major, int n,
+                          double step, double wavelength, double n_glass, const double *u_dev) {
+    // turns per (sample index x direction cosine): n_glass * step / wavelength, in extended
+    // precision on the host, split into two doubles
+    const long double s = (long double)n_glass * (long double)step / (long double)wavelength;
+    const double s_hi = (double)s;
+    const double s_lo = (double)(s - (long double)s_hi);
+    const int center = n - n / 2;   // ceil(n/2): fftshift moves sample j to (j + n//2) mod n
+    ProfScope scope(ctx, ML_K_TWIDDLE);
+    hipLaunchKernelGGL(twiddle_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<double2 *>(out), rows, cols, sample_major, center, s_hi,
+                       s_lo, u_dev);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id) {
+    ProfScope scope(ctx, kernel_id);
+    hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0, ctx->stream,
+                       a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+}  // namespace ml
+
+using namespace ml;
+
+extern "C" {
+
+int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, double wavelength,
+                     double n_glass, const double *ux, int mx, const double *uy, int my,
+                     int pair_list) {
+    ML_REQUIRE(ctx && ux && uy, "NULL argument");
+    ML_REQUIRE(nx_total >= 1 && ny >= 1 && mx >= 1 && my >= 1, "empty plan");
+    ML_REQUIRE(!pair_list || mx == my, "a pair list needs len(ux) == len(uy)");
+    ML_REQUIRE(wavelength > 0 && n_glass > 0 && dxp != 0 && dyp != 0, "bad geometry");
+    ML_HIP(hipSetDevice(ctx->device));
+    FarfieldPlan &pl = ctx->plan;
+    pl.ready = false;
+    pl.have_vectors = false;
+    pl.nx_total = nx_total;
+    pl.ny = ny;
+    pl.mx = mx;
+    pl.my = my;
+    pl.pair_list = pair_list;
+    pl.dxp = dxp;
+    pl.dyp = dyp;
+    pl.wavelength = wavelength;
+    pl.n_glass = n_glass;
+    ML_TRY(pl.ux.reserve(mx * sizeof(double)));
+    ML_TRY(pl.uy.reserve(my * sizeof(double)));
+    ML_HIP(hipMemcpyAsync(pl.ux.p, ux, mx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ML_HIP(hipMemcpyAsync(pl.uy.p, uy, my * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ML_TRY(pl.tw_x.reserve((size_t)mx * nx_total * 2 * sizeof(double)));
+    ML_TRY(pl.tw_y.reserve((size_t)ny * my * 2 * sizeof(double)));
+    const size_t out_elems = pair_list ? (size_t)mx : (size_t)mx * my;
+    ML_TRY(pl.vectors.reserve(4 * out_elems * 2 * sizeof(double)));
+    ML_TRY(pl.power.reserve(out_elems * sizeof(double)));
+    ML_TRY(pl.amplitudes.reserve(2 * out_elems * 2 * sizeof(double)));
+    // tw_y[k][j]: sample-major, B operand of stage 1
+    ML_TRY(launch_twiddle(ctx, pl.tw_y.as<double>(), ny, my, 1, ny, dyp, wavelength, n_glass,
+                          pl.uy.as<double>()));
+    // tw_x: direction-major [mx][nx_total] (A operand of stage 2) for a tensor grid,
+    // sample-major [nx_total][mx] for a pair list (column dot)
+    if (pair_list)
+        ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), nx_total, mx, 1, nx_total, dxp, wavelength,
+                              n_glass, pl.ux.as<double>()));
+    else
+        ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), mx, nx_total, 0, nx_total, dxp, wavelength,
+                              n_glass, pl.ux.as<double>()));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    pl.ready = true;
+    return ML_OK;
+}
+
+int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    FarfieldPlan &pl = ctx->plan;
+    if (!pl.ready) {
+        set_error("ml_farfield_plan has not been called");
+        return ML_ESTATE;
+    }
+    if (ctx->nx == 0) {
+        set_error("no resident field set");
+        return ML_ESTATE;
+    }
+    ML_REQUIRE(ctx->ny == pl.ny, "resident fields have ny=%d but the plan has ny=%d", ctx->ny,
+               pl.ny);
+    ML_REQUIRE(row0 >= 0 && row0 + ctx->nx <= pl.nx_total,
+               "rows [%d, %d) fall outside the planned aperture of %d rows", row0,
+               row0 + ctx->nx, pl.nx_total);
+    ML_REQUIRE(!accumulate || pl.have_vectors, "accumulate requested but nothing to add to");
+    ML_HIP(hipSetDevice(ctx->device));
+    const int nxl = ctx->nx, ny = pl.ny, mx = pl.mx, my = pl.my;
+    ML_TRY(pl.stage1.reserve((size_t)4 * nxl * my * 2 * sizeof(double)));
+    const double one[4] = {1.0, 1.0, 1.0, 1.0};
+    {
+        // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
+        ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
+        ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
+                     pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
+    }
+    const double dA = pl.dxp * pl.dyp;
+    // fields are stored Ex,Ey,Hx,Hy; radiation vectors Nx,Ny,Lx,Ly = -Hy, Hx, Ey, -Ex (x dA)
+    const double alpha[4] = {-dA, dA, dA, -dA};
+    if (!pl.pair_list) {
+        // stage 2: V_f[a][b] = alpha_f * sum_n1 exp(-i k x'_n1 ux_a) * G[(f, n1)][b];
+        // batch entry f writes radiation-vector slot 3 - f
+        ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        double *slot3 = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
+        ML_TRY(zgemm(ctx->stream, mx, my, nxl, alpha, pl.tw_x.as<double>() + (size_t)row0 * 2,
+                     pl.nx_total, 0, pl.stage1.as<double>(), my, (int64_t)nxl * my, slot3, my,
+                     -(int64_t)mx * my, 4, accumulate));
+    } else {
+        ProfScope scope(ctx, ML_K_COLDOT);
+        ML_TRY(zcoldot(ctx->stream, 4, nxl, mx, alpha, pl.tw_x.as<double>(), mx, row0,
+                       pl.stage1.as<double>(), pl.vectors.as<double>(), accumulate));
+    }
+    pl.have_vectors = true;
+    return ML_OK;
+}
+
+int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate) {
+    ML_TRY(ml_farfield_transform_async(ctx, row0, accumulate));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return prof_harvest(ctx);
+}
+
+int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    FarfieldPlan &pl = ctx->plan;
+    if (!pl.ready || !pl.have_vectors) {
+        set_error("no radiation vectors: call ml_farfield_plan and ml_farfield_transform first");
+        return ML_ESTATE;
+    }
+    ML_HIP(hipSetDevice(ctx->device));
+    const int mx = pl.mx, my = pl.pair_list ? 1 : pl.my;
+    const size_t n = (size_t)mx * my;
+    ProjArgs a;
+    const double2 *v = pl.vectors.as<double2>();
+    a.Nx = v;
+    a.Ny = v + n;
+    a.Lx = v + 2 * n;
+    a.Ly = v + 3 * n;
+    a.ux = pl.ux.as<double>();
+    a.uy = pl.uy.as<double>();
+    a.mx = mx;
+    a.my = my;
+    a.pair_list = pl.pair_list;
+    a.from_fft = 0;
+    a.dxp = a.dyp = 1.0;
+    a.Z = Z0 / pl.n_glass;
+    a.coef = pow(2 * M_PI * pl.n_glass / pl.wavelength, 2) / (32 * pow(M_PI, 2) * a.Z);
+    a.P = pl.power.as<double>();
+    a.a_theta = pl.amplitudes.as<double2>();
+    a.a_phi = pl.amplitudes.as<double2>() + n;
+    return project_launch(ctx, a, ML_K_PROJECT);
+}
+
+int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi) {
+    ML_TRY(ml_farfield_project_async(ctx, Z0));
+    FarfieldPlan &pl = ctx->plan;
+    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    if (P)
+        ML_HIP(hipMemcpyAsync(P, pl.power.p, n * sizeof(double), hipMemcpyDeviceToHost,
+                              ctx->stream));
+    if (a_theta)
+        ML_HIP(hipMemcpyAsync(a_theta, pl.amplitudes.p, n * 2 * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    if (a_phi)
+        ML_HIP(hipMemcpyAsync(a_phi, pl.amplitudes.as<double>() + 2 * n, n * 2 * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return prof_harvest(ctx);
+}
+
+int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    FarfieldPlan &pl = ctx->plan;
+    if (!pl.ready || !pl.have_vectors) {
+        set_error("no radiation vectors to download");
+        return ML_ESTATE;
+    }
+    ML_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    double *dst[4] = {Nx, Ny, Lx, Ly};
+    for (int k = 0; k < 4; ++k)
+        if (dst[k])
+            ML_HIP(hipMemcpyAsync(dst[k], pl.vectors.as<double>() + k * n * 2,
+                                  n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return ML_OK;
+}
+
+int ml_farfield_lattice_power(ml_ctx *ctx, int nx, int ny, const double *fftEx,
+                              const double *fftEy, const double *fftHx, const double *fftHy,
+                              const double *ux_list, const double *uy_list, double dxp, double dyp,
+                              double wavelength, double n_glass, double Z0, double *P) {
+    ML_REQUIRE(ctx && fftEx && fftEy && fftHx && fftHy && ux_list && uy_list && P, "NULL argument");
+    ML_REQUIRE(nx >= 1 && ny >= 1, "empty grid");
+    ML_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)nx * ny;
+    DevBuf &in = ctx->lattice_in;
+    ML_TRY(in.reserve(4 * n * 2 * sizeof(double) + (nx + ny) * sizeof(double) + n * sizeof(double)));
+    double *base = in.as<double>();
+    // order in the staging buffer: Nx<-fftHy, Ny<-fftHx, Lx<-fftEy, Ly<-fftEx
+    const double *src[4] = {fftHy, fftHx, fftEy, fftEx};
+    for (int k = 0; k < 4; ++k)
+        ML_HIP(hipMemcpyAsync(base + k * n * 2, src[k], n * 2 * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+    double *d_ux = base + 4 * n * 2, *d_uy = d_ux + nx, *d_P = d_uy + ny;
+    ML_HIP(hipMemcpyAsync(d_ux, ux_list, nx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ML_HIP(hipMemcpyAsync(d_uy, uy_list, ny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ProjArgs a;
+    const double2 *v = reinterpret_cast<const double2 *>(base);
+    a.Nx = v;
+    a.Ny = v + n;
+    a.Lx = v + 2 * n;
+    a.Ly = v + 3 * n;
+    a.ux = d_ux;
+    a.uy = d_uy;
+    a.mx = nx;
+    a.my = ny;
+    a.pair_list = 0;
+    a.from_fft = 1;
+    a.dxp = dxp;
+    a.dyp = dyp;
+    a.Z = Z0 / n_glass;
+    a.coef = pow(2 * M_PI * n_glass / wavelength, 2) / (32 * pow(M_PI, 2) * a.Z);
+    a.P = d_P;
+    a.a_theta = nullptr;
+    a.a_phi = nullptr;
+    ML_TRY(project_launch(ctx, a, ML_K_LATTICE_POWER));
+    ML_HIP(hipMemcpyAsync(P, d_P, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return prof_harvest(ctx);
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+// Near-field synthesis on MI355X: one thread per aperture sample.
+//
+// Restates reference nearfield.py:117-477 per sample (see oracle/nearfield_oracle.py for the
+// NumPy statement of the same thing).  This translation unit is compiled with
+// -ffp-contract=off: the arguments of the large phases (k*distance ~ 1e4 rad) must be
+// rounded exactly like the reference's NumPy expressions, so no multiply-add may be fused.
+//
+// Data in HBM
+//   fields          complex128 [4][nx][ny]   Ex, Ey, Hx, Hy planes, y fastest (64 B / sample,
+//                                            the only compulsory HBM traffic of this kernel)
+//   tables          complex128 [order][n0][n1][n2][4]  per collection, <= ~1 MB in total,
+//                                            L2-resident; one 64-byte line = the four
+//                                            amplitudes of one grid node
+//   ring arrays     float64 [n_rings]        + a uniform-in-r lookup table for the ring search
+//   centre cells    sorted by spatial bin    (uniform grid, exact nearest neighbour)
+#include "common.h"
+
+namespace ml {
+
+struct c2 {
+    double r, i;
+};
+__device__ __forceinline__ c2 operator+(c2 a, c2 b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) {
+    return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r};
+}
+__device__ __forceinline__ c2 scale(c2 a, double s) { return {a.r * s, a.i * s}; }
+
+struct NfArgs {
+    ml_nearfield_params p;
+    const double *x_pts, *y_pts;
+    int nx, ny;
+    // rings
+    int n_rings;
+    const double *B, *rc, *period, *dphi, *lateral, *ring_t2;
+    const int *gc, *ring_i2, *lut;
+    int lut_buckets;
+    double lut_inv_h;
+    // centre cells
+    int n_cells;
+    const double *cx, *cy;
+    const int *cwhich, *cindex, *bin_start;
+    int bins_x, bins_y;
+    double bx0, by0, bh;
+    // tables
+    const TableDesc *tables;
+    // outputs
+    double *fields;
+    double *partial_power;
+    unsigned long long *viol;
+};
+
+// monotone map double -> uint64 (so that integer max == floating max)
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Record an out-of-table sample.  Rare path: only violators touch memory.  "min" checks
+// store the complemented key so that every slot is a plain atomicMax starting from 0.
+__device__ __noinline__ void report(unsigned long long *viol, int slot, int order, int check,
+                                    double v) {
+    unsigned long long k = ordered_key(v);
+    if ((check & 1) == 0) k = ~k;
+    atomicMax(&viol[((size_t)slot * MAX_ORDERS + order) * 6 + check], k);
+}
+
+__device__ __forceinline__ void check_bounds(const NfArgs &a, const TableDesc &T, int slot,
+                                             int order, double u, double v, double g,
+                                             bool with_period) {
+    if (u < T.bounds[0]) report(a.viol, slot, order, 0, u);
+    if (u > T.bounds[1]) report(a.viol, slot, order, 1, u);
+    if (v < T.bounds[2]) report(a.viol, slot, order, 2, v);
+    if (v > T.bounds[3]) report(a.viol, slot, order, 3, v);
+    if (with_period) {
+        if (g < T.bounds[4]) report(a.viol, slot, order, 4, g);
+        if (g > T.bounds[5]) report(a.viol, slot, order, 5, g);
+    }
+}
+
+// scipy find_indices on a short axis: largest i with axis[i] <= x, clamped to [0, n-2]
+__device__ __forceinline__ void locate(const double *axis, int n, double x, int &i, double &t) {
+    i = 0;
+    for (int a = 1; a < n - 1; ++a)
+        if (axis[a] <= x) i = a;
+    t = (x - axis[i]) / (axis[i + 1] - axis[i]);
+}
+
+// The four amplitudes (x,ampfy) (x,ampfx) (y,ampfy) (y,ampfx) of one order at
+// (u, v, third-axis cell i2 / fraction t2): scipy's _evaluate_linear arithmetic.
+__device__ __forceinline__ void trilinear4(const TableDesc &T, int order, double u, double v,
+                                           int i2, double t2, c2 out[4]) {
+    int i0, i1;
+    double t0, t1;
+    locate(T.axis0, T.n0, u, i0, t0);
+    locate(T.axis1, T.n1, v, i1, t1);
+    const double w0[2] = {1 - t0, t0}, w1[2] = {1 - t1, t1}, w2[2] = {1 - t2, t2};
+    for (int q = 0; q < 4; ++q) out[q] = {0.0, 0.0};
+#pragma unroll
+    for (int c0 = 0; c0 < 2; ++c0)
+#pragma unroll
+        for (int c1 = 0; c1 < 2; ++c1)
+#pragma unroll
+            for (int c2_ = 0; c2_ < 2; ++c2_) {
+                const double w = (w0[c0] * w1[c1]) * w2[c2_];
+                const size_t node =
+                    ((((size_t)order * T.n0 + (i0 + c0)) * T.n1 + (i1 + c1)) * T.n2 + (i2 + c2_));
+                const double2 *vp = reinterpret_cast<const double2 *>(T.values) + node * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double2 val = vp[q];
+                    out[q].r = out[q].r + val.x * w;
+                    out[q].i = out[q].i + val.y * w;
+                }
+            }
+}
+
+// One diffraction order, one incident polarisation (nearfield.py:312-327 / 426-441).
+__device__ __forceinline__ void add_order(c2 &Ex, c2 &Ey, c2 &Hx, c2 &Hy, double Ew, double Hw,
+                                          c2 afy, c2 afx, double kx, double ky, double kz,
+                                          double k_glass, double inv_n, c2 ph) {
+    const double scl = 1.0 / (k_glass * kz);   // numpy divides complex by real this way
+    c2 t;
+    // ampfy
+    t = scale(scale(scale(scale(scale(afy, Ew), kx), ky), scl), inv_n);
+    Ex = Ex + cmul(t, ph);
+    t = scale(scale(scale(scale(afy, Ew), (-(kx * kx)) - kz * kz), scl), inv_n);
+    Ey = Ey + cmul(t, ph);
+    Hx = Hx + cmul(scale(afy, Hw), ph);
+    // ampfx
+    t = scale(scale(scale(scale(afx, Ew), ky * ky + kz * kz), scl), inv_n);
+    Ex = Ex + cmul(t, ph);
+    t = scale(scale(scale(scale(scale(afx, Ew), -kx), ky), scl), inv_n);
+    Ey = Ey + cmul(t, ph);
+    Hy = Hy + cmul(scale(afx, Hw), ph);
+}
+
+// exact nearest centre cell (nearfield.py:363-364) through a uniform grid of bins
+__device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y) {
+    int bx = (int)floor((x - a.bx0) / a.bh);
+    int by = (int)floor((y - a.by0) / a.bh);
+    bx = min(max(bx, 0), a.bins_x - 1);
+    by = min(max(by, 0), a.bins_y - 1);
+    double best = INFINITY;
+    int best_slot = -1, best_idx = 0x7fffffff;
+    const int kmax = max(a.bins_x, a.bins_y);
+    for (int k = 0; k <= kmax; ++k) {
+        const int x_lo = bx - k, x_hi = bx + k, y_lo = by - k, y_hi = by + k;
+        for (int gx = max(x_lo, 0); gx <= min(x_hi, a.bins_x - 1); ++gx) {
+            const bool edge_col = (gx == x_lo) || (gx == x_hi);
+            const int step = edge_col ? 1 : max(2 * k, 1);
+            for (int gy = y_lo; gy <= y_hi; gy += step) {
+                if (gy < 0 || gy >= a.bins_y) continue;
+                const int b = gx * a.bins_y + gy;
+                for (int s = a.bin_start[b]; s < a.bin_start[b + 1]; ++s) {
+                    const double ex = x - a.cx[s], ey = y - a.cy[s];
+                    const double d2 = ex * ex + ey * ey;
+                    const int idx = a.cindex[s];
+                    if (d2 < best || (d2 == best && idx < best_idx)) {
+                        best = d2;
+                        best_slot = s;
+                        best_idx = idx;
+                    }
+                }
+            }
+        }
+        // every cell not yet visited is at least k*bh away
+        const double reach = k * a.bh;
+        if (best_slot >= 0 && best <= reach * reach) break;
+    }
+    return best_slot;
+}
+
+__global__ __launch_bounds__(256) void nearfield_kernel(const NfArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;   // y index (fastest in memory)
+    const int i = blockIdx.y;                        // x index
+    const ml_nearfield_params &p = a.p;
+    double power_here = 0.0;
+    c2 Ex = {0, 0}, Ey = {0, 0}, Hx = {0, 0}, Hy = {0, 0};
+    const bool active = j < a.ny;
+    if (active) {
+        const double x = a.x_pts[i], y = a.y_pts[j];
+        const double r = sqrt(x * x + y * y);
+        // ---- which ring: searchsorted(boundaries, r, 'left') - 1  (nearfield.py:125-128)
+        int idx;   // number of boundaries strictly below r
+        if (r > a.B[a.n_rings]) {
+            idx = a.n_rings + 1;
+        } else {
+            int bucket = (int)(r * a.lut_inv_h);
+            bucket = min(max(bucket, 0), a.lut_buckets - 1);
+            idx = a.lut[bucket];
+            while (idx <= a.n_rings && a.B[idx] < r) ++idx;
+            while (idx > 0 && a.B[idx - 1] >= r) --idx;
+        }
+        const bool in_center = (idx == 0);
+        const bool in_periphery = (idx >= 1 && idx <= a.n_rings);
+        if (in_center || in_periphery) {
+            // ---- incidence direction (nearfield.py:172-184)
+            const double dx = x - p.source_x, dy = y - p.source_y;
+            double ux, uy, uz, dist = 1.0;
+            if (p.plane_wave) {
+                ux = 0.0;
+                uy = 0.0;
+                uz = 1.0;
+            } else {
+                dist = sqrt(dx * dx + dy * dy + p.dz2);
+                ux = dx / dist;
+                uy = dy / dist;
+                uz = p.dz / dist;
+            }
+            // ---- incident field (nearfield.py:213-228)
+            double Hx_i, Hy_i, Ex_i, Ey_i;
+            if (p.plane_wave) {
+                Ex_i = p.pol[0] * p.dipole_moment * 1.0;
+                Ey_i = p.pol[1] * p.dipole_moment * 1.0;
+                Hx_i = -p.pol[1] * p.dipole_moment / p.Z0 * 1.0;
+                Hy_i = p.pol[0] * p.dipole_moment / p.Z0 * 1.0;
+            } else {
+                const double suz = sqrt(uz);
+                Hx_i = (uy * p.pol[2] - uz * p.pol[1]) * p.H_coef * suz / dist;
+                Hy_i = (uz * p.pol[0] - ux * p.pol[2]) * p.H_coef * suz / dist;
+                const double Hz_i = (ux * p.pol[1] - uy * p.pol[0]) * p.H_coef * suz / dist;
+                Ex_i = (Hy_i * uz - Hz_i * uy) * p.Z0;
+                Ey_i = (Hz_i * ux - Hx_i * uz) * p.Z0;
+            }
+            power_here = Ex_i * Hy_i - Ey_i * Hx_i;   // nearfield.py:474
+            const double inv_n = 1.0 / p.n_glass;
+
+            if (in_periphery) {
+                const int ring = idx - 1;
+                const int slot = a.gc[ring];
+                const TableDesc &T = a.tables[slot];
+                const double period = a.period[ring], dphi = a.dphi[ring];
+                const double rcen = a.rc[ring], lateral = a.lateral[ring];
+                // ---- sector and local frame (nearfield.py:169,195-201)
+                const double phi = atan2(y, x);
+                const double rot = rint(phi / dphi) * dphi;
+                double sinr, cosr;
+                sincos(rot, &sinr, &cosr);
+                const double uxp = ux * cosr + uy * sinr;
+                const double uyp = -ux * sinr + uy * cosr;
+                const double xp = x * cosr + y * sinr - rcen;
+                const double yp = -x * sinr + y * cosr;
+                const double Hxp_i = Hx_i * cosr + Hy_i * sinr;
+                const double Hyp_i = -Hx_i * sinr + Hy_i * cosr;
+                // x-polarised table <=> H along y' (nearfield.py:246-247)
+                const double Hw_x = Hyp_i, Hw_y = Hxp_i;
+                const int i2 = a.ring_i2[ring];
+                const double t2 = a.ring_t2[ring];
+                c2 Exp = {0, 0}, Eyp = {0, 0}, Hxp = {0, 0}, Hyp = {0, 0};
+                for (int o = 0; o < T.n_orders; ++o) {
+                    const double kxp = p.kvac * uxp + T.order_k[2 * o] / period;
+                    const double kyp = p.kvac * uyp + T.order_k[2 * o + 1] / lateral;
+                    if (kxp * kxp + kyp * kyp <= p.kvac2) {
+                        const double kzp = sqrt(p.k_glass2 - kxp * kxp - kyp * kyp);
+                        c2 ph;
+                        sincos(kxp * xp + kyp * yp, &ph.i, &ph.r);
+                        check_bounds(a, T, slot, o, uxp, uyp, period, true);
+                        c2 amp[4];
+                        trilinear4(T, o, uxp, uyp, i2, t2, amp);
+                        add_order(Exp, Eyp, Hxp, Hyp, Hw_x * p.Z0, Hw_x, amp[0], amp[1], kxp, kyp,
+                                  kzp, p.k_glass, inv_n, ph);
+                        add_order(Exp, Eyp, Hxp, Hyp, Hw_y * p.Z0, Hw_y, amp[2], amp[3], kxp, kyp,
+                                  kzp, p.k_glass, inv_n, ph);
+                    }
+                }
+                // ---- propagation phase from the grating centre (nearfield.py:337-346)
+                if (!p.plane_wave) {
+                    const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
+                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                    c2 e;
+                    sincos(p.kvac * air, &e.i, &e.r);
+                    Exp = cmul(Exp, e);
+                    Eyp = cmul(Eyp, e);
+                    Hxp = cmul(Hxp, e);
+                    Hyp = cmul(Hyp, e);
+                }
+                // ---- back to the lab frame (nearfield.py:351-354)
+                Ex = {Exp.r * cosr - Eyp.r * sinr, Exp.i * cosr - Eyp.i * sinr};
+                Ey = {Exp.r * sinr + Eyp.r * cosr, Exp.i * sinr + Eyp.i * cosr};
+                Hx = {Hxp.r * cosr - Hyp.r * sinr, Hxp.i * cosr - Hyp.i * sinr};
+                Hy = {Hxp.r * sinr + Hyp.r * cosr, Hxp.i * sinr + Hyp.i * cosr};
+            } else if (a.n_cells > 0) {
+                // ---- lens centre: nearest hexagonal cell (nearfield.py:359-466)
+                const TableDesc &T = a.tables[MAX_SLOTS];
+                const int s = nearest_cell(a, x, y);
+                const double ccx = a.cx[s], ccy = a.cy[s];
+                const int which = a.cwhich[s];
+                const int i2 = min(max(which, 0), T.n2 - 2);
+                const double t2 = ((double)which - (double)i2) / 1.0;
+                // un-rotated weights: x-polarised table <=> H along y (nearfield.py:375-376)
+                const double Hw_x = Hy_i, Hw_y = Hx_i;
+                for (int o = 0; o < T.n_orders; ++o) {
+                    const double kx = p.kvac * ux + T.center_kx[o];
+                    const double ky = p.kvac * uy + T.center_ky[o];
+                    if (kx * kx + ky * ky <= p.kvac2) {
+                        const double kz = sqrt(p.k_glass2 - kx * kx - ky * ky);
+                        c2 ph;
+                        sincos(kx * (x - ccx) + ky * (y - ccy), &ph.i, &ph.r);
+                        check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                        c2 amp[4];
+                        trilinear4(T, o, ux, uy, i2, t2, amp);
+                        add_order(Ex, Ey, Hx, Hy, Hw_x * p.Z0, Hw_x, amp[0], amp[1], kx, ky, kz,
+                                  p.k_glass, inv_n, ph);
+                        add_order(Ex, Ey, Hx, Hy, Hw_y * p.Z0, Hw_y, amp[2], amp[3], kx, ky, kz,
+                                  p.k_glass, inv_n, ph);
+                    }
+                }
+                if (!p.plane_wave) {
+                    const double gx = ccx - p.source_x, gy = ccy - p.source_y;
+                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                    c2 e;
+                    sincos(p.kvac * air, &e.i, &e.r);
+                    Ex = cmul(Ex, e);
+                    Ey = cmul(Ey, e);
+                    Hx = cmul(Hx, e);
+                    Hy = cmul(Hy, e);
+                }
+            }
+        }
+        // ---- store: 16 B per lane per plane, coalesced along y
+        const size_t plane = (size_t)a.nx * a.ny;
+        const size_t at = (size_t)i * a.ny + j;
+        double2 *F = reinterpret_cast<double2 *>(a.fields);
+        F[at] = make_double2(Ex.r, Ex.i);
+        F[plane + at] = make_double2(Ey.r, Ey.i);
+        F[2 * plane + at] = make_double2(Hx.r, Hx.i);
+        F[3 * plane + at] = make_double2(Hy.r, Hy.i);
+    }
+    // ---- incident power: wave reduction, then one partial per block (fixed order)
+    for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
+    __shared__ double wave_sum[4];
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = power_here;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
+            (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+// deterministic tree sum of the per-block partials
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const double *partial, int n,
+                                                            double *out) {
+    __shared__ double s[1024];
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < n; k += 1024) acc += partial[k];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
+int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) {
+    NfArgs a;
+    a.p = *p;
+    a.x_pts = ctx->x_pts.as<double>();
+    a.y_pts = ctx->y_pts.as<double>();
+    a.nx = nx;
+    a.ny = ny;
+    a.n_rings = ctx->n_rings;
+    a.B = ctx->ring_boundaries.as<double>();
+    a.rc = ctx->ring_r_center.as<double>();
+    a.period = ctx->ring_period.as<double>();
+    a.dphi = ctx->ring_dphi.as<double>();
+    a.lateral = ctx->ring_lateral.as<double>();
+    a.ring_t2 = ctx->ring_t2.as<double>();
+    a.gc = ctx->ring_gc.as<int>();
+    a.ring_i2 = ctx->ring_i2.as<int>();
+    a.lut = ctx->ring_lut.as<int>();
+    a.lut_buckets = ctx->lut_buckets;
+    a.lut_inv_h = ctx->lut_inv_h;
+    a.n_cells = ctx->n_cells;
+    a.cx = ctx->cell_x.as<double>();
+    a.cy = ctx->cell_y.as<double>();
+    a.cwhich = ctx->cell_which.as<int>();
+    a.cindex = ctx->cell_index.as<int>();
+    a.bin_start = ctx->bin_start.as<int>();
+    a.bins_x = ctx->bins_x;
+    a.bins_y = ctx->bins_y;
+    a.bx0 = ctx->bin_x0;
+    a.by0 = ctx->bin_y0;
+    a.bh = ctx->bin_h;
+    a.tables = ctx->table_desc.as<TableDesc>();
+    a.fields = ctx->fields.as<double>();
+    a.partial_power = ctx->partial_power.as<double>();
+    a.viol = ctx->violations.as<unsigned long long>();
+
+    const dim3 grid((ny + 255) / 256, nx);
+    {
+        ProfScope scope(ctx, ML_K_NEARFIELD);
+        hipLaunchKernelGGL(nearfield_kernel, grid, dim3(256), 0, ctx->stream, a);
+    }
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream,
+                       ctx->partial_power.as<double>(), (int)(grid.x * grid.y),
+                       ctx->power.as<double>());
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+}  // namespace ml

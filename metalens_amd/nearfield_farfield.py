@@ -1,0 +1,141 @@
+"""Near-field to far-field transform on MI355X.
+
+``farfield_from_nearfield`` is a drop-in for the reference function of the same
+name (reference nearfield_farfield.py:14-75): it takes the caller's
+``fft2(fftshift(F))`` arrays and returns ``(P, total_P, ux, uy, dux, duy)``.  The
+per-bin projection (``farfield_from_nearfield_helper``, nearfield_farfield.py:77-191)
+runs in the HIP kernel ``project_kernel``; the axis bookkeeping, ``fftshift`` and the
+finite-sum of :68-74 stay in NumPy exactly as the reference has them.
+
+``FarfieldTransform`` / ``farfield_direct`` are new: they evaluate the
+aperture -> direction sum that the reference derives in its docstring
+(nearfield_farfield.py:97-138) for an ARBITRARY grid (or list) of direction
+cosines, as dense complex GEMMs on the fp64 matrix cores, directly from the
+GPU-resident near field - no FFT, no host round trip, and linear in the aperture
+so that the aperture rows can be sharded over GPUs and summed with one RCCL
+all-reduce.  On FFT-lattice directions the result equals the reference's
+``fft bin x dx' dy'`` (:135-138).  There is no CPU path.
+"""
+import numpy as np
+
+from . import _lib, constants
+
+
+def _check_axis(pts, wavelength):
+    d = np.diff(np.asarray(pts, dtype=float))
+    assert d.size >= 1
+    assert 0 < d[0] < wavelength / 2
+    assert d.max() - d.min() <= 1e-9 * np.abs(d).max()
+
+
+def fft_direction_cosines(n, step, wavelength, n_glass):
+    """Direction cosines (in glass) of the n un-shifted FFT bins, aliased into
+    the half-range (nearfield_farfield.py:35-39)."""
+    u = np.arange(n) * (wavelength / n_glass) / (step * n)
+    u[u > u.max() / 2] -= (wavelength / n_glass) / step
+    return u
+
+
+def farfield_from_nearfield(fftEx, fftEy, fftHx, fftHy, xp_list, yp_list, wavelength, n_glass,
+                            *, Z0=None, ctx=None):
+    """``fftEx`` is ``fft2(fftshift(Ex))`` and likewise for the others; ``xp_list``,
+    ``yp_list`` are the aperture coordinates.  Returns
+    ``(P_here_times_r2_over_uz, total_P, ux, uy, dux, duy)`` with the arrays
+    fft-shifted, as the reference does."""
+    Z0 = constants.Z0 if Z0 is None else Z0
+    dxp = xp_list[1] - xp_list[0]
+    dyp = yp_list[1] - yp_list[0]
+    num_x, num_y = len(xp_list), len(yp_list)
+    assert fftEx.shape == fftEy.shape == fftHx.shape == fftHy.shape == (num_x, num_y)
+    _check_axis(xp_list, wavelength)
+    _check_axis(yp_list, wavelength)
+    ux_list = fft_direction_cosines(num_x, dxp, wavelength, n_glass)
+    uy_list = fft_direction_cosines(num_y, dyp, wavelength, n_glass)
+
+    ctx = ctx or _lib.default_context()
+    P = np.empty((num_x, num_y), dtype=np.float64)
+    ins = [_lib.c128(a) for a in (fftEx, fftEy, fftHx, fftHy)]
+    _lib.check(ctx.lib.ml_farfield_lattice_power(
+        ctx.handle, num_x, num_y, *[_lib.dptr(a) for a in ins], _lib.dptr(ux_list),
+        _lib.dptr(uy_list), dxp, dyp, wavelength, n_glass, Z0, _lib.dptr(P)))
+
+    P = np.fft.fftshift(P)
+    ux_list = np.fft.fftshift(ux_list)
+    uy_list = np.fft.fftshift(uy_list)
+    dux = ux_list[1] - ux_list[0]
+    duy = uy_list[1] - uy_list[0]
+    ux, uy = np.meshgrid(ux_list, uy_list, indexing='ij', sparse=True)
+    total_P = (P * dux * duy)[np.isfinite(P)].sum()
+    return P, total_P, ux, uy, dux, duy
+
+
+class FarfieldTransform:
+    """Direct aperture -> direction transform for one aperture geometry and one set
+    of directions.
+
+    ``ux``/``uy`` are direction cosines in glass; with ``pair_list=False`` the far
+    field is evaluated on the tensor grid ``ux[:,None] x uy[None,:]``, with
+    ``pair_list=True`` at the ``len(ux)`` points ``(ux[d], uy[d])``.
+
+    ``num_x_total`` is the number of aperture rows of the WHOLE aperture; the rows
+    resident on this GPU are ``[row0, row0 + local rows)`` (sharded use).
+    """
+
+    def __init__(self, num_x_total, num_y, dxp, dyp, wavelength, n_glass, ux, uy,
+                 pair_list=False, ctx=None):
+        self.ctx = ctx or _lib.default_context()
+        self.ux = _lib.f64(np.ravel(ux))
+        self.uy = _lib.f64(np.ravel(uy))
+        self.pair_list = bool(pair_list)
+        self.shape = (self.ux.size,) if pair_list else (self.ux.size, self.uy.size)
+        self.wavelength, self.n_glass = wavelength, n_glass
+        _lib.check(self.ctx.lib.ml_farfield_plan(
+            self.ctx.handle, num_x_total, num_y, dxp, dyp, wavelength, n_glass,
+            _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy), self.uy.size, int(pair_list)))
+
+    def transform(self, row0=0, accumulate=False):
+        """radiation vectors of the resident field rows (a partial sum if sharded)"""
+        _lib.check(self.ctx.lib.ml_farfield_transform(self.ctx.handle, row0, int(accumulate)))
+
+    def allreduce(self):
+        _lib.check(self.ctx.lib.ml_farfield_allreduce(self.ctx.handle))
+
+    def radiation_vectors(self):
+        out = [np.empty(self.shape, dtype=np.complex128) for _ in range(4)]
+        _lib.check(self.ctx.lib.ml_farfield_download(self.ctx.handle, *[_lib.dptr(a) for a in out]))
+        return dict(zip(('Nx', 'Ny', 'Lx', 'Ly'), out))
+
+    def project(self, Z0=None):
+        """-> P (= power x r^2 / uz per unit dux duy, NaN outside the unit circle) and the
+        two complex far-field amplitudes ``L_phi + Z N_theta`` (prop. to E_theta) and
+        ``L_theta - Z N_phi`` (prop. to -E_phi) of nearfield_farfield.py:184-185."""
+        Z0 = constants.Z0 if Z0 is None else Z0
+        P = np.empty(self.shape, dtype=np.float64)
+        a_theta = np.empty(self.shape, dtype=np.complex128)
+        a_phi = np.empty(self.shape, dtype=np.complex128)
+        _lib.check(self.ctx.lib.ml_farfield_project(self.ctx.handle, Z0, _lib.dptr(P),
+                                                    _lib.dptr(a_theta), _lib.dptr(a_phi)))
+        return P, a_theta, a_phi
+
+
+def farfield_direct(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, uy,
+                    *, pair_list=False, Z0=None, ctx=None):
+    """One-shot convenience: far field of host arrays ``Ex..Hy`` (or of the field set
+    already resident on the GPU if ``Ex is None``) at the given directions.  Returns a
+    dict with ``Nx, Ny, Lx, Ly, P, a_theta, a_phi``."""
+    ctx = ctx or _lib.default_context()
+    dxp = xp_list[1] - xp_list[0]
+    dyp = yp_list[1] - yp_list[0]
+    _check_axis(xp_list, wavelength)
+    _check_axis(yp_list, wavelength)
+    if Ex is not None:
+        arrs = [_lib.c128(a) for a in (Ex, Ey, Hx, Hy)]
+        assert arrs[0].shape == arrs[1].shape == arrs[2].shape == arrs[3].shape == (len(xp_list), len(yp_list))
+        _lib.check(ctx.lib.ml_fields_upload(ctx.handle, len(xp_list), len(yp_list),
+                                            *[_lib.dptr(a) for a in arrs]))
+    t = FarfieldTransform(len(xp_list), len(yp_list), dxp, dyp, wavelength, n_glass, ux, uy,
+                          pair_list=pair_list, ctx=ctx)
+    t.transform()
+    out = t.radiation_vectors()
+    out['P'], out['a_theta'], out['a_phi'] = t.project(Z0)
+    return out

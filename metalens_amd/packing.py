@@ -1,0 +1,125 @@
+"""Flatten the reference's duck-typed inputs into the contiguous arrays the C ABI
+takes and upload them.
+
+Accepted objects are whatever the reference's ``build_nearfield`` accepts
+(nearfield.py:87-93,111,264,310,390-392): a ``lens_periphery_summary`` dict, a
+``lens_center_summary`` ``[C,3]`` array, and collection / HexGridSet objects
+exposing ``.grating_list[i].data``, ``.grating_list[0].n_glass / .grating_period
+/ .lateral_period``, ``.interpolators[(wavelength_in_nm, (ox, oy), 'x'|'y',
+'ampfy'|'ampfx')]`` (anything with ``.grid`` and ``.values``: a scipy
+``RegularGridInterpolator`` or this package's ``TrilinearTable``) and
+``.interpolator_bounds``.
+"""
+from math import pi
+
+import numpy as np
+
+from . import _lib
+
+MAX_SLOTS = 32
+MAX_ORDERS = 32
+POL_AMP = (('x', 'ampfy'), ('x', 'ampfx'), ('y', 'ampfy'), ('y', 'ampfx'))
+
+
+def orders_of(obj):
+    """the union of diffraction orders over the object's records, sorted
+    (the reference iterates a set, nearfield.py:264,390 - order only matters to rounding)"""
+    return sorted({(e['ox'], e['oy']) for g in obj.grating_list for e in g.data})
+
+
+def pack_table(obj, wavelength_in_nm):
+    """-> dict of contiguous arrays for ml_upload_table.  ``KeyError`` if the
+    object has no table for this wavelength / order, as in the reference."""
+    orders = orders_of(obj)
+    if not 1 <= len(orders) <= MAX_ORDERS:
+        raise ValueError('a table needs between 1 and %d diffraction orders, got %d'
+                         % (MAX_ORDERS, len(orders)))
+    first = obj.interpolators[(wavelength_in_nm, orders[0], 'x', 'ampfy')]
+    axes = [np.ascontiguousarray(g, dtype=np.float64) for g in first.grid]
+    shape = tuple(a.size for a in axes)
+    values = np.empty((len(orders),) + shape + (4,), dtype=np.complex128)
+    for o, order in enumerate(orders):
+        for q, (pol, amp) in enumerate(POL_AMP):
+            f = obj.interpolators[(wavelength_in_nm, order, pol, amp)]
+            if tuple(len(g) for g in f.grid) != shape or any(
+                    not np.array_equal(np.asarray(g, dtype=float), a) for g, a in zip(f.grid, axes)):
+                raise ValueError('interpolators of one collection must share one grid')
+            values[o, :, :, :, q] = np.asarray(f.values)
+    bounds = np.zeros(6)
+    b = obj.interpolator_bounds
+    bounds[:len(b)] = [float(v) for v in b][:6]
+    return {'axes': axes, 'orders': np.ascontiguousarray(orders, dtype=np.int32).reshape(-1, 2),
+            # ox * 2*pi exactly as written at nearfield.py:268-269,395-396
+            'order_k': np.array([[ox * 2 * pi, oy * 2 * pi] for ox, oy in orders], dtype=np.float64),
+            'values': values, 'bounds': bounds}
+
+
+def upload_tables(ctx, gratingcollection_list, hexgridset, wavelength_in_nm):
+    if len(gratingcollection_list) > MAX_SLOTS:
+        raise ValueError('at most %d grating collections per lens' % MAX_SLOTS)
+    token = ('tables', wavelength_in_nm, tuple(id(gc) for gc in gratingcollection_list),
+             id(hexgridset),
+             tuple(id(gc.interpolators) for gc in gratingcollection_list),
+             id(getattr(hexgridset, 'interpolators', None)))
+    if ctx.tables_token == token:
+        return
+    lib = ctx.lib
+    packed = []
+    for slot, gc in enumerate(gratingcollection_list):
+        t = pack_table(gc, wavelength_in_nm)
+        packed.append(t)
+        a0, a1, a2 = t['axes']
+        _lib.check(lib.ml_upload_table(
+            ctx.handle, slot, _lib.dptr(a0), a0.size, _lib.dptr(a1), a1.size, _lib.dptr(a2), a2.size,
+            _lib.iptr(t['orders']), _lib.dptr(t['order_k']), len(t['orders']),
+            _lib.dptr(t['values']), _lib.dptr(t['bounds']), None))
+    if hexgridset is not None:
+        t = pack_table(hexgridset, wavelength_in_nm)
+        a0, a1, a2 = t['axes']
+        g0 = hexgridset.grating_list[0]
+        periods = np.array([g0.grating_period, g0.lateral_period], dtype=np.float64)
+        _lib.check(lib.ml_upload_table(
+            ctx.handle, -1, _lib.dptr(a0), a0.size, _lib.dptr(a1), a1.size, _lib.dptr(a2), a2.size,
+            _lib.iptr(t['orders']), _lib.dptr(t['order_k']), len(t['orders']),
+            _lib.dptr(t['values']), _lib.dptr(t['bounds']), _lib.dptr(periods)))
+        packed.append(t)
+    ctx.tables_token = token
+    ctx.table_orders = [p['orders'] for p in packed]
+
+
+def pack_layout(lens_periphery_summary, lens_center_summary):
+    S = lens_periphery_summary
+    r_min = _lib.f64(S['r_min_list'])
+    r_max = _lib.f64(S['r_max_list'])
+    r_center = _lib.f64(S['r_center_list'])
+    period = _lib.f64(S['grating_period_list'])
+    num = np.asarray(S['num_around_circle_list'])
+    # per-ring constants, evaluated exactly like the reference's per-sample expressions
+    # (nearfield.py:125,163,167)
+    boundaries = np.ascontiguousarray(np.hstack((r_min, r_max[-1])))
+    dphi = _lib.f64(2 * pi / num)
+    lateral = _lib.f64(r_center * dphi)
+    ring_gc = np.ascontiguousarray(S['gratingcollection_index_here_list'], dtype=np.int32)
+    if lens_center_summary is None or len(lens_center_summary) == 0:
+        cells = np.zeros((0, 3))
+    else:
+        cells = _lib.f64(np.asarray(lens_center_summary)[:, 0:3])
+    return {'boundaries': boundaries, 'r_center': r_center, 'period': period, 'dphi': dphi,
+            'lateral': lateral, 'ring_gc': ring_gc, 'cells': cells}
+
+
+def upload_layout(ctx, lens_periphery_summary, lens_center_summary):
+    L = pack_layout(lens_periphery_summary, lens_center_summary)
+    token = ('layout', L['boundaries'].tobytes(), L['period'].tobytes(), L['dphi'].tobytes(),
+             L['ring_gc'].tobytes(), L['cells'].shape,
+             float(L['cells'].sum()) if L['cells'].size else 0.0,
+             float((L['cells'] * np.arange(1, 4)).sum()) if L['cells'].size else 0.0)
+    if ctx.layout_token == token:
+        return
+    n_rings = L['r_center'].size
+    _lib.check(ctx.lib.ml_upload_layout(
+        ctx.handle, n_rings, _lib.dptr(L['boundaries']), _lib.dptr(L['r_center']),
+        _lib.dptr(L['period']), _lib.dptr(L['dphi']), _lib.dptr(L['lateral']),
+        _lib.iptr(L['ring_gc']), len(L['cells']),
+        _lib.dptr(L['cells']) if len(L['cells']) else None))
+    ctx.layout_token = token

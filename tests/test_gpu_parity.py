@@ -1,0 +1,250 @@
+"""Parity of the HIP path (through the C ABI) with the golden fixtures produced by the
+reference and with the CPU oracle.  Needs an MI355X: run with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star): complex fields and far-field amplitudes
+|dE| / max|E| < 1e-12 in fp64.  Measured values are far below."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+CASES = sorted(os.path.basename(p) for p in glob.glob(golden_io.golden_path('nearfield_B_*.npz')))
+
+
+@pytest.fixture(scope='module')
+def ma():
+    import metalens_amd
+    return metalens_amd
+
+
+def case_args(case, **override):
+    lens = golden_io.load_lens(golden_io.golden_path(str(case['lens'])))
+    args = dict(source_x=float(case['source_x']), source_y=float(case['source_y']),
+                source_z=float(case['source_z']), source_pol=str(case['source_pol']),
+                wavelength=float(case['wavelength']), lens_periphery_summary=lens[0],
+                lens_center_summary=lens[1], hexgridset=lens[2],
+                x_pts=case['x_pts'], y_pts=case['y_pts'],
+                dipole_moment=float(case['dipole_moment']), c0=float(case['c0']), Z0=float(case['Z0']))
+    args.update(override)
+    return args
+
+
+def field_errors(got, want):
+    """(max |d| / max|want| over samples whose support agrees, number of samples whose
+    zero/non-zero support differs = discrete-decision flips)"""
+    flips = int(np.count_nonzero((got == 0) != (want == 0)))
+    scale = max(np.abs(want).max(), 1e-300)
+    return np.abs(got - want).max() / scale, flips
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_nearfield_golden_windows(ma, name):
+    case = np.load(golden_io.golden_path(name))
+    out = ma.build_nearfield(**case_args(case))
+    for got, key in zip(out[:4], ('Ex', 'Ey', 'Hx', 'Hy')):
+        err, flips = field_errors(got, case[key])
+        assert flips == 0, (key, flips)
+        assert err < TOL, (key, err)
+    assert abs(out[6] - case['power']) <= 1e-12 * abs(case['power'])
+    assert out[7] == case['n_glass']
+
+
+def test_nearfield_default_grid_golden_and_oracle(ma):
+    from oracle import nearfield_oracle
+    case = np.load(golden_io.golden_path('nearfield_A_default_grid.npz'))
+    args = case_args(case, x_pts=None, y_pts=None)
+    out = ma.build_nearfield(**args)
+    assert np.array_equal(out[4], case['x_pts']) and np.array_equal(out[5], case['y_pts'])
+    s = int(case['stride'])
+    sl = (slice(s // 2, None, s), slice(s // 3, None, s))
+    for i, key in enumerate(('Ex', 'Ey', 'Hx', 'Hy')):
+        assert np.abs(out[i][sl] - case[key]).max() / case['norms'][i] < TOL, key
+        assert (out[i] != 0).sum() == case['nonzero'][i]
+    assert abs(out[6] - case['power']) <= 1e-12 * abs(case['power'])
+    decisions = {}
+    want = nearfield_oracle.build_nearfield(decisions=decisions, **args)
+    for i in range(4):
+        err, flips = field_errors(out[i], want[i])
+        assert flips == 0 and err < TOL
+
+
+def test_big_equals_single(ma):
+    case = np.load(golden_io.golden_path('nearfield_B_straddle_offaxis_y.npz'))
+    args = case_args(case)
+    one = ma.build_nearfield(**args)
+    args.pop('dipole_moment')
+    big = ma.build_nearfield_big(pts_at_a_time=48 * 7, **args)
+    for a, b in zip(one[:4], big[:4]):
+        assert np.array_equal(a, b)       # strips are independent: bit-identical
+    assert abs(one[6] - big[6]) <= 1e-14 * abs(one[6])
+
+
+def test_empty_window_shortcut(ma):
+    case = np.load(golden_io.golden_path('nearfield_B_edge_onaxis_x.npz'))
+    far = case['x_pts'] + 400e-6
+    out = ma.build_nearfield(**case_args(case, x_pts=far))
+    assert all(not o.any() for o in out[:4]) and out[6] == 0 and isinstance(out[6], int)
+
+
+def test_negative_cases(ma):
+    neg = np.load(golden_io.golden_path('negative_cases.npz'))
+    base = np.load(golden_io.golden_path('nearfield_B_periphery_onaxis_x.npz'))
+    center = np.load(golden_io.golden_path('nearfield_B_center_onaxis_x.npz'))
+    um = 1e-6
+    wx = base['x_pts']
+    overrides = {
+        'coarse_pitch': dict(x_pts=wx[::2]),
+        'nonuniform': dict(x_pts=np.hstack((wx[:-1], wx[-1] + 1e-9))),
+        'source_above': dict(source_z=1e-6),
+        'bad_pol': dict(source_pol='s'),
+        'plane_z': dict(source_z=-float('inf'), source_pol='z'),
+        'ux_overrun': dict(source_x=-180 * um),
+        'uy_overrun': dict(source_y=150 * um, source_x=100 * um),
+        'plane_wave_overrun': dict(source_z=-float('inf')),
+        'center_overrun': dict(source_x=-60 * um, source_z=-60 * um, x_pts=center['x_pts'],
+                               y_pts=center['y_pts']),
+    }
+    for label, ov in overrides.items():
+        exc = {'AssertionError': AssertionError, 'ValueError': ValueError}[str(neg[label + '_type'])]
+        with pytest.raises(exc) as info:
+            ma.build_nearfield(**case_args(base, **ov))
+        if exc is ValueError:
+            assert info.value.args[0] == str(neg[label + '_msg']), label
+            np.testing.assert_allclose([float(v) for v in info.value.args[1:]],
+                                       neg[label + '_vals'], rtol=1e-12, err_msg=label)
+    from metalens_amd.grating import n_glass
+    with pytest.raises(ValueError) as info:
+        n_glass(532)
+    assert info.value.args[0] == str(neg['bad_wavelength_msg'])
+
+
+def test_farfield_lattice_golden(ma):
+    z = np.load(golden_io.golden_path('farfield_B_periphery_window.npz'))
+    nf = np.load(golden_io.golden_path(str(z['nearfield'])))
+    P, total_P, ux, uy, dux, duy = ma.farfield_from_nearfield(
+        z['fftEx'], z['fftEy'], z['fftHx'], z['fftHy'], nf['x_pts'], nf['y_pts'],
+        float(z['wavelength']), float(z['n_glass']), Z0=float(z['Z0']))
+    assert np.array_equal(np.isnan(P), np.isnan(z['P'])) and np.isnan(P).any()
+    ok = ~np.isnan(P)
+    assert np.abs(P[ok] - z['P'][ok]).max() <= 1e-13 * np.nanmax(z['P'])
+    assert abs(total_P - z['total_P']) <= 1e-13 * abs(z['total_P'])
+    assert np.array_equal(ux, z['ux']) and np.array_equal(uy, z['uy'])
+    assert dux == z['dux'] and duy == z['duy']
+
+
+def test_direct_transform_on_fft_lattice_golden(ma):
+    """N, L from the GEMM-cast aperture sum == the reference's fft bin x dA
+    (nearfield_farfield.py:135-138) on lattice directions"""
+    z = np.load(golden_io.golden_path('farfield_B_periphery_window.npz'))
+    nf = np.load(golden_io.golden_path(str(z['nearfield'])))
+    wl, n = float(z['wavelength']), float(z['n_glass'])
+    x, y = nf['x_pts'], nf['y_pts']
+    ux = ma.fft_direction_cosines(len(x), x[1] - x[0], wl, n)
+    uy = ma.fft_direction_cosines(len(y), y[1] - y[0], wl, n)
+    out = ma.farfield_direct(nf['Ex'], nf['Ey'], nf['Hx'], nf['Hy'], x, y, wl, n, ux, uy,
+                             Z0=float(z['Z0']))
+    for key in ('Nx', 'Ny', 'Lx', 'Ly'):
+        assert np.abs(out[key] - z[key]).max() <= TOL * np.abs(z[key]).max(), key
+    # power on the lattice equals the reference's (un-shifted) P
+    Pref = np.fft.ifftshift(z['P'])
+    ok = ~np.isnan(Pref)
+    assert np.array_equal(np.isnan(out['P']), ~ok)
+    assert np.abs(out['P'][ok] - Pref[ok]).max() <= 1e-11 * np.nanmax(Pref)
+
+
+@pytest.mark.parametrize('shape', [(48, 40, 37, 29), (130, 70, 65, 130), (64, 64, 64, 64),
+                                   (17, 200, 5, 3)])
+def test_direct_transform_vs_oracle_ragged(ma, shape):
+    """off-lattice directions, sizes that are not multiples of any tile"""
+    from oracle import farfield_oracle
+    nx, ny, mx, my = shape
+    rng = np.random.default_rng(nx * 1000 + ny)
+    F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+    wl, n = 580e-9, 1.459
+    x = (np.arange(nx) - 3.3) * (wl / 2.2)
+    y = (np.arange(ny) + 11.1) * (wl / 2.3)
+    ux = np.linspace(-0.61, 0.55, mx)
+    uy = np.linspace(-0.3, 0.72, my)
+    got = ma.farfield_direct(*F, x, y, wl, n, ux, uy)
+    want = farfield_oracle.farfield_direct(*F, x, y, wl, n, ux, uy)
+    for key in ('Nx', 'Ny', 'Lx', 'Ly', 'a_theta', 'a_phi'):
+        assert np.abs(got[key] - want[key]).max() <= TOL * np.abs(want[key]).max(), key
+    ok = ~np.isnan(want['P'])
+    assert np.array_equal(np.isnan(got['P']), ~ok)
+    assert np.abs(got['P'][ok] - want['P'][ok]).max() <= 1e-11 * want['P'][ok].max()
+
+
+def test_pair_list_vs_oracle(ma):
+    from oracle import farfield_oracle
+    rng = np.random.default_rng(7)
+    nx, ny, D = 50, 66, 300
+    F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+    wl, n = 580e-9, 1.459
+    x = np.arange(nx) * (wl / 2.2)
+    y = np.arange(ny) * (wl / 2.2)
+    th = rng.uniform(0, 1.2, D)
+    ph = rng.uniform(0, 2 * np.pi, D)
+    ux, uy = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph)
+    got = ma.farfield_direct(*F, x, y, wl, n, ux, uy, pair_list=True)
+    want = farfield_oracle.radiation_vectors_pairs(*F, x, y, wl, n, ux, uy)
+    for g, w, key in zip((got['Nx'], got['Ny'], got['Lx'], got['Ly']), want, 'NNLL'):
+        assert g.shape == (D,)
+        assert np.abs(g - w).max() <= TOL * np.abs(w).max(), key
+
+
+def test_sharded_rows_sum_to_whole(ma):
+    """linearity: transforming row blocks separately and accumulating equals the whole
+    aperture (this is the multi-GPU decomposition, minus the all-reduce)"""
+    from metalens_amd import _lib
+    rng = np.random.default_rng(3)
+    nx, ny, mx, my = 96, 80, 33, 47
+    F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+    wl, n = 580e-9, 1.459
+    x = np.arange(nx) * (wl / 2.2)
+    y = np.arange(ny) * (wl / 2.2)
+    ux = np.linspace(-0.4, 0.4, mx)
+    uy = np.linspace(-0.5, 0.3, my)
+    whole = ma.farfield_direct(*F, x, y, wl, n, ux, uy)
+    ctx = _lib.default_context()
+    t = ma.FarfieldTransform(nx, ny, x[1] - x[0], y[1] - y[0], wl, n, ux, uy, ctx=ctx)
+    first = True
+    for r0, r1 in ((0, 31), (31, 64), (64, 96)):
+        part = [np.ascontiguousarray(f[r0:r1]) for f in F]
+        _lib.check(ctx.lib.ml_fields_upload(ctx.handle, r1 - r0, ny, *[_lib.dptr(a) for a in part]))
+        t.transform(row0=r0, accumulate=not first)
+        first = False
+    got = t.radiation_vectors()
+    for key in ('Nx', 'Ny', 'Lx', 'Ly'):
+        assert np.abs(got[key] - whole[key]).max() <= 1e-13 * np.abs(whole[key]).max(), key
+
+
+def test_full_size_roundtrip_properties(ma):
+    """BASELINE config[1] size (2048^2 -> 256^2): size-independent checks - the direct
+    transform of a separable field equals the outer product of 1-D transforms, and is
+    linear."""
+    from oracle import farfield_oracle
+    N, M = 2048, 256
+    rng = np.random.default_rng(11)
+    wl, n = 580e-9, 1.459
+    x = (np.arange(N) - N / 2) * (wl / 2.2)
+    fx = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    fy = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    F = np.outer(fx, fy)
+    ux = np.linspace(-0.05, 0.05, M)
+    uy = np.linspace(-0.04, 0.06, M)
+    got = ma.farfield_direct(F, 2 * F, -F, 0.5 * F, x, x, wl, n, ux, uy)
+    A = farfield_oracle.axis_twiddles(N, x[1] - x[0], ux, wl, n)
+    B = farfield_oracle.axis_twiddles(N, x[1] - x[0], uy, wl, n)
+    dA = (x[1] - x[0]) ** 2
+    want = np.outer(A @ fx, B @ fy) * dA
+    scale = np.abs(want).max()
+    assert np.abs(got['Ly'] - (-want)).max() <= TOL * scale      # Ly = -F[Ex]
+    assert np.abs(got['Lx'] - 2 * want).max() <= TOL * 2 * scale  # Lx = F[Ey]
+    assert np.abs(got['Ny'] - (-want)).max() <= TOL * scale      # Ny = F[Hx]
+    assert np.abs(got['Nx'] - (-0.5 * want)).max() <= TOL * scale  # Nx = -F[Hy]
