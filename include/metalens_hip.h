@@ -75,11 +75,18 @@ int ml_upload_table(ml_ctx *ctx, int slot,
  *   ring_r_center, ring_period, ring_dphi (= 2*pi/num_around_circle), ring_lateral
  *   (= r_center * dphi), all [n_rings] float64 evaluated by the host in the reference's
  *   operation order; ring_gc[n_rings] = gratingcollection_index_here_list.
- *   cells[n_cells][3] = lens_center_summary rows (x, y, index into the HexGridSet).     */
+ *   cells[n_cells][3] = lens_center_summary rows (x, y, index into the HexGridSet).
+ *   rot_table[rot_len][2]: (cos, sin) of every possible grating rotation
+ *   sector*dphi (nearfield.py:169-171), evaluated by the HOST's NumPy so that the
+ *   rotation enters the large phases bit-identically to the reference on that host;
+ *   ring_rot_center[r] is the table index of sector 0 for ring r and ring_rot_half[r]
+ *   the largest |sector| tabulated.                                                     */
 int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *ring_boundaries,
                      const double *ring_r_center, const double *ring_period,
                      const double *ring_dphi, const double *ring_lateral,
-                     const int32_t *ring_gc, int n_cells, const double *cells);
+                     const int32_t *ring_gc, const double *rot_table, int rot_len,
+                     const int32_t *ring_rot_center, const int32_t *ring_rot_half,
+                     int n_cells, const double *cells);
 
 /* ---- near-field synthesis: nearfield.build_nearfield (nearfield.py:66-480) ---------
  * Scalars are evaluated by the host with the reference's own expressions so that they

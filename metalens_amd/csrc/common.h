@@ -147,6 +147,7 @@ struct ml_ctx {
     std::vector<double> h_ring_period;
     std::vector<int32_t> h_ring_gc;
     ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
+    ml::DevBuf rot_table, ring_rot_center, ring_rot_half;
     ml::DevBuf ring_i2, ring_t2;     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     int lut_buckets = 0;

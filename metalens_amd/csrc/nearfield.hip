@@ -33,7 +33,8 @@ struct NfArgs {
     // rings
     int n_rings;
     const double *B, *rc, *period, *dphi, *lateral, *ring_t2;
-    const int *gc, *ring_i2, *lut;
+    const int *gc, *ring_i2, *lut, *rot_center, *rot_half;
+    const double2 *rot_table;
     int lut_buckets;
     double lut_inv_h;
     // centre cells
@@ -234,9 +235,12 @@ __global__ __launch_bounds__(256) void nearfield_kernel(const NfArgs a) {
                 const double rcen = a.rc[ring], lateral = a.lateral[ring];
                 // ---- sector and local frame (nearfield.py:169,195-201)
                 const double phi = atan2(y, x);
-                const double rot = rint(phi / dphi) * dphi;
-                double sinr, cosr;
-                sincos(rot, &sinr, &cosr);
+                // cos / sin of the grating rotation sector*dphi come from the host's table
+                int sector = (int)rint(phi / dphi);
+                const int half = a.rot_half[ring];
+                sector = min(max(sector, -half), half);
+                const double2 cs = a.rot_table[a.rot_center[ring] + sector];
+                const double cosr = cs.x, sinr = cs.y;
                 const double uxp = ux * cosr + uy * sinr;
                 const double uyp = -ux * sinr + uy * cosr;
                 const double xp = x * cosr + y * sinr - rcen;
@@ -369,6 +373,9 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
     a.gc = ctx->ring_gc.as<int>();
     a.ring_i2 = ctx->ring_i2.as<int>();
     a.lut = ctx->ring_lut.as<int>();
+    a.rot_center = ctx->ring_rot_center.as<int>();
+    a.rot_half = ctx->ring_rot_half.as<int>();
+    a.rot_table = ctx->rot_table.as<double2>();
     a.lut_buckets = ctx->lut_buckets;
     a.lut_inv_h = ctx->lut_inv_h;
     a.n_cells = ctx->n_cells;

@@ -1,0 +1,96 @@
+"""Multi-GPU plumbing: one process per GPU, RCCL over xGMI through the C ABI.
+
+What is distributed: the aperture ROWS (x index).  Near-field
+synthesis is independent per sample and the far-field sum is linear in the aperture
+(the reason the reference's own strip chunking is exact, nearfield.py:482-516), so
+each rank synthesises and transforms its own rows with no communication, and the
+partial radiation vectors ``Nx,Ny,Lx,Ly [mx][my]`` are summed with ONE all-reduce
+before the (non-linear) projection.  Rows rather than radial annuli: every rank gets
+the same GEMM shape, and contiguous rows are one contiguous block of the C-ordered
+field arrays.
+
+No PyTorch here: ranks find each other through the environment variables that
+``python -m torch.distributed.run`` exports (RANK, LOCAL_RANK, WORLD_SIZE,
+MASTER_PORT) and the 128-byte RCCL unique id travels through a file in /tmp (all
+ranks are on one node).
+"""
+import os
+import time
+
+import numpy as np
+
+from . import _lib
+
+
+def env_rank():
+    return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
+            int(os.environ.get('WORLD_SIZE', '1')))
+
+
+def row_block(n_rows, world, rank, align=16):
+    """rows [r0, r1) of rank ``rank``: contiguous, as equal as possible, block edges
+    aligned to ``align`` rows where that is possible (the GEMM tiles are 16 high)"""
+    if world == 1:
+        return 0, n_rows
+    edges = [min(n_rows, int(round(n_rows * k / world / align)) * align) for k in range(world + 1)]
+    edges[0], edges[-1] = 0, n_rows
+    for k in range(1, world + 1):
+        edges[k] = max(edges[k], edges[k - 1])
+    return edges[rank], edges[rank + 1]
+
+
+def _id_path():
+    key = '%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'),
+                        os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())
+    return os.path.join(os.environ.get('TMPDIR', '/tmp'), 'metalens_rccl_id_%s.bin' % key)
+
+
+def exchange_unique_id(rank, world, timeout=120.0, path=None):
+    """rank 0 creates the RCCL unique id and publishes it atomically; the others poll"""
+    path = path or _id_path()
+    lib = _lib.load()
+    if rank == 0:
+        buf = (_lib.c_uint8 * 128)()
+        _lib.check(lib.ml_comm_unique_id(buf))
+        tmp = path + '.tmp%d' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(bytes(buf))
+        os.replace(tmp, path)
+        return bytes(buf)
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                data = f.read()
+            if len(data) == 128:
+                return data
+        except FileNotFoundError:
+            pass
+        if time.time() - t0 > timeout:
+            raise _lib.MetalensHipError('timed out waiting for the RCCL unique id at ' + path)
+        time.sleep(0.05)
+
+
+def init_comm(ctx, rank, world):
+    if world <= 1:
+        return
+    uid = exchange_unique_id(rank, world)
+    buf = (_lib.c_uint8 * 128).from_buffer_copy(uid)
+    _lib.check(ctx.lib.ml_comm_init(ctx.handle, buf, world, rank))
+    barrier(ctx)
+    if rank == 0:
+        try:
+            os.remove(_id_path())
+        except OSError:
+            pass
+
+
+def barrier(ctx):
+    _lib.check(ctx.lib.ml_comm_barrier(ctx.handle))
+
+
+def allreduce_host(ctx, values, op='sum'):
+    a = np.ascontiguousarray(values, dtype=np.float64).copy()
+    _lib.check(ctx.lib.ml_comm_allreduce_host(ctx.handle, _lib.dptr(a), a.size,
+                                              {'sum': 0, 'max': 1}[op]))
+    return a

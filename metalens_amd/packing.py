@@ -100,12 +100,29 @@ def pack_layout(lens_periphery_summary, lens_center_summary):
     dphi = _lib.f64(2 * pi / num)
     lateral = _lib.f64(r_center * dphi)
     ring_gc = np.ascontiguousarray(S['gratingcollection_index_here_list'], dtype=np.int32)
+    # (cos, sin) of every possible grating rotation sector*dphi (nearfield.py:169-171), one
+    # run of the table per distinct dphi.  Evaluated HERE with NumPy - not on the GPU - because
+    # the rotation multiplies lens-sized coordinates inside phases of ~1e4 rad: one ulp of
+    # cos/sin is ~1e-12 rad of phase, and this way it is the same ulp the reference gets.
+    rot_center = np.zeros(r_center.size, dtype=np.int32)
+    rot_half = np.zeros(r_center.size, dtype=np.int32)
+    runs, at = [], 0
+    for value in np.unique(dphi):
+        half = int(np.ceil(pi / value)) + 1
+        sector = np.arange(-half, half + 1, dtype=np.float64)
+        rot = sector * value
+        runs.append(np.column_stack((np.cos(rot), np.sin(rot))))
+        rot_center[dphi == value] = at + half
+        rot_half[dphi == value] = half
+        at += 2 * half + 1
+    rot_table = np.ascontiguousarray(np.vstack(runs))
     if lens_center_summary is None or len(lens_center_summary) == 0:
         cells = np.zeros((0, 3))
     else:
         cells = _lib.f64(np.asarray(lens_center_summary)[:, 0:3])
     return {'boundaries': boundaries, 'r_center': r_center, 'period': period, 'dphi': dphi,
-            'lateral': lateral, 'ring_gc': ring_gc, 'cells': cells}
+            'lateral': lateral, 'ring_gc': ring_gc, 'cells': cells, 'rot_table': rot_table,
+            'rot_center': rot_center, 'rot_half': rot_half}
 
 
 def upload_layout(ctx, lens_periphery_summary, lens_center_summary):
@@ -120,6 +137,7 @@ def upload_layout(ctx, lens_periphery_summary, lens_center_summary):
     _lib.check(ctx.lib.ml_upload_layout(
         ctx.handle, n_rings, _lib.dptr(L['boundaries']), _lib.dptr(L['r_center']),
         _lib.dptr(L['period']), _lib.dptr(L['dphi']), _lib.dptr(L['lateral']),
-        _lib.iptr(L['ring_gc']), len(L['cells']),
+        _lib.iptr(L['ring_gc']), _lib.dptr(L['rot_table']), len(L['rot_table']),
+        _lib.iptr(L['rot_center']), _lib.iptr(L['rot_half']), len(L['cells']),
         _lib.dptr(L['cells']) if len(L['cells']) else None))
     ctx.layout_token = token

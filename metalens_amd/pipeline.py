@@ -1,0 +1,89 @@
+"""The whole hot path, GPU-resident: near-field synthesis -> aperture->direction
+transform -> (all-reduce) -> projection, with nothing crossing PCIe in between.
+
+This is the composition README.md:27 of the reference describes
+(``build_nearfield`` -> ``fft2(fftshift)`` -> ``farfield_from_nearfield``) with the
+FFT replaced by the direct transform to a chosen direction grid.  ``bench.py``
+times ``step()``; the drop-in functions in nearfield.py / nearfield_farfield.py
+are the same kernels with host arrays at the boundary.
+"""
+import numpy as np
+
+from . import _lib, constants, dist, packing
+from .constants import nm
+from .grating import n_glass as tabulated_n_glass
+from .nearfield import _check_axis, _raise_violation, nearfield_params
+
+
+class HotPath:
+    def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
+                 hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
+                 c0=None, Z0=None, ctx=None, rank=0, world=1):
+        self.ctx = ctx or _lib.default_context()
+        self.rank, self.world = rank, world
+        self.c0 = constants.c0 if c0 is None else c0
+        self.Z0 = constants.Z0 if Z0 is None else Z0
+        source_x, source_y, source_z, source_pol = source
+        assert source_z < 0 and source_pol in ('x', 'y', 'z')
+        _check_axis(x_pts, wavelength)
+        _check_axis(y_pts, wavelength)
+        S = lens_periphery_summary
+        wl_nm = int(round(wavelength / nm))
+        n_glass = S['gratingcollection_list'][0].grating_list[0].n_glass
+        if n_glass == 0:
+            n_glass = tabulated_n_glass(wl_nm)
+        self.n_glass, self.wavelength = n_glass, wavelength
+        packing.upload_tables(self.ctx, S['gratingcollection_list'], hexgridset, wl_nm)
+        packing.upload_layout(self.ctx, S, lens_center_summary)
+        self.params = nearfield_params(source_x, source_y, source_z, source_pol, wavelength,
+                                       n_glass, dipole_moment, self.c0, self.Z0)
+        self.x_all = _lib.f64(x_pts)
+        self.y = _lib.f64(y_pts)
+        self.row0, self.row1 = dist.row_block(self.x_all.size, world, rank)
+        self.x_local = np.ascontiguousarray(self.x_all[self.row0:self.row1])
+        self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
+        self.pair_list = bool(pair_list)
+        self.shape = (self.ux.size,) if pair_list else (self.ux.size, self.uy.size)
+        self.dxp = x_pts[1] - x_pts[0]
+        self.dyp = y_pts[1] - y_pts[0]
+
+    def step(self):
+        """queue one pass of the hot path on the context's stream (asynchronous)"""
+        ctx, lib = self.ctx, self.ctx.lib
+        _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
+                                        self.dyp, self.wavelength, self.n_glass,
+                                        _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
+                                        self.uy.size, int(self.pair_list)))
+        if self.x_local.size:
+            _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(self.params),
+                                              _lib.dptr(self.x_local), self.x_local.size,
+                                              _lib.dptr(self.y), self.y.size))
+            _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
+        if self.world > 1:
+            _lib.check(lib.ml_farfield_allreduce(ctx.handle))
+        _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
+
+    def sync(self):
+        self.ctx.sync()
+
+    def results(self):
+        """fetch what the last step left on the GPU; raises the reference's ValueError if a
+        sample fell outside the characterisation tables"""
+        ctx, lib = self.ctx, self.ctx.lib
+        power = _lib.c_double(0)
+        viol = (_lib.BoundViolation * 8)()
+        n_viol = _lib.c_int(0)
+        _lib.check(lib.ml_nearfield_result(ctx.handle, _lib.byref(power), viol, 8,
+                                           _lib.byref(n_viol)))
+        if n_viol.value:
+            _raise_violation(viol[0], ctx)
+        P = np.empty(self.shape)
+        a_theta = np.empty(self.shape, dtype=np.complex128)
+        a_phi = np.empty(self.shape, dtype=np.complex128)
+        _lib.check(lib.ml_farfield_project(ctx.handle, self.Z0, _lib.dptr(P), _lib.dptr(a_theta),
+                                           _lib.dptr(a_phi)))
+        vec = [np.empty(self.shape, dtype=np.complex128) for _ in range(4)]
+        _lib.check(lib.ml_farfield_download(ctx.handle, *[_lib.dptr(v) for v in vec]))
+        local_power = power.value * self.dxp * self.dyp
+        return {'P': P, 'a_theta': a_theta, 'a_phi': a_phi, 'Nx': vec[0], 'Ny': vec[1],
+                'Lx': vec[2], 'Ly': vec[3], 'power_local_rows': local_power}
