@@ -114,13 +114,18 @@ def axis_twiddles(n, step, u, wavelength, n_glass):
     return (np.cos(ang) + 1j * np.sin(ang)).astype(complex)
 
 
-def radiation_vectors(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, uy):
+def radiation_vectors(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, uy,
+                      row_range=None):
     """``Nx, Ny, Lx, Ly`` on the tensor grid ``ux x uy`` by direct summation
     over the aperture, written as two dense products A @ F @ B^T
-    (nearfield_farfield.py:111-120,135-138)."""
+    (nearfield_farfield.py:111-120,135-138).  With ``row_range=(r0, r1)`` the fields
+    hold only aperture rows r0..r1-1 of ``xp_list`` and the result is that block's
+    partial sum (the multi-GPU decomposition)."""
     dxp = xp_list[1] - xp_list[0]
     dyp = yp_list[1] - yp_list[0]
     A = axis_twiddles(len(xp_list), dxp, ux, wavelength, n_glass)
+    if row_range is not None:
+        A = A[:, row_range[0]:row_range[1]]
     B = axis_twiddles(len(yp_list), dyp, uy, wavelength, n_glass)
     dA = dxp * dyp
 

@@ -1,0 +1,82 @@
+"""The N>1 decomposition on CPU: world_size-2 processes (gloo) each take their block of
+aperture rows (metalens_amd.dist.row_block), compute the near field and the partial radiation
+vectors of those rows with the CPU oracle, all-reduce, and must reproduce the unsharded
+result.  This is exactly the data flow of the GPU path (near field -> partial N,L -> one
+all-reduce(sum) -> projection) with gloo standing in for RCCL and the oracle for the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import golden_io
+from metalens_amd import dist
+
+
+def test_row_block_partitions_cover_everything():
+    for n in (1, 15, 16, 400, 2048, 2897, 8192):
+        for world in (1, 2, 3, 4, 8):
+            blocks = [dist.row_block(n, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            for (a0, a1), (b0, b1) in zip(blocks[:-1], blocks[1:]):
+                assert a1 == b0 and a0 <= a1
+            sizes = [b - a for a, b in blocks]
+            if n >= 64 * world:
+                assert max(sizes) - min(sizes) <= 32
+                assert all(a % 16 == 0 for a, _ in blocks)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as td
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import farfield_oracle, nearfield_oracle
+    case = np.load(golden_io.golden_path('nearfield_B_straddle_offaxis_y.npz'))
+    lens = golden_io.load_lens(golden_io.golden_path(str(case['lens'])))
+    x, y = case['x_pts'], case['y_pts']
+    wl = float(case['wavelength'])
+    r0, r1 = dist.row_block(len(x), world, rank, align=4)
+    Ex, Ey, Hx, Hy, _, _, power, n_glass = nearfield_oracle.build_nearfield(
+        float(case['source_x']), float(case['source_y']), float(case['source_z']),
+        str(case['source_pol']), wl, lens[0], lens[1], lens[2], x_pts=x[r0:r1], y_pts=y,
+        c0=float(case['c0']), Z0=float(case['Z0']))
+    ux = np.linspace(-0.3, 0.5, 9)
+    uy = np.linspace(-0.2, 0.2, 7)
+    part = farfield_oracle.radiation_vectors(Ex, Ey, Hx, Hy, x, y, wl, n_glass, ux, uy,
+                                             row_range=(r0, r1))
+    # RCCL has no complex type: reduce as float64 pairs, exactly like ml_farfield_allreduce
+    buf = torch.from_numpy(np.stack(part).view(np.float64).copy())
+    td.all_reduce(buf, op=td.ReduceOp.SUM)
+    p = torch.tensor([power], dtype=torch.float64)
+    td.all_reduce(p, op=td.ReduceOp.SUM)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, 'reduced.npz'), vectors=buf.numpy().view(np.complex128),
+                 power=p.numpy(), ux=ux, uy=uy)
+    td.destroy_process_group()
+
+
+def test_two_rank_sharded_sum_equals_whole(tmp_path):
+    torch = pytest.importorskip('torch')
+    import torch.multiprocessing as mp
+    from oracle import farfield_oracle
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(str(tmp_path), 'reduced.npz'))
+    case = np.load(golden_io.golden_path('nearfield_B_straddle_offaxis_y.npz'))
+    whole = farfield_oracle.radiation_vectors(case['Ex'], case['Ey'], case['Hx'], case['Hy'],
+                                              case['x_pts'], case['y_pts'],
+                                              float(case['wavelength']), float(case['n_glass']),
+                                              z['ux'], z['uy'])
+    for got, want in zip(z['vectors'], whole):
+        assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
+    assert abs(z['power'][0] - case['power']) <= 1e-13 * abs(case['power'])
