@@ -91,6 +91,7 @@ struct TableSlot {
     DevBuf axis0, axis1, values, order_k;
     std::vector<double> h_axis2;
     std::vector<double> h_order_k;
+    std::vector<double> h_values;   // host copy, for the per-ring pre-interpolation
     double bounds[6] = {0, 0, 0, 0, 0, 0};
     double center_periods[2] = {0, 0};
 };
@@ -144,11 +145,12 @@ struct ml_ctx {
     // layout
     bool have_layout = false;
     int n_rings = 0, n_cells = 0;
-    std::vector<double> h_ring_period;
+    std::vector<double> h_ring_period, h_ring_lateral;
     std::vector<int32_t> h_ring_gc;
     ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
     ml::DevBuf rot_table, ring_rot_center, ring_rot_half;
-    ml::DevBuf ring_i2, ring_t2;     // per-ring location on the table's period axis
+    ml::DevBuf ring_i2, ring_t2;
+    ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     int lut_buckets = 0;
     double lut_inv_h = 0;

@@ -118,6 +118,41 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     }
     ML_TRY(h2d(ctx, ctx->ring_i2, i2.data(), i2.size() * sizeof(int32_t)));
     ML_TRY(h2d(ctx, ctx->ring_t2, t2.data(), t2.size() * sizeof(double)));
+
+    // Fast kernel: per-ring tables with the period axis already interpolated
+    // (v[..., i2] * (1 - t2) + v[..., i2 + 1] * t2), complex [order][n0][n1][4], and the
+    // per-ring order wavenumbers ox*2*pi/grating_period, oy*2*pi/lateral_period
+    // (nearfield.py:268-269: per-sample expressions of per-ring constants).
+    std::vector<long long> tab_off(ctx->n_rings);
+    std::vector<int32_t> ok_off(ctx->n_rings);
+    size_t tab_total = 0, ok_total = 0;
+    for (int r = 0; r < ctx->n_rings; ++r) {
+        const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
+        tab_off[r] = (long long)tab_total;
+        ok_off[r] = (int32_t)ok_total;
+        tab_total += (size_t)t.n_orders * t.n0 * t.n1 * 4;
+        ok_total += (size_t)t.n_orders * 2;
+    }
+    std::vector<double> tab(tab_total * 2), ok(ok_total);
+    for (int r = 0; r < ctx->n_rings; ++r) {
+        const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
+        const double w1 = t2[r], w0 = 1 - t2[r];
+        double *dst = tab.data() + (size_t)tab_off[r] * 2;
+        for (int o = 0; o < t.n_orders; ++o) {
+            for (int a = 0; a < t.n0 * t.n1; ++a) {
+                const double *lo = t.h_values.data() +
+                                   ((((size_t)o * t.n0 * t.n1 + a) * t.n2 + i2[r]) * 4) * 2;
+                const double *hi = lo + 8;
+                for (int q = 0; q < 8; ++q) *dst++ = lo[q] * w0 + hi[q] * w1;
+            }
+            ok[ok_off[r] + 2 * o] = t.h_order_k[2 * o] / ctx->h_ring_period[r];
+            ok[ok_off[r] + 2 * o + 1] = t.h_order_k[2 * o + 1] / ctx->h_ring_lateral[r];
+        }
+    }
+    ML_TRY(h2d(ctx, ctx->ring_tab, tab.data(), tab.size() * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_tab_off, tab_off.data(), tab_off.size() * sizeof(long long)));
+    ML_TRY(h2d(ctx, ctx->ring_ok, ok.data(), ok.size() * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->ring_ok_off, ok_off.data(), ok_off.size() * sizeof(int32_t)));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return ML_OK;
 }
@@ -184,7 +219,8 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     ctx->center.order_k.release();
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
-                      &ctx->ring_i2, &ctx->ring_t2, &ctx->rot_table, &ctx->ring_rot_center,
+                      &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
+                      &ctx->ring_ok_off, &ctx->rot_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
@@ -241,6 +277,7 @@ int ml_upload_table(ml_ctx *ctx, int slot, const double *axis0, int n0, const do
     t.n_orders = n_orders;
     t.h_axis2.assign(axis2, axis2 + n2);
     t.h_order_k.assign(order_k, order_k + 2 * n_orders);
+    t.h_values.assign(values, values + (size_t)n_orders * n0 * n1 * n2 * 4 * 2);
     for (int k = 0; k < 6; ++k) t.bounds[k] = bounds[k];
     if (center_periods) {
         t.center_periods[0] = center_periods[0];
@@ -281,6 +318,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     ML_TRY(h2d(ctx, ctx->ring_rot_center, ring_rot_center, n_rings * sizeof(int32_t)));
     ML_TRY(h2d(ctx, ctx->ring_rot_half, ring_rot_half, n_rings * sizeof(int32_t)));
     ctx->h_ring_period.assign(period, period + n_rings);
+    ctx->h_ring_lateral.assign(lateral, lateral + n_rings);
     ctx->h_ring_gc.assign(ring_gc, ring_gc + n_rings);
 
     // uniform-in-r lookup for searchsorted(boundaries, r, 'left'):

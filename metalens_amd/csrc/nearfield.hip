@@ -13,71 +13,11 @@
 //                                            amplitudes of one grid node
 //   ring arrays     float64 [n_rings]        + a uniform-in-r lookup table for the ring search
 //   centre cells    sorted by spatial bin    (uniform grid, exact nearest neighbour)
-#include "common.h"
+#include <cstdlib>
+
+#include "nearfield_dev.h"
 
 namespace ml {
-
-struct c2 {
-    double r, i;
-};
-__device__ __forceinline__ c2 operator+(c2 a, c2 b) { return {a.r + b.r, a.i + b.i}; }
-__device__ __forceinline__ c2 cmul(c2 a, c2 b) {
-    return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r};
-}
-__device__ __forceinline__ c2 scale(c2 a, double s) { return {a.r * s, a.i * s}; }
-
-struct NfArgs {
-    ml_nearfield_params p;
-    const double *x_pts, *y_pts;
-    int nx, ny;
-    // rings
-    int n_rings;
-    const double *B, *rc, *period, *dphi, *lateral, *ring_t2;
-    const int *gc, *ring_i2, *lut, *rot_center, *rot_half;
-    const double2 *rot_table;
-    int lut_buckets;
-    double lut_inv_h;
-    // centre cells
-    int n_cells;
-    const double *cx, *cy;
-    const int *cwhich, *cindex, *bin_start;
-    int bins_x, bins_y;
-    double bx0, by0, bh;
-    // tables
-    const TableDesc *tables;
-    // outputs
-    double *fields;
-    double *partial_power;
-    unsigned long long *viol;
-};
-
-// monotone map double -> uint64 (so that integer max == floating max)
-__device__ __forceinline__ unsigned long long ordered_key(double v) {
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
-}
-
-// Record an out-of-table sample.  Rare path: only violators touch memory.  "min" checks
-// store the complemented key so that every slot is a plain atomicMax starting from 0.
-__device__ __noinline__ void report(unsigned long long *viol, int slot, int order, int check,
-                                    double v) {
-    unsigned long long k = ordered_key(v);
-    if ((check & 1) == 0) k = ~k;
-    atomicMax(&viol[((size_t)slot * MAX_ORDERS + order) * 6 + check], k);
-}
-
-__device__ __forceinline__ void check_bounds(const NfArgs &a, const TableDesc &T, int slot,
-                                             int order, double u, double v, double g,
-                                             bool with_period) {
-    if (u < T.bounds[0]) report(a.viol, slot, order, 0, u);
-    if (u > T.bounds[1]) report(a.viol, slot, order, 1, u);
-    if (v < T.bounds[2]) report(a.viol, slot, order, 2, v);
-    if (v > T.bounds[3]) report(a.viol, slot, order, 3, v);
-    if (with_period) {
-        if (g < T.bounds[4]) report(a.viol, slot, order, 4, g);
-        if (g > T.bounds[5]) report(a.viol, slot, order, 5, g);
-    }
-}
 
 // scipy find_indices on a short axis: largest i with axis[i] <= x, clamped to [0, n-2]
 __device__ __forceinline__ void locate(const double *axis, int n, double x, int &i, double &t) {
@@ -136,43 +76,7 @@ __device__ __forceinline__ void add_order(c2 &Ex, c2 &Ey, c2 &Hx, c2 &Hy, double
     Hy = Hy + cmul(scale(afx, Hw), ph);
 }
 
-// exact nearest centre cell (nearfield.py:363-364) through a uniform grid of bins
-__device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y) {
-    int bx = (int)floor((x - a.bx0) / a.bh);
-    int by = (int)floor((y - a.by0) / a.bh);
-    bx = min(max(bx, 0), a.bins_x - 1);
-    by = min(max(by, 0), a.bins_y - 1);
-    double best = INFINITY;
-    int best_slot = -1, best_idx = 0x7fffffff;
-    const int kmax = max(a.bins_x, a.bins_y);
-    for (int k = 0; k <= kmax; ++k) {
-        const int x_lo = bx - k, x_hi = bx + k, y_lo = by - k, y_hi = by + k;
-        for (int gx = max(x_lo, 0); gx <= min(x_hi, a.bins_x - 1); ++gx) {
-            const bool edge_col = (gx == x_lo) || (gx == x_hi);
-            const int step = edge_col ? 1 : max(2 * k, 1);
-            for (int gy = y_lo; gy <= y_hi; gy += step) {
-                if (gy < 0 || gy >= a.bins_y) continue;
-                const int b = gx * a.bins_y + gy;
-                for (int s = a.bin_start[b]; s < a.bin_start[b + 1]; ++s) {
-                    const double ex = x - a.cx[s], ey = y - a.cy[s];
-                    const double d2 = ex * ex + ey * ey;
-                    const int idx = a.cindex[s];
-                    if (d2 < best || (d2 == best && idx < best_idx)) {
-                        best = d2;
-                        best_slot = s;
-                        best_idx = idx;
-                    }
-                }
-            }
-        }
-        // every cell not yet visited is at least k*bh away
-        const double reach = k * a.bh;
-        if (best_slot >= 0 && best <= reach * reach) break;
-    }
-    return best_slot;
-}
-
-__global__ __launch_bounds__(256) void nearfield_kernel(const NfArgs a) {
+__global__ __launch_bounds__(256) void nearfield_exact_kernel(const NfArgs a) {
     const int j = blockIdx.x * 256 + threadIdx.x;   // y index (fastest in memory)
     const int i = blockIdx.y;                        // x index
     const ml_nearfield_params &p = a.p;
@@ -182,17 +86,7 @@ __global__ __launch_bounds__(256) void nearfield_kernel(const NfArgs a) {
     if (active) {
         const double x = a.x_pts[i], y = a.y_pts[j];
         const double r = sqrt(x * x + y * y);
-        // ---- which ring: searchsorted(boundaries, r, 'left') - 1  (nearfield.py:125-128)
-        int idx;   // number of boundaries strictly below r
-        if (r > a.B[a.n_rings]) {
-            idx = a.n_rings + 1;
-        } else {
-            int bucket = (int)(r * a.lut_inv_h);
-            bucket = min(max(bucket, 0), a.lut_buckets - 1);
-            idx = a.lut[bucket];
-            while (idx <= a.n_rings && a.B[idx] < r) ++idx;
-            while (idx > 0 && a.B[idx - 1] >= r) --idx;
-        }
+        const int idx = boundaries_below(a, r);   // searchsorted(..., 'left')
         const bool in_center = (idx == 0);
         const bool in_periphery = (idx >= 1 && idx <= a.n_rings);
         if (in_center || in_periphery) {
@@ -322,23 +216,9 @@ __global__ __launch_bounds__(256) void nearfield_kernel(const NfArgs a) {
                 }
             }
         }
-        // ---- store: 16 B per lane per plane, coalesced along y
-        const size_t plane = (size_t)a.nx * a.ny;
-        const size_t at = (size_t)i * a.ny + j;
-        double2 *F = reinterpret_cast<double2 *>(a.fields);
-        F[at] = make_double2(Ex.r, Ex.i);
-        F[plane + at] = make_double2(Ey.r, Ey.i);
-        F[2 * plane + at] = make_double2(Hx.r, Hx.i);
-        F[3 * plane + at] = make_double2(Hy.r, Hy.i);
+        store_fields(a, i, j, Ex, Ey, Hx, Hy);
     }
-    // ---- incident power: wave reduction, then one partial per block (fixed order)
-    for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
-    __shared__ double wave_sum[4];
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = power_here;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
-            (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+    block_power(a, power_here);
 }
 
 // deterministic tree sum of the per-block partials
@@ -356,8 +236,7 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const double *partia
     if (threadIdx.x == 0) *out = s[0];
 }
 
-int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) {
-    NfArgs a;
+void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a) {
     a.p = *p;
     a.x_pts = ctx->x_pts.as<double>();
     a.y_pts = ctx->y_pts.as<double>();
@@ -390,14 +269,35 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
     a.by0 = ctx->bin_y0;
     a.bh = ctx->bin_h;
     a.tables = ctx->table_desc.as<TableDesc>();
+    a.ring_tab = ctx->ring_tab.as<double2>();
+    a.ring_tab_off = ctx->ring_tab_off.as<long long>();
+    a.ring_ok = ctx->ring_ok.as<double>();
+    a.ring_ok_off = ctx->ring_ok_off.as<int>();
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
     a.viol = ctx->violations.as<unsigned long long>();
+}
 
+// ML_NEARFIELD_EXACT=1 selects the operation-by-operation restatement above; the default is
+// the fast kernel (nearfield_fast.hip), which keeps only the phase-critical arithmetic exact.
+static bool use_exact_kernel() {
+    static const bool v = [] {
+        const char *e = getenv("ML_NEARFIELD_EXACT");
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
+
+int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) {
+    NfArgs a;
+    fill_nf_args(ctx, p, nx, ny, a);
     const dim3 grid((ny + 255) / 256, nx);
-    {
+    if (use_exact_kernel()) {
         ProfScope scope(ctx, ML_K_NEARFIELD);
-        hipLaunchKernelGGL(nearfield_kernel, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL(nearfield_exact_kernel, grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        ProfScope scope(ctx, ML_K_NEARFIELD);
+        ML_TRY(nearfield_fast_launch(ctx, a, grid));
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->partial_power.as<double>(), (int)(grid.x * grid.y),

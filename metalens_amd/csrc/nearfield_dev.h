@@ -1,0 +1,151 @@
+// Device-side pieces shared by the two near-field kernels (exact / fast).
+#pragma once
+#include "common.h"
+
+namespace ml {
+
+struct c2 {
+    double r, i;
+};
+__device__ __forceinline__ c2 operator+(c2 a, c2 b) { return {a.r + b.r, a.i + b.i}; }
+__device__ __forceinline__ c2 cmul(c2 a, c2 b) {
+    return {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r};
+}
+__device__ __forceinline__ c2 scale(c2 a, double s) { return {a.r * s, a.i * s}; }
+
+struct NfArgs {
+    ml_nearfield_params p;
+    const double *x_pts, *y_pts;
+    int nx, ny;
+    // rings
+    int n_rings;
+    const double *B, *rc, *period, *dphi, *lateral, *ring_t2;
+    const int *gc, *ring_i2, *lut, *rot_center, *rot_half;
+    const double2 *rot_table;
+    int lut_buckets;
+    double lut_inv_h;
+    // centre cells
+    int n_cells;
+    const double *cx, *cy;
+    const int *cwhich, *cindex, *bin_start;
+    int bins_x, bins_y;
+    double bx0, by0, bh;
+    // tables
+    const TableDesc *tables;
+    // per-ring tables for the fast kernel: period axis already interpolated, complex
+    // [order][n0][n1][4] per ring at ring_tab + ring_tab_off[ring]; per-ring order
+    // wavenumbers (ox*2*pi/period, oy*2*pi/lateral) at ring_ok + ring_ok_off[ring]
+    const double2 *ring_tab;
+    const long long *ring_tab_off;
+    const double *ring_ok;
+    const int *ring_ok_off;
+    // outputs
+    double *fields;
+    double *partial_power;
+    unsigned long long *viol;
+};
+
+// monotone map double -> uint64 (so that integer max == floating max)
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// Record an out-of-table sample.  Rare path: only violators touch memory.  "min" checks
+// store the complemented key so that every slot is a plain atomicMax starting from 0.
+__device__ __forceinline__ void report(unsigned long long *viol, int slot, int order, int check,
+                                    double v) {
+    unsigned long long k = ordered_key(v);
+    if ((check & 1) == 0) k = ~k;
+    atomicMax(&viol[((size_t)slot * MAX_ORDERS + order) * 6 + check], k);
+}
+
+__device__ __forceinline__ void check_bounds(const NfArgs &a, const TableDesc &T, int slot,
+                                             int order, double u, double v, double g,
+                                             bool with_period) {
+    if (u < T.bounds[0]) report(a.viol, slot, order, 0, u);
+    if (u > T.bounds[1]) report(a.viol, slot, order, 1, u);
+    if (v < T.bounds[2]) report(a.viol, slot, order, 2, v);
+    if (v > T.bounds[3]) report(a.viol, slot, order, 3, v);
+    if (with_period) {
+        if (g < T.bounds[4]) report(a.viol, slot, order, 4, g);
+        if (g > T.bounds[5]) report(a.viol, slot, order, 5, g);
+    }
+}
+
+// exact nearest centre cell (nearfield.py:363-364) through a uniform grid of bins
+__device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y) {
+    int bx = (int)floor((x - a.bx0) / a.bh);
+    int by = (int)floor((y - a.by0) / a.bh);
+    bx = min(max(bx, 0), a.bins_x - 1);
+    by = min(max(by, 0), a.bins_y - 1);
+    double best = INFINITY;
+    int best_slot = -1, best_idx = 0x7fffffff;
+    const int kmax = max(a.bins_x, a.bins_y);
+    for (int k = 0; k <= kmax; ++k) {
+        const int x_lo = bx - k, x_hi = bx + k, y_lo = by - k, y_hi = by + k;
+        for (int gx = max(x_lo, 0); gx <= min(x_hi, a.bins_x - 1); ++gx) {
+            const bool edge_col = (gx == x_lo) || (gx == x_hi);
+            const int step = edge_col ? 1 : max(2 * k, 1);
+            for (int gy = y_lo; gy <= y_hi; gy += step) {
+                if (gy < 0 || gy >= a.bins_y) continue;
+                const int b = gx * a.bins_y + gy;
+                for (int s = a.bin_start[b]; s < a.bin_start[b + 1]; ++s) {
+                    const double ex = x - a.cx[s], ey = y - a.cy[s];
+                    const double d2 = ex * ex + ey * ey;
+                    const int idx = a.cindex[s];
+                    if (d2 < best || (d2 == best && idx < best_idx)) {
+                        best = d2;
+                        best_slot = s;
+                        best_idx = idx;
+                    }
+                }
+            }
+        }
+        // every cell not yet visited is at least k*bh away
+        const double reach = k * a.bh;
+        if (best_slot >= 0 && best <= reach * reach) break;
+    }
+    return best_slot;
+}
+
+
+// which ring: number of ring boundaries strictly below r, i.e.
+// searchsorted(boundaries, r, 'left') (nearfield.py:125-128), through the uniform-in-r LUT
+__device__ __forceinline__ int boundaries_below(const NfArgs &a, double r) {
+    if (r > a.B[a.n_rings]) return a.n_rings + 1;
+    int bucket = (int)(r * a.lut_inv_h);
+    bucket = min(max(bucket, 0), a.lut_buckets - 1);
+    int idx = a.lut[bucket];
+    while (idx <= a.n_rings && a.B[idx] < r) ++idx;
+    while (idx > 0 && a.B[idx - 1] >= r) --idx;
+    return idx;
+}
+
+// incident power: wave reduction, then one partial per block (fixed order)
+__device__ __forceinline__ void block_power(const NfArgs &a, double power_here) {
+    for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
+    __shared__ double wave_sum[4];
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = power_here;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
+            (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+__device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 Ex, c2 Ey, c2 Hx,
+                                             c2 Hy) {
+    // 16 B per lane per plane, coalesced along y
+    const size_t plane = (size_t)a.nx * a.ny;
+    const size_t at = (size_t)i * a.ny + j;
+    double2 *F = reinterpret_cast<double2 *>(a.fields);
+    F[at] = make_double2(Ex.r, Ex.i);
+    F[plane + at] = make_double2(Ey.r, Ey.i);
+    F[2 * plane + at] = make_double2(Hx.r, Hx.i);
+    F[3 * plane + at] = make_double2(Hy.r, Hy.i);
+}
+
+void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a);
+int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid);
+
+}  // namespace ml

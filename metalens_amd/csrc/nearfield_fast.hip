@@ -1,0 +1,253 @@
+// Near-field synthesis, fast kernel (the default).
+//
+// Same result as nearfield.hip's operation-by-operation kernel to ~1e-15, but only the
+// arithmetic that feeds LARGE phases is kept in the reference's exact order:
+//   * ring / sector / nearest-cell decisions (r, atan2, round)            -> exact
+//   * local coordinates xp = x cos + y sin - r_center, yp                 -> exact
+//     (a 1e-19 m rounding difference here is ~1e-12 rad of phase)
+//   * propagation distance sqrt(gx^2 + gy^2 + z^2) and k*distance         -> exact
+// Everything else (direction cosines, incident amplitudes, table interpolation, the 2x2
+// polarisation algebra, small-argument sin/cos) only has to be accurate to a few ulp, which
+// frees the kernel to
+//   * read tables that already have the period axis interpolated per ring (4 nodes, not 8);
+//     the centre tables need no third-axis interpolation at all (cell index = exact node);
+//   * locate the (ux, uy) table cell once per sample instead of once per order and use
+//     per-ring pre-divided order wavenumbers;
+//   * combine both incident polarisations BEFORE the phase multiply:
+//       U_fy = sum_p Hw_p a_fy,p ;  U_fx = sum_p Hw_p a_fx,p
+//       Hx += U_fy ph ; Hy += U_fx ph ;
+//       Ex += Z0 g (kx ky U_fy + (ky^2+kz^2) U_fx) ph ; Ey += Z0 g (-(kx^2+kz^2) U_fy - kx ky U_fx) ph
+//     with g = 1/(k_glass kz n_glass)  (nearfield.py:313-327 rearranged);
+//   * use one reciprocal per sample and a branch-free Cody-Waite sin/cos.
+#include "nearfield_dev.h"
+
+namespace ml {
+
+// sin and cos of x for |x| < ~1e9: three-constant Cody-Waite reduction with FMA (each step
+// rounds once, relative to the already small remainder), fdlibm kernel polynomials.
+__device__ __forceinline__ void sincos_cw(double x, double &s, double &c) {
+    const double k = rint(x * 0.63661977236758138243);          // 2/pi
+    double r = fma(-k, 1.57079632679489655800e+00, x);          // pi/2 hi
+    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid
+    r = fma(-k, -1.49738490485916983291e-33, r);                // pi/2 lo
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
+// Accurate reciprocal: hardware estimate + two Newton steps (~1 ulp).
+__device__ __forceinline__ double recip(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return y;
+}
+
+// cell of a short ascending axis: largest i with axis[i] <= x, clamped to [0, n-2]
+__device__ __forceinline__ void locate_fast(const double *axis, int n, double x, int &i,
+                                            double &t) {
+    i = 0;
+    for (int a = 1; a < n - 1; ++a) i = (axis[a] <= x) ? a : i;
+    const double lo = axis[i], hi = axis[i + 1];
+    t = (x - lo) * recip(hi - lo);
+}
+
+struct Acc {
+    c2 Ex, Ey, Hx, Hy;
+};
+
+// one diffraction order: bilinear table read at 4 nodes, both polarisations, phase multiply
+__device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int stride0,
+                                           int stride1, double t0, double t1, double Hw_x,
+                                           double Hw_y, double kx, double ky, double kz2,
+                                           double k_glass, double inv_n, double Z0, double arg) {
+    const double w00 = (1 - t0) * (1 - t1), w01 = (1 - t0) * t1, w10 = t0 * (1 - t1), w11 = t0 * t1;
+    // U_fy = sum_p Hw_p a_fy,p ; U_fx = sum_p Hw_p a_fx,p with a = sum_nodes w v
+    double ufy_r = 0, ufy_i = 0, ufx_r = 0, ufx_i = 0;
+    const double2 *nodes[4] = {node00, node00 + stride1, node00 + stride0,
+                               node00 + stride0 + stride1};
+    const double w[4] = {w00, w01, w10, w11};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double2 xfy = nodes[c][0], xfx = nodes[c][1], yfy = nodes[c][2], yfx = nodes[c][3];
+        const double wx = w[c] * Hw_x, wy = w[c] * Hw_y;
+        ufy_r = fma(wx, xfy.x, fma(wy, yfy.x, ufy_r));
+        ufy_i = fma(wx, xfy.y, fma(wy, yfy.y, ufy_i));
+        ufx_r = fma(wx, xfx.x, fma(wy, yfx.x, ufx_r));
+        ufx_i = fma(wx, xfx.y, fma(wy, yfx.y, ufx_i));
+    }
+    double sn, cs;
+    sincos_cw(arg, sn, cs);
+    // V = U * exp(i arg)
+    const double vy_r = fma(ufy_r, cs, -ufy_i * sn), vy_i = fma(ufy_r, sn, ufy_i * cs);
+    const double vx_r = fma(ufx_r, cs, -ufx_i * sn), vx_i = fma(ufx_r, sn, ufx_i * cs);
+    acc.Hx.r += vy_r;
+    acc.Hx.i += vy_i;
+    acc.Hy.r += vx_r;
+    acc.Hy.i += vx_i;
+    const double kz = sqrt(kz2);
+    const double g = Z0 * inv_n * recip(k_glass * kz);
+    const double cxy = kx * ky * g, cxx = fma(ky, ky, kz2) * g, cyy = -fma(kx, kx, kz2) * g;
+    acc.Ex.r += fma(cxy, vy_r, cxx * vx_r);
+    acc.Ex.i += fma(cxy, vy_i, cxx * vx_i);
+    acc.Ey.r += fma(cyy, vy_r, -cxy * vx_r);
+    acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
+}
+
+__global__ __launch_bounds__(256) void nearfield_fast_kernel(const NfArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;   // y index (fastest in memory)
+    const int i = blockIdx.y;                        // x index
+    const ml_nearfield_params &p = a.p;
+    double power_here = 0.0;
+    Acc acc = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if (j < a.ny) {
+        const double x = a.x_pts[i], y = a.y_pts[j];
+        const double r = sqrt(x * x + y * y);
+        const int idx = boundaries_below(a, r);
+        if (idx <= a.n_rings) {
+            // ---- incidence direction and incident field (amplitude-type arithmetic)
+            double ux = 0.0, uy = 0.0, uz = 1.0;
+            double Hx_i, Hy_i, Ex_i, Ey_i;
+            if (p.plane_wave) {
+                Ex_i = p.pol[0] * p.dipole_moment;
+                Ey_i = p.pol[1] * p.dipole_moment;
+                Hx_i = -p.pol[1] * p.dipole_moment / p.Z0;
+                Hy_i = p.pol[0] * p.dipole_moment / p.Z0;
+            } else {
+                const double dx = x - p.source_x, dy = y - p.source_y;
+                const double inv = recip(sqrt(dx * dx + dy * dy + p.dz2));
+                ux = dx * inv;
+                uy = dy * inv;
+                uz = p.dz * inv;
+                const double amp = p.H_coef * sqrt(uz) * inv;
+                Hx_i = (uy * p.pol[2] - uz * p.pol[1]) * amp;
+                Hy_i = (uz * p.pol[0] - ux * p.pol[2]) * amp;
+                const double Hz_i = (ux * p.pol[1] - uy * p.pol[0]) * amp;
+                Ex_i = (Hy_i * uz - Hz_i * uy) * p.Z0;
+                Ey_i = (Hz_i * ux - Hx_i * uz) * p.Z0;
+            }
+            power_here = Ex_i * Hy_i - Ey_i * Hx_i;
+            const double inv_n = recip(p.n_glass);
+
+            if (idx >= 1) {
+                // ================= periphery =================
+                const int ring = idx - 1;
+                const int slot = a.gc[ring];
+                const TableDesc &T = a.tables[slot];
+                const double dphi = a.dphi[ring], rcen = a.rc[ring];
+                // sector decision: exact (nearfield.py:169)
+                int sector = (int)rint(atan2(y, x) / dphi);
+                const int half = a.rot_half[ring];
+                sector = min(max(sector, -half), half);
+                const double2 cs = a.rot_table[a.rot_center[ring] + sector];
+                const double cosr = cs.x, sinr = cs.y;
+                // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
+                const double xp = x * cosr + y * sinr - rcen;
+                const double yp = -x * sinr + y * cosr;
+                const double uxp = fma(ux, cosr, uy * sinr), uyp = fma(uy, cosr, -ux * sinr);
+                const double Hw_y = fma(Hx_i, cosr, Hy_i * sinr);    // H along x' <-> y table
+                const double Hw_x = fma(Hy_i, cosr, -Hx_i * sinr);   // H along y' <-> x table
+                int i0, i1;
+                double t0, t1;
+                locate_fast(T.axis0, T.n0, uxp, i0, t0);
+                locate_fast(T.axis1, T.n1, uyp, i1, t1);
+                const double *ok = a.ring_ok + a.ring_ok_off[ring];
+                const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
+                const int stride1 = 4, stride0 = T.n1 * 4, stride_o = T.n0 * T.n1 * 4;
+                const double period = a.period[ring];
+                Acc pr = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+                for (int o = 0; o < T.n_orders; ++o) {
+                    const double kxp = fma(p.kvac, uxp, ok[2 * o]);
+                    const double kyp = fma(p.kvac, uyp, ok[2 * o + 1]);
+                    const double kt2 = fma(kxp, kxp, kyp * kyp);
+                    if (kt2 <= p.kvac2) {
+                        check_bounds(a, T, slot, o, uxp, uyp, period, true);
+                        order_term(pr, tab + o * stride_o + i0 * stride0 + i1 * stride1, stride0,
+                                   stride1, t0, t1, Hw_x, Hw_y, kxp, kyp, p.k_glass2 - kt2,
+                                   p.k_glass, inv_n, p.Z0, kxp * xp + kyp * yp);
+                    }
+                }
+                // phase-critical: propagation from the grating centre (nearfield.py:337-341)
+                if (!p.plane_wave) {
+                    const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
+                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                    double sn, cn;
+                    sincos_cw(p.kvac * air, sn, cn);
+                    const c2 e = {cn, sn};
+                    pr.Ex = cmul(pr.Ex, e);
+                    pr.Ey = cmul(pr.Ey, e);
+                    pr.Hx = cmul(pr.Hx, e);
+                    pr.Hy = cmul(pr.Hy, e);
+                }
+                // back to the lab frame (nearfield.py:351-354)
+                acc.Ex = {fma(pr.Ex.r, cosr, -pr.Ey.r * sinr), fma(pr.Ex.i, cosr, -pr.Ey.i * sinr)};
+                acc.Ey = {fma(pr.Ex.r, sinr, pr.Ey.r * cosr), fma(pr.Ex.i, sinr, pr.Ey.i * cosr)};
+                acc.Hx = {fma(pr.Hx.r, cosr, -pr.Hy.r * sinr), fma(pr.Hx.i, cosr, -pr.Hy.i * sinr)};
+                acc.Hy = {fma(pr.Hx.r, sinr, pr.Hy.r * cosr), fma(pr.Hx.i, sinr, pr.Hy.i * cosr)};
+            } else if (a.n_cells > 0) {
+                // ================= centre: nearest hexagonal cell =================
+                const TableDesc &T = a.tables[MAX_SLOTS];
+                const int s = nearest_cell(a, x, y);
+                const double ccx = a.cx[s], ccy = a.cy[s];
+                const int which = min(max(a.cwhich[s], 0), T.n2 - 1);
+                int i0, i1;
+                double t0, t1;
+                locate_fast(T.axis0, T.n0, ux, i0, t0);
+                locate_fast(T.axis1, T.n1, uy, i1, t1);
+                const double2 *tab = reinterpret_cast<const double2 *>(T.values);
+                const int stride1 = T.n2 * 4, stride0 = T.n1 * T.n2 * 4;
+                const size_t stride_o = (size_t)T.n0 * T.n1 * T.n2 * 4;
+                // phase-critical: offset from the cell centre (nearfield.py:408-409)
+                const double ox_ = x - ccx, oy_ = y - ccy;
+                for (int o = 0; o < T.n_orders; ++o) {
+                    const double kx = fma(p.kvac, ux, T.center_kx[o]);
+                    const double ky = fma(p.kvac, uy, T.center_ky[o]);
+                    const double kt2 = fma(kx, kx, ky * ky);
+                    if (kt2 <= p.kvac2) {
+                        check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                        // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+                        order_term(acc, tab + o * stride_o + (size_t)i0 * stride0 + i1 * stride1 +
+                                            which * 4,
+                                   stride0, stride1, t0, t1, Hy_i, Hx_i, kx, ky, p.k_glass2 - kt2,
+                                   p.k_glass, inv_n, p.Z0, kx * ox_ + ky * oy_);
+                    }
+                }
+                if (!p.plane_wave) {
+                    const double gx = ccx - p.source_x, gy = ccy - p.source_y;
+                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                    double sn, cn;
+                    sincos_cw(p.kvac * air, sn, cn);
+                    const c2 e = {cn, sn};
+                    acc.Ex = cmul(acc.Ex, e);
+                    acc.Ey = cmul(acc.Ey, e);
+                    acc.Hx = cmul(acc.Hx, e);
+                    acc.Hy = cmul(acc.Hy, e);
+                }
+            }
+        }
+        store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
+    }
+    block_power(a, power_here);
+}
+
+int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid) {
+    hipLaunchKernelGGL(nearfield_fast_kernel, grid, dim3(256), 0, ctx->stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+}  // namespace ml

@@ -19,6 +19,8 @@
 //   current one is multiplied; several workgroups per CU cover the barrier bubbles
 // The fp64 MFMA issues once per 64 cycles per SIMD (2048 flop), so LDS and L2 traffic are far
 // from limiting: per 16 MFMAs a wave issues 10 ds_read_b64.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ml {
@@ -190,6 +192,20 @@ static int launch(hipStream_t stream, ZArgs &a, int batch) {
     return ML_OK;
 }
 
+// Tile selection.  Small problems (stage 2 of a 256^2 far field is 16 tiles of 64x64 per field)
+// take 32x32 tiles so that the grid still covers the 256 CUs; ML_ZGEMM_TILE=<id> forces a
+// configuration (tuning / tests).
+static int pick_tile(int M, int N, int batch) {
+    static const int forced = [] {
+        const char *e = getenv("ML_ZGEMM_TILE");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0) return forced;
+    const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    if (tiles64 < 2 * 256) return 1;
+    return 0;
+}
+
 int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const double *A,
           int64_t lda, int64_t strideA, const double *B, int64_t ldb, int64_t strideB, double *C,
           int64_t ldc, int64_t strideC, int batch, int accumulate) {
@@ -210,7 +226,15 @@ int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const do
     a.K = K;
     for (int k = 0; k < 4; ++k) a.alpha[k] = alpha[k < batch ? k : 0];
     a.accumulate = accumulate;
-    return launch<64, 64, 2, 2>(stream, a, batch);
+    switch (pick_tile(M, N, batch)) {
+        case 1: return launch<32, 32, 2, 2>(stream, a, batch);
+        case 2: return launch<128, 64, 2, 2>(stream, a, batch);
+        case 3: return launch<64, 128, 2, 2>(stream, a, batch);
+        case 4: return launch<128, 128, 2, 2>(stream, a, batch);
+        case 5: return launch<128, 64, 4, 2>(stream, a, batch);
+        case 6: return launch<128, 128, 4, 2>(stream, a, batch);
+        default: return launch<64, 64, 2, 2>(stream, a, batch);
+    }
 }
 
 // Pair-list stage 2: out[f][d] (+)= alpha[f] * sum_j TX[j0 + j][d] * G[f][j][d]
