@@ -11,7 +11,10 @@
 // Tiling (wave64, one MFMA = a 16x16 real tile over 4 k):
 //   workgroup = WM x WN waves, tile BM x BN complex outputs, K step BK = 16
 //   each wave owns TM x TN blocks of 16x16; per block two real accumulators (re, im)
-//   complex product = 4 real MFMAs:  Cr += Ar*Br + Ai*(-Bi),  Ci += Ar*Bi + Ai*Br
+//   complex product: the default "3M" form uses 3 real MFMAs per block and k-step,
+//     T1 += Ar*Br, T2 += Ai*Bi, T3 += (Ar+Ai)*(Br+Bi);  Cr = T1 - T2, Ci = T3 - T1 - T2
+//   (25 % fewer MFMAs than the 4-product form, which is kept as template variant M3 = false:
+//     Cr += Ar*Br + Ai*(-Bi),  Ci += Ar*Bi + Ai*Br)
 //   LDS holds split planes Ar, Ai [BM][BK+2] and Br, Bi, -Bi [BK][BN+16]; the paddings make
 //   every ds_read_b64 of an MFMA fragment bank-conflict free (rows step 18 doubles, k-rows
 //   step BN+16 doubles == 16 mod 32)
@@ -39,7 +42,7 @@ struct ZArgs {
 
 constexpr int BK = 16;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool M3>
 __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -48,7 +51,9 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
     static_assert(BM * BK % NT == 0 && BK * BN % NT == 0, "tile/threads mismatch");
     static_assert(TM >= 1 && TN >= 1, "wave tile too small");
 
-    __shared__ double sAr[BM * LDAS], sAi[BM * LDAS];
+    // third planes: 4M keeps -Bi (so that Cr accumulates Ar*Br + Ai*(-Bi)); 3M keeps the sums
+    // As = Ar + Ai and Bs = Br + Bi
+    __shared__ double sAr[BM * LDAS], sAi[BM * LDAS], sAs[M3 ? BM * LDAS : 1];
     __shared__ double sBr[BK * LDBS], sBi[BK * LDBS], sBn[BK * LDBS];
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
             const int at = (e / BK) * LDAS + e % BK;
             sAr[at] = ra[p].x;
             sAi[at] = ra[p].y;
+            if (M3) sAs[at] = ra[p].x + ra[p].y;
         }
 #pragma unroll
         for (int p = 0; p < B_PER; ++p) {
@@ -97,17 +103,19 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
             const int at = (e / BN) * LDBS + e % BN;
             sBr[at] = rb[p].x;
             sBi[at] = rb[p].y;
-            sBn[at] = -rb[p].y;
+            sBn[at] = M3 ? rb[p].x + rb[p].y : -rb[p].y;
         }
     };
 
-    v4d cr[TM][TN], ci[TM][TN];
+    // 4M: cr, ci.  3M: cr = T1 = Ar*Br, ci = T2 = Ai*Bi, ct = T3 = (Ar+Ai)*(Br+Bi)
+    v4d cr[TM][TN], ci[TM][TN], ct[M3 ? TM : 1][M3 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             cr[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
             ci[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (M3) ct[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
     load_tile(0);
@@ -118,12 +126,13 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
         if (k0 + BK < a.K) load_tile(k0 + BK);
 #pragma unroll
         for (int s = 0; s < BK / 4; ++s) {
-            double ar[TM], ai[TM], br[TN], bi[TN], bn[TN];
+            double ar[TM], ai[TM], as[M3 ? TM : 1], br[TN], bi[TN], bn[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int at = ((wm * TM + i) * 16 + frow) * LDAS + s * 4 + fk;
                 ar[i] = sAr[at];
                 ai[i] = sAi[at];
+                if (M3) as[i] = sAs[at];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -138,21 +147,34 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     cr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], br[j], cr[i][j], 0, 0, 0);
+            if (M3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bi[j], ci[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], bi[j], ci[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    cr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], bn[j], cr[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        ct[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[i], bn[j], ct[i][j], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], br[j], ci[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[i], bi[j], ci[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        cr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], bn[j], cr[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        ci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[i], br[j], ci[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -167,7 +189,14 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + (wm * TM + i) * 16 + (lane >> 4) + 4 * r;
                 if (row < a.M && col < a.N) {
-                    double2 v = make_double2(alpha * cr[i][j][r], alpha * ci[i][j][r]);
+                    double re = cr[i][j][r], im = ci[i][j][r];
+                    if (M3) {
+                        // Cr = T1 - T2, Ci = T3 - T1 - T2
+                        const double t1 = re, t2 = im;
+                        re = t1 - t2;
+                        im = (ct[i][j][r] - t1) - t2;
+                    }
+                    double2 v = make_double2(alpha * re, alpha * im);
                     double2 *dst = C + (int64_t)row * a.ldc + col;
                     if (a.accumulate) {
                         const double2 old = *dst;
@@ -180,13 +209,13 @@ __global__ __launch_bounds__(WM *WN * 64) void zgemm_kernel(const ZArgs a) {
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool M3 = false>
 static int launch(hipStream_t stream, ZArgs &a, int batch) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zgemm_kernel<BM, BN, WM, WN>), dim3(a.chunk * 8, batch),
+    hipLaunchKernelGGL((zgemm_kernel<BM, BN, WM, WN, M3>), dim3(a.chunk * 8, batch),
                        dim3(WM * WN * 64), 0, stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
@@ -201,9 +230,13 @@ static int pick_tile(int M, int N, int batch) {
         return e ? atoi(e) : -1;
     }();
     if (forced >= 0) return forced;
-    const long tiles64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
-    if (tiles64 < 2 * 256) return 1;
-    return 0;
+    // measured on MI355X (tools/zgemm_sweep.py): the 3M variants win everywhere; 128x64 tiles
+    // with 8 waves are best as soon as they give one workgroup per CU
+    const long t128 = (long)((M + 127) / 128) * ((N + 63) / 64) * batch;
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64) * batch;
+    if (t128 >= 256) return 15;
+    if (t64 >= 256) return 10;
+    return 11;
 }
 
 int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const double *A,
@@ -233,6 +266,11 @@ int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const do
         case 4: return launch<128, 128, 2, 2>(stream, a, batch);
         case 5: return launch<128, 64, 4, 2>(stream, a, batch);
         case 6: return launch<128, 128, 4, 2>(stream, a, batch);
+        case 10: return launch<64, 64, 2, 2, true>(stream, a, batch);
+        case 11: return launch<32, 32, 2, 2, true>(stream, a, batch);
+        case 15: return launch<128, 64, 4, 2, true>(stream, a, batch);
+        case 16: return launch<128, 128, 4, 2, true>(stream, a, batch);
+        case 12: return launch<128, 64, 2, 2, true>(stream, a, batch);
         default: return launch<64, 64, 2, 2>(stream, a, batch);
     }
 }

@@ -22,6 +22,11 @@ du = (wl / n) / (pitch * N)
 u = (np.arange(M) - M // 2) * du
 t = ma.FarfieldTransform(N, N, pitch, pitch, wl, n, u, u, ctx=ctx)
 t.transform()
+from oracle import farfield_oracle
+sel = np.arange(0, M, max(1, M // 8))
+ref = farfield_oracle.radiation_vectors(*F, np.arange(N) * pitch, np.arange(N) * pitch, wl, n, u[sel], u[sel])
+got = t.radiation_vectors()
+err = max(np.abs(got[k][np.ix_(sel, sel)] - r).max() / np.abs(r).max() for k, r in zip(('Nx', 'Ny', 'Lx', 'Ly'), ref))
 ctx.profile(True)
 ctx.profile_reset()
 for _ in range(reps):
@@ -31,5 +36,5 @@ s1 = p['zgemm_stage1']['total_ms'] / reps
 s2 = p['zgemm_stage2']['total_ms'] / reps
 f1 = 8.0 * 4 * N * N * M
 f2 = 8.0 * 4 * M * N * M
-print('tile=%s N=%d M=%d stage1 %.3f ms %.1f TF | stage2 %.3f ms %.1f TF' % (
-    os.environ.get('ML_ZGEMM_TILE', 'auto'), N, M, s1, f1 / s1 / 1e9, s2, f2 / s2 / 1e9))
+print('tile=%s N=%d M=%d stage1 %.3f ms %.1f TF | stage2 %.3f ms %.1f TF | rel err %.1e' % (
+    os.environ.get('ML_ZGEMM_TILE', 'auto'), N, M, s1, f1 / s1 / 1e9, s2, f2 / s2 / 1e9, err))
