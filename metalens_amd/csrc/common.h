@@ -125,6 +125,10 @@ struct FarfieldPlan {
     DevBuf power;        // double  [mx][my]
     DevBuf amplitudes;   // complex [2][mx][my]  (a_theta, a_phi)
     bool have_vectors = false;
+    // folded (even/odd) stage 1, see zfold.hip; used when uy is centre-symmetric
+    bool fold = false, fold_has_E = false;
+    int fold_T = 0, fold_S = 0;
+    DevBuf fold_cm, fold_sm, fold_E, fold_D, fold_v;
 };
 
 }  // namespace ml
@@ -200,6 +204,10 @@ int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const do
 // out[f][d] (+)= alpha[f] * sum_j TX[d][j0 + j] * G[f][j][d]   (pair-list stage 2)
 int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *alpha4,
             const double *TX, int64_t ldtx, int j0, const double *G, double *out, int accumulate);
+// zfold.hip: stage 1 with both mirror symmetries folded (real cos/sin kernel)
+int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
+                 const double *Sm, int T, int S, const double *E, const double *D, double *C,
+                 int64_t ldc, int my);
 // comm.hip
 void comm_release(ml_ctx *ctx);
 

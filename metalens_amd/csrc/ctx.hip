@@ -226,7 +226,9 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
-                      &ctx->plan.amplitudes, &ctx->comm_scratch, &ctx->lattice_in};
+                      &ctx->plan.amplitudes, &ctx->comm_scratch, &ctx->lattice_in,
+                      &ctx->plan.fold_cm, &ctx->plan.fold_sm, &ctx->plan.fold_E, &ctx->plan.fold_D,
+                      &ctx->plan.fold_v};
     for (DevBuf *b : bufs) b->release();
     for (auto &pd : ctx->prof.pending) {
         (void)hipEventDestroy(pd.a);

@@ -8,6 +8,7 @@
 //   * ml_farfield_lattice_power   the same projection on the caller's FFT'd fields
 //                           (drop-in for farfield_from_nearfield_helper)
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -40,6 +41,40 @@ __global__ __launch_bounds__(256) void twiddle_kernel(double2 *out, int rows, in
     double sn, cs;
     sincos(ang, &sn, &cs);
     out[(size_t)r * cols + c] = make_double2(cs, -sn);
+}
+
+// General phase table: out[r][c] = exp(-2 pi i frac(s * coord * u)) with
+// coord = coord0 + coord_step * (sample index), u = u_hi[dir] + u_lo[dir] (u_lo may be null),
+// (sample, dir) = (r, c) if sample_major else (c, r).  real_planes != 0 writes cos and +sin
+// into two REAL planes (outc, outs) instead of one complex array.
+__global__ __launch_bounds__(256) void phase_table_kernel(double2 *out, double *outc, double *outs,
+                                                          int rows, int cols, int sample_major,
+                                                          double coord0, double coord_step,
+                                                          double s_hi, double s_lo,
+                                                          const double *u_hi, const double *u_lo) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols) return;
+    const int sample = sample_major ? r : c;
+    const int dir = sample_major ? c : r;
+    const double kk = coord0 + coord_step * (double)sample;   // exact: (half-)integers
+    const double uh = u_hi[dir], ul = u_lo ? u_lo[dir] : 0.0;
+    const double p_hi = kk * s_hi;
+    const double p_lo = fma(kk, s_hi, -p_hi) + kk * s_lo;
+    const double q_hi = p_hi * uh;
+    const double q_lo = fma(p_hi, uh, -q_hi) + (p_lo * uh + p_hi * ul);
+    const double f = (q_hi - rint(q_hi)) + q_lo;
+    const double a_hi = f * ML_TWO_PI_HI;
+    const double ang = a_hi + (fma(f, ML_TWO_PI_HI, -a_hi) + f * ML_TWO_PI_LO);
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const size_t at = (size_t)r * cols + c;
+    if (outc) {
+        outc[at] = cs;
+        outs[at] = sn;
+    } else {
+        out[at] = make_double2(cs, -sn);
+    }
 }
 
 struct ProjArgs {
@@ -119,6 +154,72 @@ static int launch_twiddle(ml_ctx *ctx, double *out, int rows, int cols, int samp
     return ML_OK;
 }
 
+// Decide whether stage 1 can run folded (zfold.hip) and build its tables.  Needs a tensor
+// grid whose uy are centre-symmetric to within 1e-13 rad of phase at the aperture edge.
+static int plan_fold(ml_ctx *ctx, const double *uy) {
+    FarfieldPlan &pl = ctx->plan;
+    pl.fold = false;
+    static const bool disabled = [] {
+        const char *e = getenv("ML_NO_FOLD");
+        return e && atoi(e) != 0;
+    }();
+    if (disabled || pl.pair_list || pl.my < 2 || pl.ny < 2) return ML_OK;
+    const int ny = pl.ny, my = pl.my;
+    const int T = (ny + 1) / 2, S = (my + 1) / 2;
+    const long double kappa = (long double)pl.n_glass / (long double)pl.wavelength;
+    const long double p_max = 0.5L * (ny - 1) * fabsl((long double)pl.dyp);
+    const long double uc = 0.5L * ((long double)uy[0] + (long double)uy[my - 1]);
+    std::vector<double> v(2 * (size_t)S);   // hi[S] then lo[S]
+    long double worst = 0;
+    for (int s = 0; s < S; ++s) {
+        const long double up = uy[my - 1 - s], um = uy[s];
+        worst = fmaxl(worst, fabsl(0.5L * (up + um) - uc));
+        const long double vs = 0.5L * (up - um);
+        v[s] = (double)vs;
+        v[S + s] = (double)(vs - (long double)v[s]);
+    }
+    if (2 * M_PIl * kappa * p_max * worst > 1e-13L) return ML_OK;   // not symmetric enough
+    ML_TRY(pl.fold_v.reserve(v.size() * sizeof(double)));
+    ML_HIP(hipMemcpyAsync(pl.fold_v.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+    ML_TRY(pl.fold_cm.reserve((size_t)T * S * sizeof(double)));
+    ML_TRY(pl.fold_sm.reserve((size_t)T * S * sizeof(double)));
+    ML_TRY(pl.fold_E.reserve((size_t)ny * 2 * sizeof(double) + 16));
+    ML_TRY(pl.fold_D.reserve((size_t)my * 2 * sizeof(double)));
+    const long double s = kappa * (long double)pl.dyp;   // turns per (sample index x u)
+    const double s_hi = (double)s, s_lo = (double)(s - (long double)s_hi);
+    const double half = 0.5 * (ny - 1);
+    ProfScope scope(ctx, ML_K_TWIDDLE);
+    // cos / sin of kappa p_t v_s, p_t = (half - t) dy
+    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, T), dim3(256), 0, ctx->stream,
+                       (double2 *)nullptr, pl.fold_cm.as<double>(), pl.fold_sm.as<double>(), T, S,
+                       1, half, -1.0, s_hi, s_lo, pl.fold_v.as<double>(),
+                       pl.fold_v.as<double>() + S);
+    // input modulation E_k = exp(-i kappa p_k u_c), p_k = (k - half) dy; skipped when u_c == 0
+    const double uc_hi = (double)uc, uc_lo = (double)(uc - (long double)uc_hi);
+    pl.fold_has_E = (uc != 0);
+    if (pl.fold_has_E) {
+        // the single direction u_c travels behind the table in fold_E's tail
+        double ucs[2] = {uc_hi, uc_lo};
+        double *tail = pl.fold_E.as<double>() + (size_t)ny * 2;
+        ML_HIP(hipMemcpyAsync(tail, ucs, sizeof ucs, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(phase_table_kernel, dim3((ny + 255) / 256, 1), dim3(256), 0, ctx->stream,
+                           pl.fold_E.as<double2>(), (double *)nullptr, (double *)nullptr, 1, ny, 0,
+                           -half, 1.0, s_hi, s_lo, tail, tail + 1);
+    }
+    // output diagonal D_j = exp(-i kappa delta u_j), delta = (half - ceil(ny/2)) dy
+    const double delta = half - (double)(ny - ny / 2);
+    hipLaunchKernelGGL(phase_table_kernel, dim3((my + 255) / 256, 1), dim3(256), 0, ctx->stream,
+                       pl.fold_D.as<double2>(), (double *)nullptr, (double *)nullptr, 1, my, 1,
+                       delta, 0.0, s_hi, s_lo, pl.uy.as<double>(), (const double *)nullptr);
+    ML_HIP(hipGetLastError());
+    ML_HIP(hipStreamSynchronize(ctx->stream));   // v, ucs are host temporaries
+    pl.fold = true;
+    pl.fold_T = T;
+    pl.fold_S = S;
+    return ML_OK;
+}
+
 static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id) {
     ProfScope scope(ctx, kernel_id);
     hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0, ctx->stream,
@@ -174,6 +275,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     else
         ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), mx, nx_total, 0, nx_total, dxp, wavelength,
                               n_glass, pl.ux.as<double>()));
+    ML_TRY(plan_fold(ctx, uy));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     pl.ready = true;
     return ML_OK;
@@ -203,8 +305,14 @@ int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
-        ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
-                     pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
+        if (pl.fold)
+            ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->fields.as<double>(), ny,
+                                pl.fold_cm.as<double>(), pl.fold_sm.as<double>(), pl.fold_T,
+                                pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
+                                pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my));
+        else
+            ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
+                         pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
     }
     const double dA = pl.dxp * pl.dyp;
     // fields are stored Ex,Ey,Hx,Hy; radiation vectors Nx,Ny,Lx,Ly = -Hy, Hx, Ey, -Ex (x dA)

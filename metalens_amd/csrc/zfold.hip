@@ -1,0 +1,267 @@
+// Stage 1 of the aperture -> direction transform with BOTH mirror symmetries folded in.
+//
+// Stage 1 is  G[m][j] = sum_k F[m][k] exp(-i kappa x'_k u_j)  (nearfield_farfield.py:111-120 along
+// one axis).  Aperture samples are uniformly spaced, so about the array centre the positions
+// come in +/- pairs p_t; if the direction grid is also centre-symmetric, u_j = u_c +/- v_s, then
+//
+//   x'_k u_j = (p + delta)(u_c + v) = p u_c + p v + delta u_j
+//   exp(-i kappa x' u) = D_j * E_k * (cos(kappa p v) - i sin(kappa p v))
+//
+// with E_k = exp(-i kappa p_k u_c) a modulation of the input, D_j = exp(-i kappa delta u_j) a
+// diagonal on the output, and a REAL, separately even/odd kernel in between:
+//
+//   Ge[t] = E+F[k+] + E-F[k-],  Go[t] = E+F[k+] - E-F[k-]          (fold the aperture)
+//   Pc[s] = sum_t Ge[t] cos(kappa p_t v_s),  Ps[s] = sum_t Go[t] sin(kappa p_t v_s)
+//   G[j+] = D_j+ (Pc - i Ps),  G[j-] = D_j- (Pc + i Ps)             (unfold the directions)
+//
+// Four real MFMAs (Ge_r*C, Ge_i*C, Go_r*S, Go_i*S) now serve 2 aperture samples x 2 directions:
+// one real multiply-add per complex (sample, direction) pair instead of four (or three in the 3M
+// form) - the radix-2 step of a DFT applied on both sides, exact for any uniform grids.
+// Grids that are not centre-symmetric take the generic zgemm path.
+//
+// Tiling: 64 rows x 128 half-directions (= 256 directions) per workgroup of 8 waves (2 x 4,
+// 32 x 32 per wave, 16 MFMAs per 4 t), K step 16 pairs (= 32 aperture samples).  LDS: four A
+// planes [64][18] + two B planes [16][144] = 74 KB -> 2 workgroups per CU.  With my <= 256 the
+// aperture is read from HBM exactly once.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace ml {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+struct FoldArgs {
+    const double2 *A;       // [M][ny] complex, k contiguous
+    int64_t lda;
+    int M, ny;
+    const double *Cm, *Sm;  // [T][S] real, s contiguous
+    int T, S;
+    const double2 *E;       // [ny] input modulation, or nullptr when u_c == 0
+    const double2 *D;       // [my] output diagonal
+    double2 *C;             // [M][my]
+    int64_t ldc;
+    int my;
+    int tiles_m, tiles_n, chunk;
+};
+
+__device__ __forceinline__ double2 zmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM *WN * 64) void zfold_kernel(const FoldArgs a) {
+    constexpr int BKT = 16;
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int LDAS = BKT + 2, LDBS = BN + 16;
+    constexpr int A_PER = BM * BKT / NT;          // (row, t) pairs per thread
+    constexpr int B_PER = BKT * BN / 2 / NT;      // double2 per thread per plane
+    static_assert(BM * BKT % NT == 0 && (BKT * BN / 2) % NT == 0, "tile/threads mismatch");
+
+    __shared__ double sGer[BM * LDAS], sGei[BM * LDAS], sGor[BM * LDAS], sGoi[BM * LDAS];
+    __shared__ __align__(16) double sC[BKT * LDBS], sS[BKT * LDBS];
+
+    const int b = blockIdx.x;
+    const int linear = (b & 7) * a.chunk + (b >> 3);   // XCD-aware order, see zgemm.hip
+    if (linear >= a.tiles_m * a.tiles_n) return;
+    const int tile_m = linear / a.tiles_n, tile_n = linear % a.tiles_n;
+    const int m0 = tile_m * BM, s0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fk = lane >> 4;
+
+    double2 gm[A_PER], gp[A_PER];   // F[k-], F[k+] (already modulated)
+    double2 rc[B_PER], rs[B_PER];
+    auto load_tile = [&](int t0) {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int e = tid + p * NT;
+            const int row = m0 + e / BKT, t = t0 + e % BKT;
+            const int km = t, kp = a.ny - 1 - t;
+            double2 fm = make_double2(0.0, 0.0), fp = make_double2(0.0, 0.0);
+            if (row < a.M && t < a.T) {
+                const double2 *Ar = a.A + (int64_t)row * a.lda;
+                fp = Ar[kp];
+                if (a.E) fp = zmul(fp, a.E[kp]);
+                if (km != kp) {   // odd ny: the centre sample has no partner
+                    fm = Ar[km];
+                    if (a.E) fm = zmul(fm, a.E[km]);
+                }
+            }
+            gm[p] = fm;
+            gp[p] = fp;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) {
+            const int e = (tid + p * NT) * 2;
+            const int t = t0 + e / BN, s = s0 + e % BN;
+            double2 c = make_double2(0.0, 0.0), sn = make_double2(0.0, 0.0);
+            if (t < a.T) {
+                const int64_t at = (int64_t)t * a.S + s;
+                if (s + 1 < a.S && (at & 1) == 0) {
+                    c = *reinterpret_cast<const double2 *>(a.Cm + at);
+                    sn = *reinterpret_cast<const double2 *>(a.Sm + at);
+                } else {
+                    if (s < a.S) {
+                        c.x = a.Cm[at];
+                        sn.x = a.Sm[at];
+                    }
+                    if (s + 1 < a.S) {
+                        c.y = a.Cm[at + 1];
+                        sn.y = a.Sm[at + 1];
+                    }
+                }
+            }
+            rc[p] = c;
+            rs[p] = sn;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int e = tid + p * NT;
+            const int at = (e / BKT) * LDAS + e % BKT;
+            sGer[at] = gp[p].x + gm[p].x;
+            sGei[at] = gp[p].y + gm[p].y;
+            sGor[at] = gp[p].x - gm[p].x;
+            sGoi[at] = gp[p].y - gm[p].y;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) {
+            const int e = (tid + p * NT) * 2;
+            const int at = (e / BN) * LDBS + e % BN;
+            *reinterpret_cast<double2 *>(&sC[at]) = rc[p];
+            *reinterpret_cast<double2 *>(&sS[at]) = rs[p];
+        }
+    };
+
+    v4d pcr[TM][TN], pci[TM][TN], psr[TM][TN], psi[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            pcr[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            pci[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            psr[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            psi[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
+
+    load_tile(0);
+    for (int t0 = 0; t0 < a.T; t0 += BKT) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (t0 + BKT < a.T) load_tile(t0 + BKT);
+#pragma unroll
+        for (int s = 0; s < BKT / 4; ++s) {
+            double ger[TM], gei[TM], gor[TM], goi[TM], cc[TN], ss[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int at = ((wm * TM + i) * 16 + frow) * LDAS + s * 4 + fk;
+                ger[i] = sGer[at];
+                gei[i] = sGei[at];
+                gor[i] = sGor[at];
+                goi[i] = sGoi[at];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int at = (s * 4 + fk) * LDBS + (wn * TN + j) * 16 + frow;
+                cc[j] = sC[at];
+                ss[j] = sS[at];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    pcr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ger[i], cc[j], pcr[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    pci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gei[i], cc[j], pci[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    psr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gor[i], ss[j], psr[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    psi[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(goi[i], ss[j], psi[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: unfold the directions.  f64 MFMA C/D layout: col = lane & 15,
+    // row = (lane >> 4) + 4 * reg.
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int s = s0 + (wn * TN + j) * 16 + (lane & 15);
+            if (s >= a.S) continue;
+            const int jm = s, jp = a.my - 1 - s;       // direction columns of -v_s and +v_s
+            const double2 dm = a.D[jm], dp = a.D[jp];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + (wm * TM + i) * 16 + (lane >> 4) + 4 * r;
+                if (row >= a.M) continue;
+                const double cr = pcr[i][j][r], ci = pci[i][j][r];
+                const double sr = psr[i][j][r], si = psi[i][j][r];
+                // +v: Pc - i Ps ; -v: Pc + i Ps
+                const double2 plus = make_double2(cr + si, ci - sr);
+                const double2 minus = make_double2(cr - si, ci + sr);
+                double2 *Crow = a.C + (int64_t)row * a.ldc;
+                Crow[jp] = zmul(plus, dp);
+                if (jm != jp) Crow[jm] = zmul(minus, dm);
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_fold(hipStream_t stream, FoldArgs &a) {
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.S + BN - 1) / BN;
+    const int tiles = a.tiles_m * a.tiles_n;
+    a.chunk = (tiles + 7) / 8;
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
+                       stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
+                 const double *Sm, int T, int S, const double *E, const double *D, double *C,
+                 int64_t ldc, int my) {
+    FoldArgs a;
+    a.A = reinterpret_cast<const double2 *>(A);
+    a.lda = lda;
+    a.M = M;
+    a.ny = ny;
+    a.Cm = Cm;
+    a.Sm = Sm;
+    a.T = T;
+    a.S = S;
+    a.E = reinterpret_cast<const double2 *>(E);
+    a.D = reinterpret_cast<const double2 *>(D);
+    a.C = reinterpret_cast<double2 *>(C);
+    a.ldc = ldc;
+    a.my = my;
+    static const int forced = [] {
+        const char *e = getenv("ML_ZFOLD_TILE");
+        return e ? atoi(e) : -1;
+    }();
+    const long big = (long)((M + 63) / 64) * ((S + 127) / 128);
+    int pick = big >= 256 ? 0 : 1;
+    if (forced >= 0) pick = forced;
+    switch (pick) {
+        case 1: return launch_fold<64, 64, 2, 2>(stream, a);
+        case 2: return launch_fold<32, 64, 2, 2>(stream, a);
+        case 3: return launch_fold<128, 64, 4, 2>(stream, a);
+        default: return launch_fold<64, 128, 2, 4>(stream, a);
+    }
+}
+
+}  // namespace ml

@@ -159,7 +159,8 @@ def test_direct_transform_on_fft_lattice_golden(ma):
 
 
 @pytest.mark.parametrize('shape', [(48, 40, 37, 29), (130, 70, 65, 130), (64, 64, 64, 64),
-                                   (17, 200, 5, 3)])
+                                   (17, 200, 5, 3), (33, 45, 12, 18), (21, 131, 7, 131),
+                                   (40, 257, 9, 2)])
 def test_direct_transform_vs_oracle_ragged(ma, shape):
     """off-lattice directions, sizes that are not multiples of any tile"""
     from oracle import farfield_oracle
@@ -178,6 +179,32 @@ def test_direct_transform_vs_oracle_ragged(ma, shape):
     ok = ~np.isnan(want['P'])
     assert np.array_equal(np.isnan(got['P']), ~ok)
     assert np.abs(got['P'][ok] - want['P'][ok]).max() <= 1e-11 * want['P'][ok].max()
+
+
+@pytest.mark.parametrize('kind', ['symmetric_about_zero', 'random_unsorted', 'nearly_symmetric'])
+def test_direct_transform_direction_grids(ma, kind):
+    """the folded (even/odd) stage 1 is used for centre-symmetric uy grids and the generic
+    GEMM otherwise; both must agree with the oracle"""
+    from oracle import farfield_oracle
+    rng = np.random.default_rng(5)
+    nx, ny, mx, my = 40, 90, 11, 50
+    F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+    wl, n = 580e-9, 1.459
+    x = np.arange(nx) * (wl / 2.2)
+    y = np.arange(ny) * (wl / 2.2)
+    ux = rng.uniform(-0.5, 0.5, mx)
+    if kind == 'symmetric_about_zero':
+        uy = np.linspace(-0.4, 0.4, my)
+        uy = 0.5 * (uy - uy[::-1])                      # exactly antisymmetric: no modulation
+    elif kind == 'random_unsorted':
+        uy = rng.uniform(-0.6, 0.6, my)                 # generic path
+    else:
+        uy = np.linspace(-0.2, 0.5, my)
+        uy[7] += 3e-9                                   # breaks the symmetry: generic path
+    got = ma.farfield_direct(*F, x, y, wl, n, ux, uy)
+    want = farfield_oracle.farfield_direct(*F, x, y, wl, n, ux, uy)
+    for key in ('Nx', 'Ny', 'Lx', 'Ly', 'a_theta', 'a_phi'):
+        assert np.abs(got[key] - want[key]).max() <= TOL * np.abs(want[key]).max(), key
 
 
 def test_pair_list_vs_oracle(ma):
