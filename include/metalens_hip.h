@@ -172,6 +172,9 @@ int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_allreduce(ml_ctx *ctx);
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi);
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
+/* which stage-1 kernel the current plan uses: *stage1_kernel = 0 generic complex GEMM (3M),
+ * 1 folded even/odd real-kernel GEMM (centre-symmetric uy grid).                          */
+int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
  * ml_comm_unique_id fills id[128] on rank 0; the host passes it to the other ranks by

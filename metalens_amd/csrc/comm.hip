@@ -9,6 +9,8 @@
 // librccl is loaded with dlopen the first time a communicator is needed, so single-GPU use
 // never touches it.
 #include <dlfcn.h>
+
+#include <cstdlib>
 #include <rccl/rccl.h>
 
 #include "common.h"
@@ -71,7 +73,7 @@ void comm_release(ml_ctx *ctx) {
 }
 
 static int allreduce_dev(ml_ctx *ctx, double *buf, size_t count, int op) {
-    if (ctx->n_ranks <= 1) return ML_OK;
+    if (ctx->n_ranks <= 1 && !ctx->comm) return ML_OK;
     if (!ctx->comm) {
         set_error("ml_comm_init has not been called");
         return ML_ESTATE;
@@ -104,7 +106,10 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     comm_release(ctx);
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
-    if (n_ranks == 1) return ML_OK;
+    // ML_FORCE_RCCL=1 builds a real one-rank communicator (exercises dlopen, the unique-id
+    // ABI and the all-reduce on a single-GPU box)
+    const char *force = getenv("ML_FORCE_RCCL");
+    if (n_ranks == 1 && !(force && atoi(force))) return ML_OK;
     ML_TRY(load_rccl());
     ncclUniqueId u;
     memcpy(&u, id, 128);
@@ -128,7 +133,7 @@ int ml_farfield_allreduce(ml_ctx *ctx) {
 
 int ml_comm_allreduce_host(ml_ctx *ctx, double *values, int count, int op) {
     ML_REQUIRE(ctx && values && count >= 1, "bad argument");
-    if (ctx->n_ranks <= 1) return ML_OK;
+    if (ctx->n_ranks <= 1 && !ctx->comm) return ML_OK;
     ML_HIP(hipSetDevice(ctx->device));
     ML_TRY(ctx->comm_scratch.reserve(count * sizeof(double)));
     ML_HIP(hipMemcpyAsync(ctx->comm_scratch.p, values, count * sizeof(double),

@@ -420,7 +420,7 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     ML_TRY(ctx->fields.reserve(4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
-    const int blocks = ((ny + 255) / 256) * nx;
+    const int blocks = std::max(((ny + 255) / 256) * nx, ((ny + 31) / 32) * ((nx + 7) / 8));
     ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
     ML_TRY(ctx->power.reserve(sizeof(double)));
     const size_t viol_bytes = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);

@@ -388,6 +388,16 @@ int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, doub
     return prof_harvest(ctx);
 }
 
+int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel) {
+    ML_REQUIRE(ctx && stage1_kernel, "NULL argument");
+    if (!ctx->plan.ready) {
+        set_error("ml_farfield_plan has not been called");
+        return ML_ESTATE;
+    }
+    *stage1_kernel = ctx->plan.fold ? 1 : 0;
+    return ML_OK;
+}
+
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly) {
     ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;

@@ -292,16 +292,16 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
     NfArgs a;
     fill_nf_args(ctx, p, nx, ny, a);
     const dim3 grid((ny + 255) / 256, nx);
+    int n_partials = (int)(grid.x * grid.y);
     if (use_exact_kernel()) {
         ProfScope scope(ctx, ML_K_NEARFIELD);
         hipLaunchKernelGGL(nearfield_exact_kernel, grid, dim3(256), 0, ctx->stream, a);
     } else {
         ProfScope scope(ctx, ML_K_NEARFIELD);
-        ML_TRY(nearfield_fast_launch(ctx, a, grid));
+        ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->partial_power.as<double>(), (int)(grid.x * grid.y),
-                       ctx->power.as<double>());
+                       ctx->partial_power.as<double>(), n_partials, ctx->power.as<double>());
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

@@ -146,6 +146,7 @@ __device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 E
 }
 
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a);
-int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid);
+// writes the number of per-block power partials it produces to *n_partials
+int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
 
 }  // namespace ml

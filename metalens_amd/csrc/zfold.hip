@@ -49,8 +49,8 @@ __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM *WN * 64) void zfold_kernel(const FoldArgs a) {
+template <int BM, int BN, int WM, int WN, int UNR>
+__global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a) {
     constexpr int BKT = 16;
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WM *WN * 64) void zfold_kernel(const FoldArgs a) {
         store_tile();
         __syncthreads();
         if (t0 + BKT < a.T) load_tile(t0 + BKT);
-#pragma unroll
+#pragma unroll UNR
         for (int s = 0; s < BKT / 4; ++s) {
             double ger[TM], gei[TM], gor[TM], goi[TM], cc[TN], ss[TN];
 #pragma unroll
@@ -220,13 +220,13 @@ __global__ __launch_bounds__(WM *WN * 64) void zfold_kernel(const FoldArgs a) {
         }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int UNR = 4>
 static int launch_fold(hipStream_t stream, FoldArgs &a) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
@@ -253,13 +253,22 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         const char *e = getenv("ML_ZFOLD_TILE");
         return e ? atoi(e) : -1;
     }();
-    const long big = (long)((M + 63) / 64) * ((S + 127) / 128);
-    int pick = big >= 256 ? 0 : 1;
+    // measured (tools/zgemm_sweep.py): 32 x 128 tiles (4 waves, 2 workgroups per CU) once they
+    // give >= 2 workgroups per CU, else 32 x 64
+    const long wide = (long)((M + 31) / 32) * ((S + 127) / 128);
+    int pick = wide >= 512 ? 9 : 8;
     if (forced >= 0) pick = forced;
     switch (pick) {
         case 1: return launch_fold<64, 64, 2, 2>(stream, a);
         case 2: return launch_fold<32, 64, 2, 2>(stream, a);
         case 3: return launch_fold<128, 64, 4, 2>(stream, a);
+        case 4: return launch_fold<64, 64, 2, 2, 1>(stream, a);
+        case 5: return launch_fold<64, 64, 2, 2, 2>(stream, a);
+        case 6: return launch_fold<64, 128, 2, 4, 1>(stream, a);
+        case 7: return launch_fold<64, 128, 2, 4, 2>(stream, a);
+        case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a);
+        case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a);
+        case 10: return launch_fold<32, 128, 2, 2, 1>(stream, a);
         default: return launch_fold<64, 128, 2, 4>(stream, a);
     }
 }

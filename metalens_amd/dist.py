@@ -22,6 +22,12 @@ import numpy as np
 from . import _lib
 
 
+def force_rccl():
+    """ML_FORCE_RCCL=1: build a real one-rank RCCL communicator and run the all-reduce even
+    with a single GPU (test hook for the multi-GPU code path)"""
+    return os.environ.get('ML_FORCE_RCCL', '0') not in ('', '0')
+
+
 def env_rank():
     return (int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')),
             int(os.environ.get('WORLD_SIZE', '1')))
@@ -72,7 +78,7 @@ def exchange_unique_id(rank, world, timeout=120.0, path=None):
 
 
 def init_comm(ctx, rank, world):
-    if world <= 1:
+    if world <= 1 and not force_rccl():
         return
     uid = exchange_unique_id(rank, world)
     buf = (_lib.c_uint8 * 128).from_buffer_copy(uid)

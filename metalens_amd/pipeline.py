@@ -59,7 +59,7 @@ class HotPath:
                                               _lib.dptr(self.x_local), self.x_local.size,
                                               _lib.dptr(self.y), self.y.size))
             _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
-        if self.world > 1:
+        if self.world > 1 or dist.force_rccl():
             _lib.check(lib.ml_farfield_allreduce(ctx.handle))
         _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
 

@@ -251,6 +251,26 @@ def test_sharded_rows_sum_to_whole(ma):
         assert np.abs(got[key] - whole[key]).max() <= 1e-13 * np.abs(whole[key]).max(), key
 
 
+def test_rccl_path_single_rank():
+    """the multi-GPU code path (RCCL loaded with dlopen, unique-id exchange through /tmp,
+    communicator, all-reduce of the radiation vectors, max/sum reductions) run for real with
+    one rank: results must equal the plain single-GPU run"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', '512', '--farfield', '64',
+           '--diameter', '3e-4', '--steps', '2', '--warmup', '1', '--cpu-rows', '0']
+    env = dict(os.environ, ML_FORCE_RCCL='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29511')
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1
+    assert line['rel_err']['farfield_E_vs_oracle'] < 1e-12
+    assert line['rel_err']['nearfield_vs_oracle'] < 1e-12
+
+
 def test_full_size_roundtrip_properties(ma):
     """BASELINE config[1] size (2048^2 -> 256^2): size-independent checks - the direct
     transform of a separable field equals the outer product of 1-D transforms, and is
