@@ -128,7 +128,8 @@ struct FarfieldPlan {
     // folded (even/odd) stage 1, see zfold.hip; used when uy is centre-symmetric
     bool fold = false, fold_has_E = false;
     int fold_T = 0, fold_S = 0;
-    DevBuf fold_cm, fold_sm, fold_E, fold_D, fold_v;
+    DevBuf fold_cm, fold_sm, fold_E, fold_D, fold_v, fold_r4;
+    std::vector<double> h_ux, h_uy, h_fold_v;   // host copies of the plan's inputs
 };
 
 }  // namespace ml
@@ -206,8 +207,8 @@ int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *
             const double *TX, int64_t ldtx, int j0, const double *G, double *out, int accumulate);
 // zfold.hip: stage 1 with both mirror symmetries folded (real cos/sin kernel)
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
-                 const double *Sm, int T, int S, const double *E, const double *D, double *C,
-                 int64_t ldc, int my);
+                 const double *Sm, const double *R4, int T, int S, const double *E,
+                 const double *D, double *C, int64_t ldc, int my);
 // comm.hip
 void comm_release(ml_ctx *ctx);
 

@@ -7,8 +7,10 @@
 //                           restating nearfield_farfield.py:153-189 operation by operation
 //   * ml_farfield_lattice_power   the same projection on the caller's FFT'd fields
 //                           (drop-in for farfield_from_nearfield_helper)
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -154,6 +156,22 @@ static int launch_twiddle(ml_ctx *ctx, double *out, int rows, int cols, int samp
     return ML_OK;
 }
 
+// Host arrays that parametrise a plan are kept in the plan and re-uploaded only when they
+// change, so that re-planning the same geometry every step queues kernels only (no host
+// synchronisation): the phase tables themselves are recomputed on every call.
+static int upload_if_changed(ml_ctx *ctx, DevBuf &dev, std::vector<double> &host,
+                             const double *src, size_t n) {
+    if (host.size() == n && dev.p && memcmp(host.data(), src, n * sizeof(double)) == 0)
+        return ML_OK;
+    // an earlier asynchronous copy may still be reading `host`
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    host.assign(src, src + n);
+    ML_TRY(dev.reserve(std::max<size_t>(n, 2) * sizeof(double)));
+    ML_HIP(hipMemcpyAsync(dev.p, host.data(), n * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+    return ML_OK;
+}
+
 // Decide whether stage 1 can run folded (zfold.hip) and build its tables.  Needs a tensor
 // grid whose uy are centre-symmetric to within 1e-13 rad of phase at the aperture edge.
 static int plan_fold(ml_ctx *ctx, const double *uy) {
@@ -169,7 +187,7 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
     const long double kappa = (long double)pl.n_glass / (long double)pl.wavelength;
     const long double p_max = 0.5L * (ny - 1) * fabsl((long double)pl.dyp);
     const long double uc = 0.5L * ((long double)uy[0] + (long double)uy[my - 1]);
-    std::vector<double> v(2 * (size_t)S);   // hi[S] then lo[S]
+    std::vector<double> v(2 * (size_t)S + 2);   // hi[S], lo[S], then u_c as (hi, lo)
     long double worst = 0;
     for (int s = 0; s < S; ++s) {
         const long double up = uy[my - 1 - s], um = uy[s];
@@ -179,13 +197,14 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
         v[S + s] = (double)(vs - (long double)v[s]);
     }
     if (2 * M_PIl * kappa * p_max * worst > 1e-13L) return ML_OK;   // not symmetric enough
-    ML_TRY(pl.fold_v.reserve(v.size() * sizeof(double)));
-    ML_HIP(hipMemcpyAsync(pl.fold_v.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice,
-                          ctx->stream));
+    v[2 * (size_t)S] = (double)uc;
+    v[2 * (size_t)S + 1] = (double)(uc - (long double)v[2 * (size_t)S]);
+    ML_TRY(upload_if_changed(ctx, pl.fold_v, pl.h_fold_v, v.data(), v.size()));
     ML_TRY(pl.fold_cm.reserve((size_t)T * S * sizeof(double)));
     ML_TRY(pl.fold_sm.reserve((size_t)T * S * sizeof(double)));
-    ML_TRY(pl.fold_E.reserve((size_t)ny * 2 * sizeof(double) + 16));
+    ML_TRY(pl.fold_E.reserve((size_t)ny * 2 * sizeof(double)));
     ML_TRY(pl.fold_D.reserve((size_t)my * 2 * sizeof(double)));
+    ML_TRY(pl.fold_r4.reserve((size_t)S * 2 * sizeof(double)));
     const long double s = kappa * (long double)pl.dyp;   // turns per (sample index x u)
     const double s_hi = (double)s, s_lo = (double)(s - (long double)s_hi);
     const double half = 0.5 * (ny - 1);
@@ -195,14 +214,16 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
                        (double2 *)nullptr, pl.fold_cm.as<double>(), pl.fold_sm.as<double>(), T, S,
                        1, half, -1.0, s_hi, s_lo, pl.fold_v.as<double>(),
                        pl.fold_v.as<double>() + S);
+    // rotation that advances the table by four samples: cos / sin of kappa (4 dy) v_s
+    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, 1), dim3(256), 0, ctx->stream,
+                       (double2 *)nullptr, pl.fold_r4.as<double>(), pl.fold_r4.as<double>() + S, 1,
+                       S, 1, 4.0, 0.0, s_hi, s_lo, pl.fold_v.as<double>(),
+                       pl.fold_v.as<double>() + S);
     // input modulation E_k = exp(-i kappa p_k u_c), p_k = (k - half) dy; skipped when u_c == 0
-    const double uc_hi = (double)uc, uc_lo = (double)(uc - (long double)uc_hi);
     pl.fold_has_E = (uc != 0);
     if (pl.fold_has_E) {
-        // the single direction u_c travels behind the table in fold_E's tail
-        double ucs[2] = {uc_hi, uc_lo};
-        double *tail = pl.fold_E.as<double>() + (size_t)ny * 2;
-        ML_HIP(hipMemcpyAsync(tail, ucs, sizeof ucs, hipMemcpyHostToDevice, ctx->stream));
+        // the single direction u_c travels behind v in fold_v
+        const double *tail = pl.fold_v.as<double>() + 2 * (size_t)S;
         hipLaunchKernelGGL(phase_table_kernel, dim3((ny + 255) / 256, 1), dim3(256), 0, ctx->stream,
                            pl.fold_E.as<double2>(), (double *)nullptr, (double *)nullptr, 1, ny, 0,
                            -half, 1.0, s_hi, s_lo, tail, tail + 1);
@@ -213,7 +234,6 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
                        pl.fold_D.as<double2>(), (double *)nullptr, (double *)nullptr, 1, my, 1,
                        delta, 0.0, s_hi, s_lo, pl.uy.as<double>(), (const double *)nullptr);
     ML_HIP(hipGetLastError());
-    ML_HIP(hipStreamSynchronize(ctx->stream));   // v, ucs are host temporaries
     pl.fold = true;
     pl.fold_T = T;
     pl.fold_S = S;
@@ -254,19 +274,21 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     pl.dyp = dyp;
     pl.wavelength = wavelength;
     pl.n_glass = n_glass;
-    ML_TRY(pl.ux.reserve(mx * sizeof(double)));
-    ML_TRY(pl.uy.reserve(my * sizeof(double)));
-    ML_HIP(hipMemcpyAsync(pl.ux.p, ux, mx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    ML_HIP(hipMemcpyAsync(pl.uy.p, uy, my * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ML_TRY(upload_if_changed(ctx, pl.ux, pl.h_ux, ux, mx));
+    ML_TRY(upload_if_changed(ctx, pl.uy, pl.h_uy, uy, my));
     ML_TRY(pl.tw_x.reserve((size_t)mx * nx_total * 2 * sizeof(double)));
-    ML_TRY(pl.tw_y.reserve((size_t)ny * my * 2 * sizeof(double)));
     const size_t out_elems = pair_list ? (size_t)mx : (size_t)mx * my;
     ML_TRY(pl.vectors.reserve(4 * out_elems * 2 * sizeof(double)));
     ML_TRY(pl.power.reserve(out_elems * sizeof(double)));
     ML_TRY(pl.amplitudes.reserve(2 * out_elems * 2 * sizeof(double)));
-    // tw_y[k][j]: sample-major, B operand of stage 1
-    ML_TRY(launch_twiddle(ctx, pl.tw_y.as<double>(), ny, my, 1, ny, dyp, wavelength, n_glass,
-                          pl.uy.as<double>()));
+    // stage 1 operand: the folded cos/sin tables when uy is centre-symmetric, else the complex
+    // twiddles tw_y[k][j] (sample-major, B operand of the generic GEMM)
+    ML_TRY(plan_fold(ctx, uy));
+    if (!pl.fold) {
+        ML_TRY(pl.tw_y.reserve((size_t)ny * my * 2 * sizeof(double)));
+        ML_TRY(launch_twiddle(ctx, pl.tw_y.as<double>(), ny, my, 1, ny, dyp, wavelength, n_glass,
+                              pl.uy.as<double>()));
+    }
     // tw_x: direction-major [mx][nx_total] (A operand of stage 2) for a tensor grid,
     // sample-major [nx_total][mx] for a pair list (column dot)
     if (pair_list)
@@ -275,8 +297,6 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     else
         ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), mx, nx_total, 0, nx_total, dxp, wavelength,
                               n_glass, pl.ux.as<double>()));
-    ML_TRY(plan_fold(ctx, uy));
-    ML_HIP(hipStreamSynchronize(ctx->stream));
     pl.ready = true;
     return ML_OK;
 }
@@ -307,7 +327,8 @@ int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
         if (pl.fold)
             ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->fields.as<double>(), ny,
-                                pl.fold_cm.as<double>(), pl.fold_sm.as<double>(), pl.fold_T,
+                                pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
+                                pl.fold_r4.as<double>(), pl.fold_T,
                                 pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
                                 pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my));
         else

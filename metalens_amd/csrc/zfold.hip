@@ -36,6 +36,7 @@ struct FoldArgs {
     int64_t lda;
     int M, ny;
     const double *Cm, *Sm;  // [T][S] real, s contiguous
+    const double *R4c, *R4s; // [S] cos / sin of the rotation that advances t by 4 (FLY kernels)
     int T, S;
     const double2 *E;       // [ny] input modulation, or nullptr when u_c == 0
     const double2 *D;       // [my] output diagonal
@@ -49,7 +50,7 @@ __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN, int UNR>
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY>
 __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a) {
     constexpr int BKT = 16;
     constexpr int NT = WM * WN * 64;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
     static_assert(BM * BKT % NT == 0 && (BKT * BN / 2) % NT == 0, "tile/threads mismatch");
 
     __shared__ double sGer[BM * LDAS], sGei[BM * LDAS], sGor[BM * LDAS], sGoi[BM * LDAS];
-    __shared__ __align__(16) double sC[BKT * LDBS], sS[BKT * LDBS];
+    __shared__ __align__(16) double sC[FLY ? 2 : BKT * LDBS], sS[FLY ? 2 : BKT * LDBS];
 
     const int b = blockIdx.x;
     const int linear = (b & 7) * a.chunk + (b >> 3);   // XCD-aware order, see zgemm.hip
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
             gp[p] = fp;
         }
 #pragma unroll
-        for (int p = 0; p < B_PER; ++p) {
+        for (int p = 0; p < (FLY ? 0 : B_PER); ++p) {
             const int e = (tid + p * NT) * 2;
             const int t = t0 + e / BN, s = s0 + e % BN;
             double2 c = make_double2(0.0, 0.0), sn = make_double2(0.0, 0.0);
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
             sGoi[at] = gp[p].y - gm[p].y;
         }
 #pragma unroll
-        for (int p = 0; p < B_PER; ++p) {
+        for (int p = 0; p < (FLY ? 0 : B_PER); ++p) {
             const int e = (tid + p * NT) * 2;
             const int at = (e / BN) * LDBS + e % BN;
             *reinterpret_cast<double2 *>(&sC[at]) = rc[p];
@@ -148,12 +149,48 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
             psi[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
         }
 
+    // FLY: the cos/sin operand never touches LDS.  Lane (fk, frow) needs, for each of its TN
+    // direction columns, the entries at t = t0 + 4 q + fk: successive s-steps are a rotation
+    // by the fixed angle 4 kappa dy v_s, so each lane carries (cos, sin) per column, rotates it
+    // after every s-step, and re-seeds it from the exact table every RESEED samples (rounding
+    // drift stays below ~16 rotations).
+    constexpr int RESEED = 64;
+    double bc[TN], bs[TN], r4c[TN], r4s[TN], seed_c[TN], seed_s[TN];
+    auto load_seed = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int s = s0 + (wn * TN + j) * 16 + frow, t = t0 + fk;
+            const bool ok = s < a.S && t < a.T;
+            seed_c[j] = ok ? a.Cm[(int64_t)t * a.S + s] : 0.0;
+            seed_s[j] = ok ? a.Sm[(int64_t)t * a.S + s] : 0.0;
+        }
+    };
+    if (FLY) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int s = s0 + (wn * TN + j) * 16 + frow;
+            r4c[j] = s < a.S ? a.R4c[s] : 1.0;
+            r4s[j] = s < a.S ? a.R4s[s] : 0.0;
+        }
+        load_seed(0);
+    }
+
     load_tile(0);
     for (int t0 = 0; t0 < a.T; t0 += BKT) {
         __syncthreads();
         store_tile();
         __syncthreads();
         if (t0 + BKT < a.T) load_tile(t0 + BKT);
+        if (FLY) {
+            if (t0 % RESEED == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bc[j] = seed_c[j];
+                    bs[j] = seed_s[j];
+                }
+            }
+            if ((t0 + BKT) % RESEED == 0 && t0 + BKT < a.T) load_seed(t0 + BKT);
+        }
 #pragma unroll UNR
         for (int s = 0; s < BKT / 4; ++s) {
             double ger[TM], gei[TM], gor[TM], goi[TM], cc[TN], ss[TN];
@@ -167,9 +204,19 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int at = (s * 4 + fk) * LDBS + (wn * TN + j) * 16 + frow;
-                cc[j] = sC[at];
-                ss[j] = sS[at];
+                if (FLY) {
+                    cc[j] = bc[j];
+                    ss[j] = bs[j];
+                    // advance t by 4: angle decreases by 4 kappa dy v_s
+                    const double nc = fma(bc[j], r4c[j], bs[j] * r4s[j]);
+                    const double ns = fma(bs[j], r4c[j], -bc[j] * r4s[j]);
+                    bc[j] = nc;
+                    bs[j] = ns;
+                } else {
+                    const int at = (s * 4 + fk) * LDBS + (wn * TN + j) * 16 + frow;
+                    cc[j] = sC[at];
+                    ss[j] = sS[at];
+                }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -220,21 +267,21 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
         }
 }
 
-template <int BM, int BN, int WM, int WN, int UNR = 4>
+template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false>
 static int launch_fold(hipStream_t stream, FoldArgs &a) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
 
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
-                 const double *Sm, int T, int S, const double *E, const double *D, double *C,
-                 int64_t ldc, int my) {
+                 const double *Sm, const double *R4, int T, int S, const double *E,
+                 const double *D, double *C, int64_t ldc, int my) {
     FoldArgs a;
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
@@ -242,6 +289,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.ny = ny;
     a.Cm = Cm;
     a.Sm = Sm;
+    a.R4c = R4;
+    a.R4s = R4 + S;
     a.T = T;
     a.S = S;
     a.E = reinterpret_cast<const double2 *>(E);
@@ -256,7 +305,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     // measured (tools/zgemm_sweep.py): 32 x 128 tiles (4 waves, 2 workgroups per CU) once they
     // give >= 2 workgroups per CU, else 32 x 64
     const long wide = (long)((M + 31) / 32) * ((S + 127) / 128);
-    int pick = wide >= 512 ? 9 : 8;
+    // (the on-the-fly-rotation variants 21 / 26 are 2-5 % faster than the table variants 9 / 8)
+    int pick = wide >= 512 ? 21 : 26;
     if (forced >= 0) pick = forced;
     switch (pick) {
         case 1: return launch_fold<64, 64, 2, 2>(stream, a);
@@ -269,6 +319,14 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a);
         case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a);
         case 10: return launch_fold<32, 128, 2, 2, 1>(stream, a);
+        case 20: return launch_fold<32, 128, 2, 2, 2, true>(stream, a);
+        case 21: return launch_fold<32, 128, 2, 2, 1, true>(stream, a);
+        case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a);
+        case 23: return launch_fold<64, 64, 2, 2, 1, true>(stream, a);
+        case 24: return launch_fold<64, 64, 2, 2, 2, true>(stream, a);
+        case 25: return launch_fold<64, 128, 2, 4, 2, true>(stream, a);
+        case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a);
+        case 27: return launch_fold<64, 128, 2, 2, 1, true>(stream, a);
         default: return launch_fold<64, 128, 2, 4>(stream, a);
     }
 }
