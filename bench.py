@@ -196,7 +196,7 @@ def main():
     # ---- roofline of the dominant kernel: stage-1 complex GEMM on the fp64 matrix cores.
     # algorithmic flops per launch = 8 (complex MAC) x (4 fields x local rows) x ny x my
     s1 = prof['zgemm_stage1']
-    local_rows = hp.row1 - hp.row0
+    local_rows = hp.x_local.size
     flops = 8.0 * 4 * local_rows * side * u.size
     if s1['launches']:
         avg_ms = s1['total_ms'] / s1['launches']

@@ -169,6 +169,10 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp,
                      double wavelength, double n_glass,
                      const double *ux, int mx, const double *uy, int my, int pair_list);
 int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate);
+/* Same for a MIRRORED shard: the resident rows are [row0, row0+h) followed by
+ * [nx_total-row0-h, nx_total-row0), h = resident rows / 2 - the row pairs +/-x' of one rank.
+ * Both transform stages then run folded; needs a tensor grid with centre-symmetric ux.      */
+int ml_farfield_transform_mirrored(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_allreduce(ml_ctx *ctx);
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi);
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
@@ -208,6 +212,7 @@ int ml_sync(ml_ctx *ctx);
 int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p,
                        const double *x_pts, int nx, const double *y_pts, int ny);
 int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate);
+int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_project_async(ml_ctx *ctx, double Z0);
 int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,
                         int max_violations, int *n_violations);

@@ -26,7 +26,8 @@ SYMBOLS = (
     'ml_farfield_plan', 'ml_farfield_transform', 'ml_farfield_allreduce', 'ml_farfield_project',
     'ml_farfield_download', 'ml_farfield_plan_info', 'ml_comm_unique_id', 'ml_comm_init', 'ml_comm_allreduce_host',
     'ml_comm_barrier', 'ml_profile_enable', 'ml_profile_reset', 'ml_profile_get', 'ml_sync',
-    'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_project_async',
+    'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_transform_mirrored',
+    'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
     'ml_nearfield_result',
 )
 
@@ -92,6 +93,8 @@ def load():
                                      c_double, _dp, c_int, _dp, c_int, c_int]
     lib.ml_farfield_transform.argtypes = [c_void_p, c_int, c_int]
     lib.ml_farfield_transform_async.argtypes = [c_void_p, c_int, c_int]
+    lib.ml_farfield_transform_mirrored.argtypes = [c_void_p, c_int, c_int]
+    lib.ml_farfield_transform_mirrored_async.argtypes = [c_void_p, c_int, c_int]
     lib.ml_farfield_allreduce.argtypes = [c_void_p]
     lib.ml_farfield_project.argtypes = [c_void_p, c_double, _dp, _dp, _dp]
     lib.ml_farfield_project_async.argtypes = [c_void_p, c_double]

@@ -129,7 +129,11 @@ struct FarfieldPlan {
     bool fold = false, fold_has_E = false;
     int fold_T = 0, fold_S = 0;
     DevBuf fold_cm, fold_sm, fold_E, fold_D, fold_v, fold_r4;
-    std::vector<double> h_ux, h_uy, h_fold_v;   // host copies of the plan's inputs
+    std::vector<double> h_ux, h_uy, h_fold_v, h_fold2_v;   // host copies of the plan's inputs
+    // folded stage 2 (needs centre-symmetric ux and a mirror-symmetric set of resident rows)
+    bool fold2 = false, fold2_has_E = false;
+    int fold2_S = 0;
+    DevBuf fold2_v, fold2_cm, fold2_sm, fold2_r4, fold2_E, fold2_D, fold2_gt, fold2_ot;
 };
 
 }  // namespace ml

@@ -228,7 +228,9 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
                       &ctx->plan.amplitudes, &ctx->comm_scratch, &ctx->lattice_in,
                       &ctx->plan.fold_cm, &ctx->plan.fold_sm, &ctx->plan.fold_E, &ctx->plan.fold_D,
-                      &ctx->plan.fold_v, &ctx->plan.fold_r4};
+                      &ctx->plan.fold_v, &ctx->plan.fold_r4, &ctx->plan.fold2_v, &ctx->plan.fold2_cm,
+                      &ctx->plan.fold2_sm, &ctx->plan.fold2_r4, &ctx->plan.fold2_E, &ctx->plan.fold2_D,
+                      &ctx->plan.fold2_gt, &ctx->plan.fold2_ot};
     for (DevBuf *b : bufs) b->release();
     for (auto &pd : ctx->prof.pending) {
         (void)hipEventDestroy(pd.a);

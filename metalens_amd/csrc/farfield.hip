@@ -79,6 +79,55 @@ __global__ __launch_bounds__(256) void phase_table_kernel(double2 *out, double *
     }
 }
 
+// out[b][c][r] = in[b][r][c] (complex), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void ztranspose_kernel(const double2 *in, double2 *out, int rows,
+                                                         int cols) {
+    __shared__ double2 tile[32][33];
+    const size_t plane = (size_t)rows * cols;
+    in += blockIdx.z * plane;
+    out += blockIdx.z * plane;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < rows && c0 + tx < cols) tile[k][tx] = in[(size_t)(r0 + k) * cols + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < cols && r0 + tx < rows) out[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
+}
+
+struct Alpha4f {
+    double v[4];
+};
+
+// V[3 - f][a][j] (+)= alpha_f * in[f][j][a]: transposes the folded stage-2 result back into
+// the radiation-vector layout, applies the reference's signs x dA and the field -> vector map
+__global__ __launch_bounds__(256) void zunfold_out_kernel(const double2 *in, double2 *out, int my,
+                                                          int mx, Alpha4f alpha, int accumulate) {
+    __shared__ double2 tile[32][33];
+    const int f = blockIdx.z;
+    const size_t plane = (size_t)mx * my;
+    in += (size_t)f * plane;
+    out += (size_t)(3 - f) * plane;
+    const double al = alpha.v[f];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int a0 = blockIdx.x * 32, j0 = blockIdx.y * 32;   // in is [j][a]
+    for (int k = ty; k < 32; k += 8)
+        if (j0 + k < my && a0 + tx < mx) tile[k][tx] = in[(size_t)(j0 + k) * mx + a0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (a0 + k < mx && j0 + tx < my) {
+            double2 v = tile[tx][k];
+            v.x *= al;
+            v.y *= al;
+            double2 *dst = out + (size_t)(a0 + k) * my + j0 + tx;
+            if (accumulate) {
+                v.x += dst->x;
+                v.y += dst->y;
+            }
+            *dst = v;
+        }
+}
+
 struct ProjArgs {
     const double2 *Nx, *Ny, *Lx, *Ly;   // each [mx][my]
     const double *ux, *uy;
@@ -240,6 +289,97 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
     return ML_OK;
 }
 
+// Stage 2 can be folded the same way when ux is centre-symmetric; its tables depend on
+// which aperture rows are resident and are built in the transform call.
+static int plan_fold2(ml_ctx *ctx, const double *ux) {
+    FarfieldPlan &pl = ctx->plan;
+    pl.fold2 = false;
+    static const bool disabled = [] {
+        const char *e = getenv("ML_NO_FOLD2");
+        return e && atoi(e) != 0;
+    }();
+    if (disabled || pl.pair_list || pl.mx < 2 || pl.nx_total < 2) return ML_OK;
+    const int mx = pl.mx, S = (mx + 1) / 2;
+    const long double kappa = (long double)pl.n_glass / (long double)pl.wavelength;
+    const long double p_max = 0.5L * (pl.nx_total - 1) * fabsl((long double)pl.dxp);
+    const long double uc = 0.5L * ((long double)ux[0] + (long double)ux[mx - 1]);
+    std::vector<double> v(2 * (size_t)S + 2);
+    long double worst = 0;
+    for (int s = 0; s < S; ++s) {
+        const long double up = ux[mx - 1 - s], um = ux[s];
+        worst = fmaxl(worst, fabsl(0.5L * (up + um) - uc));
+        const long double vs = 0.5L * (up - um);
+        v[s] = (double)vs;
+        v[S + s] = (double)(vs - (long double)v[s]);
+    }
+    if (2 * M_PIl * kappa * p_max * worst > 1e-13L) return ML_OK;
+    v[2 * (size_t)S] = (double)uc;
+    v[2 * (size_t)S + 1] = (double)(uc - (long double)v[2 * (size_t)S]);
+    ML_TRY(upload_if_changed(ctx, pl.fold2_v, pl.h_fold2_v, v.data(), v.size()));
+    pl.fold2 = true;
+    pl.fold2_S = S;
+    pl.fold2_has_E = (uc != 0);
+    return ML_OK;
+}
+
+// Folded stage 2 for a mirror-symmetric set of resident rows: local row k pairs with local
+// row nxl-1-k, pair t sits at +/-(half_x - row0 - t) dx.  G is transposed so that the
+// reduction index is contiguous, run through the same folded kernel as stage 1 (rows = 4*my
+// stage-1 columns, "directions" = ux), and transposed back with the signs applied.
+static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, const double *alpha) {
+    FarfieldPlan &pl = ctx->plan;
+    const int nxl = ctx->nx, mx = pl.mx, my = pl.my, S = pl.fold2_S, T = (nxl + 1) / 2;
+    const size_t g_elems = (size_t)4 * nxl * my;
+    ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
+    ML_TRY(pl.fold2_ot.reserve((size_t)4 * my * mx * 2 * sizeof(double)));
+    ML_TRY(pl.fold2_cm.reserve((size_t)T * S * sizeof(double)));
+    ML_TRY(pl.fold2_sm.reserve((size_t)T * S * sizeof(double)));
+    ML_TRY(pl.fold2_r4.reserve((size_t)S * 2 * sizeof(double)));
+    ML_TRY(pl.fold2_E.reserve((size_t)nxl * 2 * sizeof(double)));
+    ML_TRY(pl.fold2_D.reserve((size_t)mx * 2 * sizeof(double)));
+    const long double sl = (long double)pl.n_glass / (long double)pl.wavelength * (long double)pl.dxp;
+    const double s_hi = (double)sl, s_lo = (double)(sl - (long double)s_hi);
+    const double half = 0.5 * (pl.nx_total - 1);
+    const double *v_hi = pl.fold2_v.as<double>(), *v_lo = v_hi + S, *uc = v_hi + 2 * (size_t)S;
+    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, T), dim3(256), 0, ctx->stream,
+                       (double2 *)nullptr, pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), T, S,
+                       1, half - row0, -1.0, s_hi, s_lo, v_hi, v_lo);
+    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, 1), dim3(256), 0, ctx->stream,
+                       (double2 *)nullptr, pl.fold2_r4.as<double>(), pl.fold2_r4.as<double>() + S, 1,
+                       S, 1, 4.0, 0.0, s_hi, s_lo, v_hi, v_lo);
+    if (pl.fold2_has_E) {
+        // E_k = exp(-i kappa p_k u_c) at the resident rows: one run, or two for a mirrored shard
+        const int h = mirrored ? nxl / 2 : nxl;
+        hipLaunchKernelGGL(phase_table_kernel, dim3((h + 255) / 256, 1), dim3(256), 0, ctx->stream,
+                           pl.fold2_E.as<double2>(), (double *)nullptr, (double *)nullptr, 1, h, 0,
+                           row0 - half, 1.0, s_hi, s_lo, uc, uc + 1);
+        if (mirrored)
+            hipLaunchKernelGGL(phase_table_kernel, dim3((h + 255) / 256, 1), dim3(256), 0,
+                               ctx->stream, pl.fold2_E.as<double2>() + h, (double *)nullptr,
+                               (double *)nullptr, 1, h, 0,
+                               (double)(pl.nx_total - row0 - h) - half, 1.0, s_hi, s_lo, uc, uc + 1);
+    }
+    const double delta = half - (double)(pl.nx_total - pl.nx_total / 2);
+    hipLaunchKernelGGL(phase_table_kernel, dim3((mx + 255) / 256, 1), dim3(256), 0, ctx->stream,
+                       pl.fold2_D.as<double2>(), (double *)nullptr, (double *)nullptr, 1, mx, 1,
+                       delta, 0.0, s_hi, s_lo, pl.ux.as<double>(), (const double *)nullptr);
+    // G[(f, n1)][j] -> GT[(f, j)][n1]
+    hipLaunchKernelGGL(ztranspose_kernel, dim3((my + 31) / 32, (nxl + 31) / 32, 4), dim3(256), 0,
+                       ctx->stream, pl.stage1.as<double2>(), pl.fold2_gt.as<double2>(), nxl, my);
+    ML_HIP(hipGetLastError());
+    ML_TRY(zfold_stage1(ctx->stream, 4 * my, nxl, pl.fold2_gt.as<double>(), nxl,
+                        pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), pl.fold2_r4.as<double>(),
+                        T, S, pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr,
+                        pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx));
+    Alpha4f al;
+    for (int k = 0; k < 4; ++k) al.v[k] = alpha[k];
+    hipLaunchKernelGGL(zunfold_out_kernel, dim3((mx + 31) / 32, (my + 31) / 32, 4), dim3(256), 0,
+                       ctx->stream, pl.fold2_ot.as<double2>(), pl.vectors.as<double2>(), my, mx, al,
+                       accumulate);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
 static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id) {
     ProfScope scope(ctx, kernel_id);
     hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0, ctx->stream,
@@ -297,11 +437,12 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     else
         ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), mx, nx_total, 0, nx_total, dxp, wavelength,
                               n_glass, pl.ux.as<double>()));
+    ML_TRY(plan_fold2(ctx, ux));
     pl.ready = true;
     return ML_OK;
 }
 
-int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
+static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready) {
@@ -314,9 +455,16 @@ int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
     }
     ML_REQUIRE(ctx->ny == pl.ny, "resident fields have ny=%d but the plan has ny=%d", ctx->ny,
                pl.ny);
-    ML_REQUIRE(row0 >= 0 && row0 + ctx->nx <= pl.nx_total,
-               "rows [%d, %d) fall outside the planned aperture of %d rows", row0,
-               row0 + ctx->nx, pl.nx_total);
+    if (mirrored) {
+        ML_REQUIRE(ctx->nx % 2 == 0 && row0 >= 0 && 2 * row0 + ctx->nx <= pl.nx_total,
+                   "mirrored shard: %d resident rows starting at %d do not form row pairs of a "
+                   "%d-row aperture", ctx->nx, row0, pl.nx_total);
+        ML_REQUIRE(!pl.pair_list, "mirrored shards are for tensor grids");
+    } else {
+        ML_REQUIRE(row0 >= 0 && row0 + ctx->nx <= pl.nx_total,
+                   "rows [%d, %d) fall outside the planned aperture of %d rows", row0,
+                   row0 + ctx->nx, pl.nx_total);
+    }
     ML_REQUIRE(!accumulate || pl.have_vectors, "accumulate requested but nothing to add to");
     ML_HIP(hipSetDevice(ctx->device));
     const int nxl = ctx->nx, ny = pl.ny, mx = pl.mx, my = pl.my;
@@ -338,7 +486,26 @@ int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
     const double dA = pl.dxp * pl.dyp;
     // fields are stored Ex,Ey,Hx,Hy; radiation vectors Nx,Ny,Lx,Ly = -Hy, Hx, Ey, -Ex (x dA)
     const double alpha[4] = {-dA, dA, dA, -dA};
-    if (!pl.pair_list) {
+    const bool whole = (row0 == 0 && nxl == pl.nx_total);
+    // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
+    // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
+    const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= 256;
+    if (!pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole)) {
+        ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha));
+    } else if (!pl.pair_list && mirrored) {
+        // generic stage 2 on the two runs of a mirrored shard
+        ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        const int h = nxl / 2;
+        double *slot3 = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
+        for (int run = 0; run < 2; ++run) {
+            const int first = run == 0 ? row0 : pl.nx_total - row0 - h;
+            ML_TRY(zgemm(ctx->stream, mx, my, h, alpha, pl.tw_x.as<double>() + (size_t)first * 2,
+                         pl.nx_total, 0, pl.stage1.as<double>() + (size_t)run * h * my * 2, my,
+                         (int64_t)nxl * my, slot3, my, -(int64_t)mx * my, 4,
+                         run == 0 ? accumulate : 1));
+        }
+    } else if (!pl.pair_list) {
         // stage 2: V_f[a][b] = alpha_f * sum_n1 exp(-i k x'_n1 ux_a) * G[(f, n1)][b];
         // batch entry f writes radiation-vector slot 3 - f
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
@@ -355,8 +522,22 @@ int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
     return ML_OK;
 }
 
+int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
+    return transform_impl(ctx, row0, 0, accumulate);
+}
+
+int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate) {
+    return transform_impl(ctx, row0, 1, accumulate);
+}
+
 int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate) {
-    ML_TRY(ml_farfield_transform_async(ctx, row0, accumulate));
+    ML_TRY(transform_impl(ctx, row0, 0, accumulate));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    return prof_harvest(ctx);
+}
+
+int ml_farfield_transform_mirrored(ml_ctx *ctx, int row0, int accumulate) {
+    ML_TRY(transform_impl(ctx, row0, 1, accumulate));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return prof_harvest(ctx);
 }

@@ -45,6 +45,21 @@ def row_block(n_rows, world, rank, align=16):
     return edges[rank], edges[rank + 1]
 
 
+def mirrored_block(n_rows, world, rank, align=8):
+    """Mirror-symmetric shard of an aperture with an EVEN number of rows: rank ``rank`` owns
+    the row pairs q in [q0, q1), i.e. rows [q0, q1) and [n_rows-q1, n_rows-q0).  Every rank
+    then holds both members of each +/-x' pair, which lets BOTH far-field stages run folded
+    (csrc/zfold.hip).  Returns (q0, q1)."""
+    assert n_rows % 2 == 0
+    return row_block(n_rows // 2, world, rank, align=align)
+
+
+def mirrored_rows(n_rows, q0, q1):
+    """row indices of the shard (q0, q1), in resident order"""
+    import numpy as np
+    return np.concatenate((np.arange(q0, q1), np.arange(n_rows - q1, n_rows - q0)))
+
+
 def _id_path():
     key = '%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'),
                         os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())

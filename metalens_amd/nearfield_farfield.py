@@ -93,9 +93,13 @@ class FarfieldTransform:
             self.ctx.handle, num_x_total, num_y, dxp, dyp, wavelength, n_glass,
             _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy), self.uy.size, int(pair_list)))
 
-    def transform(self, row0=0, accumulate=False):
-        """radiation vectors of the resident field rows (a partial sum if sharded)"""
-        _lib.check(self.ctx.lib.ml_farfield_transform(self.ctx.handle, row0, int(accumulate)))
+    def transform(self, row0=0, accumulate=False, mirrored=False):
+        """radiation vectors of the resident field rows (a partial sum if sharded).
+        ``mirrored``: the resident rows are the pairs [row0, row0+h) + [N-row0-h, N-row0)
+        (see dist.mirrored_rows) instead of the contiguous block [row0, row0+rows)."""
+        fn = (self.ctx.lib.ml_farfield_transform_mirrored if mirrored
+              else self.ctx.lib.ml_farfield_transform)
+        _lib.check(fn(self.ctx.handle, row0, int(accumulate)))
 
     def allreduce(self):
         _lib.check(self.ctx.lib.ml_farfield_allreduce(self.ctx.handle))

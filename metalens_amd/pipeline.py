@@ -39,8 +39,16 @@ class HotPath:
                                        n_glass, dipole_moment, self.c0, self.Z0)
         self.x_all = _lib.f64(x_pts)
         self.y = _lib.f64(y_pts)
-        self.row0, self.row1 = dist.row_block(self.x_all.size, world, rank)
-        self.x_local = np.ascontiguousarray(self.x_all[self.row0:self.row1])
+        # rows of this rank: mirrored row pairs when the aperture has an even number of rows
+        # (both far-field stages fold), one contiguous block otherwise
+        self.mirrored = world > 1 and self.x_all.size % 2 == 0
+        if self.mirrored:
+            self.row0, self.row1 = dist.mirrored_block(self.x_all.size, world, rank)
+            self.rows = dist.mirrored_rows(self.x_all.size, self.row0, self.row1)
+        else:
+            self.row0, self.row1 = dist.row_block(self.x_all.size, world, rank)
+            self.rows = np.arange(self.row0, self.row1)
+        self.x_local = np.ascontiguousarray(self.x_all[self.rows])
         self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
         self.pair_list = bool(pair_list)
         self.shape = (self.ux.size,) if pair_list else (self.ux.size, self.uy.size)
@@ -58,7 +66,10 @@ class HotPath:
             _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(self.params),
                                               _lib.dptr(self.x_local), self.x_local.size,
                                               _lib.dptr(self.y), self.y.size))
-            _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
+            if self.mirrored:
+                _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
+            else:
+                _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
         if self.world > 1 or dist.force_rccl():
             _lib.check(lib.ml_farfield_allreduce(ctx.handle))
         _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))

@@ -125,7 +125,11 @@ def radiation_vectors(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux,
     dyp = yp_list[1] - yp_list[0]
     A = axis_twiddles(len(xp_list), dxp, ux, wavelength, n_glass)
     if row_range is not None:
-        A = A[:, row_range[0]:row_range[1]]
+        # (r0, r1) = a contiguous block; an index array = any subset of rows (mirrored shards)
+        if len(row_range) == 2 and np.ndim(row_range[0]) == 0:
+            A = A[:, row_range[0]:row_range[1]]
+        else:
+            A = A[:, np.asarray(row_range)]
     B = axis_twiddles(len(yp_list), dyp, uy, wavelength, n_glass)
     dA = dxp * dyp
 

@@ -13,6 +13,17 @@ import golden_io
 from metalens_amd import dist
 
 
+def test_mirrored_blocks_cover_everything():
+    for n in (16, 400, 2048, 5792):
+        for world in (1, 2, 3, 8):
+            seen = np.concatenate([dist.mirrored_rows(n, *dist.mirrored_block(n, world, r))
+                                   for r in range(world)])
+            assert np.array_equal(np.sort(seen), np.arange(n))
+            for r in range(world):
+                rows = dist.mirrored_rows(n, *dist.mirrored_block(n, world, r))
+                assert np.array_equal(rows + rows[::-1], np.full(rows.size, n - 1))
+
+
 def test_row_block_partitions_cover_everything():
     for n in (1, 15, 16, 400, 2048, 2897, 8192):
         for world in (1, 2, 3, 4, 8):
@@ -45,15 +56,22 @@ def _worker(rank, world, port, out_dir):
     lens = golden_io.load_lens(golden_io.golden_path(str(case['lens'])))
     x, y = case['x_pts'], case['y_pts']
     wl = float(case['wavelength'])
-    r0, r1 = dist.row_block(len(x), world, rank, align=4)
-    Ex, Ey, Hx, Hy, _, _, power, n_glass = nearfield_oracle.build_nearfield(
+    # the decomposition HotPath uses for N > 1: mirrored row pairs per rank
+    q0, q1 = dist.mirrored_block(len(x), world, rank, align=2)
+    rows = dist.mirrored_rows(len(x), q0, q1)
+    # (the near-field oracle checks that x_pts is uniform, so feed it the two runs separately)
+    h = q1 - q0
+    parts = [nearfield_oracle.build_nearfield(
         float(case['source_x']), float(case['source_y']), float(case['source_z']),
-        str(case['source_pol']), wl, lens[0], lens[1], lens[2], x_pts=x[r0:r1], y_pts=y,
-        c0=float(case['c0']), Z0=float(case['Z0']))
+        str(case['source_pol']), wl, lens[0], lens[1], lens[2], x_pts=x[run], y_pts=y,
+        c0=float(case['c0']), Z0=float(case['Z0'])) for run in (rows[:h], rows[h:])]
+    Ex, Ey, Hx, Hy = (np.vstack((a, b)) for a, b in zip(parts[0][:4], parts[1][:4]))
+    power = parts[0][6] + parts[1][6]
+    n_glass = parts[0][7]
     ux = np.linspace(-0.3, 0.5, 9)
     uy = np.linspace(-0.2, 0.2, 7)
     part = farfield_oracle.radiation_vectors(Ex, Ey, Hx, Hy, x, y, wl, n_glass, ux, uy,
-                                             row_range=(r0, r1))
+                                             row_range=rows)
     # RCCL has no complex type: reduce as float64 pairs, exactly like ml_farfield_allreduce
     buf = torch.from_numpy(np.stack(part).view(np.float64).copy())
     td.all_reduce(buf, op=td.ReduceOp.SUM)

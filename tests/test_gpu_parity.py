@@ -160,7 +160,7 @@ def test_direct_transform_on_fft_lattice_golden(ma):
 
 @pytest.mark.parametrize('shape', [(48, 40, 37, 29), (130, 70, 65, 130), (64, 64, 64, 64),
                                    (17, 200, 5, 3), (33, 45, 12, 18), (21, 131, 7, 131),
-                                   (40, 257, 9, 2)])
+                                   (40, 257, 9, 2), (45, 33, 18, 12), (131, 21, 131, 7)])
 def test_direct_transform_vs_oracle_ragged(ma, shape):
     """off-lattice directions, sizes that are not multiples of any tile"""
     from oracle import farfield_oracle
@@ -249,6 +249,36 @@ def test_sharded_rows_sum_to_whole(ma):
     got = t.radiation_vectors()
     for key in ('Nx', 'Ny', 'Lx', 'Ly'):
         assert np.abs(got[key] - whole[key]).max() <= 1e-13 * np.abs(whole[key]).max(), key
+
+
+@pytest.mark.parametrize('nx,ny,mx,my', [(96, 80, 34, 47), (64, 50, 33, 20), (130, 66, 7, 64),
+                                         (64, 2100, 520, 2100)])
+def test_mirrored_shards_sum_to_whole(ma, nx, ny, mx, my):
+    """the multi-GPU decomposition used by HotPath: each rank holds mirrored row pairs so that
+    BOTH stages run folded; accumulating the shards must reproduce the unsharded transform and
+    the oracle"""
+    from metalens_amd import _lib, dist
+    from oracle import farfield_oracle
+    rng = np.random.default_rng(nx)
+    F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+    wl, n = 580e-9, 1.459
+    x = np.arange(nx) * (wl / 2.2)
+    y = np.arange(ny) * (wl / 2.2)
+    ux = np.linspace(-0.45, 0.35, mx)
+    uy = np.linspace(-0.5, 0.3, my)
+    want = farfield_oracle.radiation_vectors(*F, x, y, wl, n, ux, uy)
+    ctx = _lib.default_context()
+    t = ma.FarfieldTransform(nx, ny, x[1] - x[0], y[1] - y[0], wl, n, ux, uy, ctx=ctx)
+    world = 3
+    for rank in range(world):
+        q0, q1 = dist.mirrored_block(nx, world, rank, align=2)
+        rows = dist.mirrored_rows(nx, q0, q1)
+        part = [np.ascontiguousarray(f[rows]) for f in F]
+        _lib.check(ctx.lib.ml_fields_upload(ctx.handle, len(rows), ny, *[_lib.dptr(a) for a in part]))
+        t.transform(row0=q0, accumulate=rank > 0, mirrored=True)
+    got = t.radiation_vectors()
+    for key, w in zip(('Nx', 'Ny', 'Lx', 'Ly'), want):
+        assert np.abs(got[key] - w).max() <= TOL * np.abs(w).max(), key
 
 
 def test_rccl_path_single_rank():
