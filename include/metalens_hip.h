@@ -80,11 +80,16 @@ int ml_upload_table(ml_ctx *ctx, int slot,
  *   sector*dphi (nearfield.py:169-171), evaluated by the HOST's NumPy so that the
  *   rotation enters the large phases bit-identically to the reference on that host;
  *   ring_rot_center[r] is the table index of sector 0 for ring r and ring_rot_half[r]
- *   the largest |sector| tabulated.                                                     */
+ *   the largest |sector| tabulated (entries run from sector -half-1 to +half).
+ *   tie_table[rot_len][6]: for the sector boundary (k + 1/2)*dphi stored at the index of
+ *   sector k: the angle, its cosine and its sine, each as (hi, lo) float64 pairs from an
+ *   extended-precision evaluation; used to settle round(arctan2(y,x)/dphi) for samples
+ *   that sit within 1e-9 of a tie (samples on the diagonals of a symmetric grid).       */
 int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *ring_boundaries,
                      const double *ring_r_center, const double *ring_period,
                      const double *ring_dphi, const double *ring_lateral,
-                     const int32_t *ring_gc, const double *rot_table, int rot_len,
+                     const int32_t *ring_gc, const double *rot_table,
+                     const double *tie_table, int rot_len,
                      const int32_t *ring_rot_center, const int32_t *ring_rot_half,
                      int n_cells, const double *cells);
 

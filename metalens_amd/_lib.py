@@ -77,8 +77,8 @@ def load():
     lib.ml_device_info.argtypes = [c_void_p, c_char_p, c_int, POINTER(c_int), POINTER(c_int64)]
     lib.ml_upload_table.argtypes = [c_void_p, c_int, _dp, c_int, _dp, c_int, _dp, c_int, _ip, _dp,
                                     c_int, _dp, _dp, _dp]
-    lib.ml_upload_layout.argtypes = [c_void_p, c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, c_int, _ip,
-                                     _ip, c_int, _dp]
+    lib.ml_upload_layout.argtypes = [c_void_p, c_int, _dp, _dp, _dp, _dp, _dp, _ip, _dp, _dp, c_int,
+                                     _ip, _ip, c_int, _dp]
     lib.ml_nearfield.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int, _dp,
                                  POINTER(BoundViolation), c_int, POINTER(c_int)]
     lib.ml_nearfield_async.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int]

@@ -220,7 +220,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
                       &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
-                      &ctx->ring_ok_off, &ctx->rot_table, &ctx->ring_rot_center,
+                      &ctx->ring_ok_off, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
@@ -294,16 +294,17 @@ int ml_upload_table(ml_ctx *ctx, int slot, const double *axis0, int n0, const do
 
 int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_center,
                      const double *period, const double *dphi, const double *lateral,
-                     const int32_t *ring_gc, const double *rot_table, int rot_len,
+                     const int32_t *ring_gc, const double *rot_table, const double *tie_table,
+                     int rot_len,
                      const int32_t *ring_rot_center, const int32_t *ring_rot_half, int n_cells,
                      const double *cells) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_REQUIRE(n_rings >= 1 && B && r_center && period && dphi && lateral && ring_gc,
                "ring arrays missing (n_rings=%d)", n_rings);
-    ML_REQUIRE(rot_table && rot_len >= 1 && ring_rot_center && ring_rot_half,
+    ML_REQUIRE(rot_table && tie_table && rot_len >= 1 && ring_rot_center && ring_rot_half,
                "rotation table missing");
     for (int r = 0; r < n_rings; ++r)
-        ML_REQUIRE(ring_rot_half[r] >= 0 && ring_rot_center[r] - ring_rot_half[r] >= 0 &&
+        ML_REQUIRE(ring_rot_half[r] >= 0 && ring_rot_center[r] - ring_rot_half[r] - 1 >= 0 &&
                        ring_rot_center[r] + ring_rot_half[r] < rot_len,
                    "rotation table range of ring %d falls outside the table", r);
     ML_REQUIRE(n_cells >= 0 && (n_cells == 0 || cells), "cell array missing");
@@ -319,6 +320,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     ML_TRY(h2d(ctx, ctx->ring_lateral, lateral, n_rings * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_gc, ring_gc, n_rings * sizeof(int32_t)));
     ML_TRY(h2d(ctx, ctx->rot_table, rot_table, (size_t)rot_len * 2 * sizeof(double)));
+    ML_TRY(h2d(ctx, ctx->tie_table, tie_table, (size_t)rot_len * 6 * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_rot_center, ring_rot_center, n_rings * sizeof(int32_t)));
     ML_TRY(h2d(ctx, ctx->ring_rot_half, ring_rot_half, n_rings * sizeof(int32_t)));
     ctx->h_ring_period.assign(period, period + n_rings);

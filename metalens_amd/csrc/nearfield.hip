@@ -128,11 +128,8 @@ __global__ __launch_bounds__(256) void nearfield_exact_kernel(const NfArgs a) {
                 const double period = a.period[ring], dphi = a.dphi[ring];
                 const double rcen = a.rc[ring], lateral = a.lateral[ring];
                 // ---- sector and local frame (nearfield.py:169,195-201)
-                const double phi = atan2(y, x);
                 // cos / sin of the grating rotation sector*dphi come from the host's table
-                int sector = (int)rint(phi / dphi);
-                const int half = a.rot_half[ring];
-                sector = min(max(sector, -half), half);
+                const int sector = sector_of(a, ring, x, y, dphi);
                 const double2 cs = a.rot_table[a.rot_center[ring] + sector];
                 const double cosr = cs.x, sinr = cs.y;
                 const double uxp = ux * cosr + uy * sinr;
@@ -255,6 +252,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.rot_center = ctx->ring_rot_center.as<int>();
     a.rot_half = ctx->ring_rot_half.as<int>();
     a.rot_table = ctx->rot_table.as<double2>();
+    a.tie_table = ctx->tie_table.as<double>();
     a.lut_buckets = ctx->lut_buckets;
     a.lut_inv_h = ctx->lut_inv_h;
     a.n_cells = ctx->n_cells;

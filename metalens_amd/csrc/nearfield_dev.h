@@ -22,6 +22,7 @@ struct NfArgs {
     const double *B, *rc, *period, *dphi, *lateral, *ring_t2;
     const int *gc, *ring_i2, *lut, *rot_center, *rot_half;
     const double2 *rot_table;
+    const double *tie_table;   // [rot_len][6]: boundary angle, cos, sin as (hi, lo) pairs
     int lut_buckets;
     double lut_inv_h;
     // centre cells
@@ -109,6 +110,32 @@ __device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y)
     return best_slot;
 }
 
+
+// Sector of a sample: round(arctan2(y, x) / dphi) (nearfield.py:119,169), clamped to the
+// tabulated range.  If phi / dphi comes within 1e-9 of a tie the decision would hang on the
+// last bit of atan2 (samples on or one ulp off the diagonals of a symmetric grid do this when
+// num_around_circle = 4 mod 8), so phi is then recomputed to ~1e-19 about the boundary angle
+// theta = (k + 1/2) dphi from the host's extended-precision table,
+//   phi = theta + atan((y cos theta - x sin theta) / (x cos theta + y sin theta)),
+// and rounded: the correctly rounded arctan2, which is what NumPy returns on these arguments.
+__device__ __forceinline__ int sector_of(const NfArgs &a, int ring, double x, double y,
+                                         double dphi) {
+    const int half = a.rot_half[ring];
+    double q = atan2(y, x) / dphi;
+    const double fl = floor(q);
+    if (fabs((q - fl) - 0.5) < 1e-9) {
+        const int k = min(max((int)fl, -half - 1), half);
+        const double *e = a.tie_table + (size_t)(a.rot_center[ring] + k) * 6;
+        const double th_hi = e[0], th_lo = e[1], c_hi = e[2], c_lo = e[3], s_hi = e[4], s_lo = e[5];
+        const double p1 = y * c_hi, e1 = fma(y, c_hi, -p1);
+        const double p2 = x * s_hi, e2 = fma(x, s_hi, -p2);
+        const double num = (p1 - p2) + ((e1 - e2) + (y * c_lo - x * s_lo));
+        const double den = x * c_hi + y * s_hi;
+        const double phi = th_hi + (th_lo + num / den);
+        q = phi / dphi;
+    }
+    return min(max((int)rint(q), -half), half);
+}
 
 // which ring: number of ring boundaries strictly below r, i.e.
 // searchsorted(boundaries, r, 'left') (nearfield.py:125-128), through the uniform-in-r LUT

@@ -19,6 +19,8 @@
 //       Ex += Z0 g (kx ky U_fy + (ky^2+kz^2) U_fx) ph ; Ey += Z0 g (-(kx^2+kz^2) U_fy - kx ky U_fx) ph
 //     with g = 1/(k_glass kz n_glass)  (nearfield.py:313-327 rearranged);
 //   * use one reciprocal per sample and a branch-free Cody-Waite sin/cos.
+#include <cstdlib>
+
 #include "nearfield_dev.h"
 
 namespace ml {
@@ -108,7 +110,8 @@ __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int 
     acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
 }
 
-__global__ __launch_bounds__(256) void nearfield_fast_kernel(const NfArgs a) {
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs a) {
     // Thread -> sample map: each wave covers an 8 x 8 patch of the aperture (not a 64 x 1
     // line), so its lanes fall into 2-3 rings instead of ~10 and the table gathers of one
     // wave instruction touch few distinct cache lines (measured: -20 % at 4096^2).  The four
@@ -156,9 +159,7 @@ __global__ __launch_bounds__(256) void nearfield_fast_kernel(const NfArgs a) {
                 const TableDesc &T = a.tables[slot];
                 const double dphi = a.dphi[ring], rcen = a.rc[ring];
                 // sector decision: exact (nearfield.py:169)
-                int sector = (int)rint(atan2(y, x) / dphi);
-                const int half = a.rot_half[ring];
-                sector = min(max(sector, -half), half);
+                const int sector = sector_of(a, ring, x, y, dphi);
                 const double2 cs = a.rot_table[a.rot_center[ring] + sector];
                 const double cosr = cs.x, sinr = cs.y;
                 // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
@@ -253,7 +254,16 @@ __global__ __launch_bounds__(256) void nearfield_fast_kernel(const NfArgs a) {
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     const dim3 grid((a.ny + 31) / 32, (a.nx + 7) / 8);
     *n_partials = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL(nearfield_fast_kernel, grid, dim3(256), 0, ctx->stream, a);
+    static const int waves = [] {
+        const char *e = getenv("ML_NF_WAVES");
+        return e ? atoi(e) : 3;
+    }();
+    if (waves == 4)
+        hipLaunchKernelGGL(nearfield_fast_kernel<4>, grid, dim3(256), 0, ctx->stream, a);
+    else if (waves == 5)
+        hipLaunchKernelGGL(nearfield_fast_kernel<5>, grid, dim3(256), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(nearfield_fast_kernel<3>, grid, dim3(256), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

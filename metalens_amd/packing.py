@@ -104,24 +104,40 @@ def pack_layout(lens_periphery_summary, lens_center_summary):
     # run of the table per distinct dphi.  Evaluated HERE with NumPy - not on the GPU - because
     # the rotation multiplies lens-sized coordinates inside phases of ~1e4 rad: one ulp of
     # cos/sin is ~1e-12 rad of phase, and this way it is the same ulp the reference gets.
+    #
+    # The sector itself is round(arctan2(y, x) / dphi).  A symmetric sample grid puts samples on
+    # (or one ulp off) the diagonals, where phi / dphi can be an exact tie, and then the decision
+    # hangs on the last bit of arctan2.  For such near-tie samples the kernel recomputes phi to
+    # ~1e-19 from the boundary angle (k + 1/2) * dphi, whose value, cosine and sine are tabulated
+    # here in extended precision, and rounds it - i.e. it uses the correctly rounded arctan2,
+    # which is what NumPy returns on these arguments.
     rot_center = np.zeros(r_center.size, dtype=np.int32)
     rot_half = np.zeros(r_center.size, dtype=np.int32)
-    runs, at = [], 0
+    runs, ties, at = [], [], 0
     for value in np.unique(dphi):
         half = int(np.ceil(pi / value)) + 1
-        sector = np.arange(-half, half + 1, dtype=np.float64)
+        sector = np.arange(-half - 1, half + 1, dtype=np.float64)   # entry k: sector k
         rot = sector * value
         runs.append(np.column_stack((np.cos(rot), np.sin(rot))))
-        rot_center[dphi == value] = at + half
+        b = (sector.astype(np.longdouble) + np.longdouble(0.5)) * np.longdouble(value)
+        tie = np.empty((sector.size, 6))                            # entry k: boundary k + 1/2
+        for col, ext in enumerate((b, np.cos(b), np.sin(b))):
+            hi = ext.astype(np.float64)
+            tie[:, 2 * col] = hi
+            tie[:, 2 * col + 1] = (ext - hi.astype(np.longdouble)).astype(np.float64)
+        ties.append(tie)
+        rot_center[dphi == value] = at + half + 1
         rot_half[dphi == value] = half
-        at += 2 * half + 1
+        at += sector.size
     rot_table = np.ascontiguousarray(np.vstack(runs))
+    tie_table = np.ascontiguousarray(np.vstack(ties))
     if lens_center_summary is None or len(lens_center_summary) == 0:
         cells = np.zeros((0, 3))
     else:
         cells = _lib.f64(np.asarray(lens_center_summary)[:, 0:3])
     return {'boundaries': boundaries, 'r_center': r_center, 'period': period, 'dphi': dphi,
             'lateral': lateral, 'ring_gc': ring_gc, 'cells': cells, 'rot_table': rot_table,
+            'tie_table': tie_table,
             'rot_center': rot_center, 'rot_half': rot_half}
 
 
@@ -137,7 +153,8 @@ def upload_layout(ctx, lens_periphery_summary, lens_center_summary):
     _lib.check(ctx.lib.ml_upload_layout(
         ctx.handle, n_rings, _lib.dptr(L['boundaries']), _lib.dptr(L['r_center']),
         _lib.dptr(L['period']), _lib.dptr(L['dphi']), _lib.dptr(L['lateral']),
-        _lib.iptr(L['ring_gc']), _lib.dptr(L['rot_table']), len(L['rot_table']),
+        _lib.iptr(L['ring_gc']), _lib.dptr(L['rot_table']), _lib.dptr(L['tie_table']),
+        len(L['rot_table']),
         _lib.iptr(L['rot_center']), _lib.iptr(L['rot_half']), len(L['cells']),
         _lib.dptr(L['cells']) if len(L['cells']) else None))
     ctx.layout_token = token

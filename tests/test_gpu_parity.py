@@ -281,6 +281,68 @@ def test_mirrored_shards_sum_to_whole(ma, nx, ny, mx, my):
         assert np.abs(got[key] - w).max() <= TOL * np.abs(w).max(), key
 
 
+def _synthetic_lens(radius, na, wavelength, n_glass=0, switch_deg=12.0):
+    import math
+    import metalens_amd as ma_
+    from metalens_amd import layout, synthetic
+    return synthetic.make_lens((ma_.Grating, ma_.GratingCollection, ma_.HexGridSet),
+                               layout.make_design, radius=radius, numerical_aperture=na,
+                               wavelength=wavelength, switch_angle=switch_deg * math.pi / 180,
+                               n_glass=n_glass, num_gratings=20, num_entries=12,
+                               design_kwargs={'wavelength': wavelength})
+
+
+@pytest.mark.parametrize('pol', ['x', 'y'])
+def test_paper_lens_na094_windows_vs_oracle(ma, pol):
+    """BASELINE config 3's lens (2 mm diameter, NA 0.94, TE+TM = x and y dipoles run
+    separately): ~1200 rings, outer collections at grazing angles.  Windows at the lens edge
+    and at mid radius against the CPU oracle."""
+    import math
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens = _synthetic_lens(1e-3, 0.94, wl)
+    assert len(lens['lens_periphery_summary']['r_center_list']) > 1000
+    pitch = wl / 2.2
+    for cx, cy in ((0.99e-3 * math.cos(0.3), 0.99e-3 * math.sin(0.3)), (-0.5e-3, 0.35e-3)):
+        x = cx + (np.arange(72) - 35.5) * pitch
+        y = cy + (np.arange(56) - 27.5) * pitch
+        args = dict(source_x=0.0, source_y=0.0, source_z=-lens['source_distance'], source_pol=pol,
+                    wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                    lens_center_summary=lens['lens_center_summary'][:64],
+                    hexgridset=lens['hexgridset'], x_pts=x, y_pts=y)
+        got = ma.build_nearfield(**args)
+        want = nearfield_oracle.build_nearfield(**args)
+        scale = max(np.abs(w).max() for w in want[:4])
+        assert scale > 0
+        for g, w in zip(got[:4], want[:4]):
+            assert np.count_nonzero((g == 0) != (w == 0)) == 0
+            assert np.abs(g - w).max() <= TOL * scale
+        assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
+
+
+@pytest.mark.parametrize('wl_nm,n_glass', [(450, 0), (532, 1.4607), (635, 1.457)])
+def test_rgb_wavelengths_vs_oracle(ma, wl_nm, n_glass):
+    """BASELINE config 4 (450 / 532 / 635 nm): 532 and 635 nm are not in the reference's glass
+    table (grating.py:1277-1288), so those lenses carry an explicit n_glass"""
+    from oracle import farfield_oracle, nearfield_oracle
+    wl = wl_nm * 1e-9
+    lens = _synthetic_lens(30e-6, 0.4, wl, n_glass=n_glass, switch_deg=9.0)
+    args = dict(source_x=1e-6, source_y=-0.5e-6, source_z=-lens['source_distance'], source_pol='y',
+                wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'])
+    got = ma.build_nearfield(**args)
+    want = nearfield_oracle.build_nearfield(**args)
+    assert got[7] == want[7] == (n_glass or {450: 1.466}[wl_nm])
+    scale = max(np.abs(w).max() for w in want[:4])
+    for g, w in zip(got[:4], want[:4]):
+        assert np.abs(g - w).max() <= TOL * scale
+    u = np.linspace(-0.12, 0.12, 40)
+    ff = ma.farfield_direct(None, None, None, None, got[4], got[5], wl, got[7], u, u)
+    ref = farfield_oracle.farfield_direct(*want[:4], want[4], want[5], wl, want[7], u, u)
+    for k in ('a_theta', 'a_phi'):
+        assert np.abs(ff[k] - ref[k]).max() <= TOL * np.abs(ref[k]).max()
+
+
 def test_rccl_path_single_rank():
     """the multi-GPU code path (RCCL loaded with dlopen, unique-id exchange through /tmp,
     communicator, all-reduce of the radiation vectors, max/sum reductions) run for real with
