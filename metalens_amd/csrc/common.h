@@ -163,7 +163,7 @@ struct ml_ctx {
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     int lut_buckets = 0;
     double lut_inv_h = 0;
-    ml::DevBuf cell_x, cell_y, cell_which, cell_index, bin_start;
+    ml::DevBuf cell_x, cell_y, cell_xy, cell_which, cell_index, bin_start;
     int bins_x = 0, bins_y = 0;
     double bin_x0 = 0, bin_y0 = 0, bin_h = 0;
 

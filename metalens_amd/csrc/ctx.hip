@@ -222,7 +222,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
-                      &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
+                      &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
@@ -385,6 +385,12 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
         }
         ML_TRY(h2d(ctx, ctx->cell_x, sx.data(), n_cells * sizeof(double)));
         ML_TRY(h2d(ctx, ctx->cell_y, sy.data(), n_cells * sizeof(double)));
+        std::vector<double> sxy(2 * (size_t)n_cells);
+        for (int c = 0; c < n_cells; ++c) {
+            sxy[2 * (size_t)c] = sx[c];
+            sxy[2 * (size_t)c + 1] = sy[c];
+        }
+        ML_TRY(h2d(ctx, ctx->cell_xy, sxy.data(), sxy.size() * sizeof(double)));
         ML_TRY(h2d(ctx, ctx->cell_which, sw.data(), n_cells * sizeof(int32_t)));
         ML_TRY(h2d(ctx, ctx->cell_index, si.data(), n_cells * sizeof(int32_t)));
         ML_TRY(h2d(ctx, ctx->bin_start, start.data(), start.size() * sizeof(int32_t)));

@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
             } else if (a.n_cells > 0) {
                 // ================= centre: nearest hexagonal cell =================
                 const TableDesc &T = a.tables[MAX_SLOTS];
-                const int s = nearest_cell(a, x, y);
-                const double ccx = a.cx[s], ccy = a.cy[s];
+                const int s = nearest_cell_fast(a, x, y);
+                const double2 cc = a.cxy[s];
+                const double ccx = cc.x, ccy = cc.y;
                 const int which = min(max(a.cwhich[s], 0), T.n2 - 1);
                 int i0, i1;
                 double t0, t1;
