@@ -193,12 +193,19 @@ def main():
                    'centre_cells': int(len(lens['lens_center_summary'])),
                    'parallelism': 'aperture rows sharded over %d GPU(s), 1 RCCL all-reduce' % world},
     }
-    # ---- roofline of the dominant kernel: stage-1 complex GEMM on the fp64 matrix cores.
-    # algorithmic flops per launch = 8 (complex MAC) x (4 fields x local rows) x ny x my
-    s1 = prof['zgemm_stage1']
+    # ---- rooflines.  `roofline` describes the kernel that takes the most time per step; the
+    # other of the two large kernels goes to `roofline_other`.
+    #  * stage 1 (fp64 matrix cores): algorithmic flops per launch = 8 (complex MAC) x
+    #    (4 fields x local rows) x ny x my            (8 M N^2 per field)
+    #  * near field (HBM): algorithmic bytes per launch = 64 B per sample written (4 complex128)
+    line['kernels_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in prof.items()
+                                   if v['launches']}
     local_rows = hp.x_local.size
-    flops = 8.0 * 4 * local_rows * side * u.size
+    default_cfg = (world == 1 and side == 2048 and u.size == 256)
+    roofs = {}
+    s1 = prof['zgemm_stage1']
     if s1['launches']:
+        flops = 8.0 * 4 * local_rows * side * u.size
         avg_ms = s1['total_ms'] / s1['launches']
         achieved = flops / (avg_ms * 1e-3) / 1e12
         folded = _lib.c_int(0)
@@ -207,22 +214,37 @@ def main():
         # flop per complex (sample, direction) pair (both mirror symmetries), the generic 3M
         # kernel 6, against the 8 of the textbook complex multiply-add that `achieved` counts
         executed = flops * (0.25 if folded.value else 0.75)
-        line['roofline'] = {'bound': 'mfma',
-                            'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
-                            'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
-                            'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
-                            'executed_flops_per_launch': executed,
-                            'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                            'note': 'achieved = algorithmic flops (8 per complex MAC) / time; the '
-                                    'kernel executes executed_flops_per_launch of them, so frac can '
-                                    'exceed 1; mfma_pipe_frac is the matrix-pipe occupancy at 2.4 GHz'}
-    line['kernels_ms_per_step'] = {k: v['total_ms'] / args.steps for k, v in prof.items()
-                                   if v['launches']}
+        roofs['zgemm_stage1'] = {
+            'bound': 'mfma',
+            'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
+            'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
+            # PMC, profiles/r01c_summary.txt: FETCH_SIZE x2 + WRITE_SIZE per launch [bytes]
+            'traffic': 303.5e6 if default_cfg else None,
+            'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
+            'executed_flops_per_launch': executed,
+            'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            'note': 'achieved = algorithmic flops (8 per complex MAC) / time; the kernel executes '
+                    'executed_flops_per_launch of them, so frac can exceed 1; mfma_pipe_frac is '
+                    'the matrix-pipe occupancy at 2.4 GHz'}
     nf = prof['nearfield']
     if nf['launches']:
         nf_bytes = 64.0 * local_rows * side
-        line['nearfield_store_GBs'] = nf_bytes / (nf['total_ms'] / nf['launches'] * 1e-3) / 1e9
+        avg_ms = nf['total_ms'] / nf['launches']
+        achieved = nf_bytes / (avg_ms * 1e-3) / 1e9
+        roofs['nearfield'] = {
+            'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
+            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            # PMC, profiles/r01c_summary.txt: FETCH_SIZE x2 (51.8 MB) + WRITE_SIZE (269.0 MB) per launch
+            'traffic': 320.8e6 if default_cfg else None,
+            'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
+            'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by L1 '
+                    'gather throughput and fp64 VALU work, not by HBM (DESIGN.md 4.1)'}
+    if roofs:
+        order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
+        line['roofline'] = roofs[order[0]]
+        if len(order) > 1:
+            line['roofline_other'] = roofs[order[1]]
     if rel_err is not None:
         line['rel_err'] = rel_err
     if rank == 0 and world == 1 and args.cpu_rows > 0:
