@@ -45,13 +45,30 @@ def row_block(n_rows, world, rank, align=16):
     return edges[rank], edges[rank + 1]
 
 
-def mirrored_block(n_rows, world, rank, align=8):
+def mirrored_block(n_rows, world, rank, align=8, weights=None):
     """Mirror-symmetric shard of an aperture with an EVEN number of rows: rank ``rank`` owns
     the row pairs q in [q0, q1), i.e. rows [q0, q1) and [n_rows-q1, n_rows-q0).  Every rank
     then holds both members of each +/-x' pair, which lets BOTH far-field stages run folded
-    (csrc/zfold.hip).  Returns (q0, q1)."""
+    (csrc/zfold.hip).  Returns (q0, q1).
+
+    ``weights[q]`` (optional, length n_rows/2) is the relative cost of row pair q; the pairs
+    are then split so that every rank gets about the same total cost instead of the same
+    count (rows through the lens centre cost more near-field time than rows at the rim)."""
     assert n_rows % 2 == 0
-    return row_block(n_rows // 2, world, rank, align=align)
+    half = n_rows // 2
+    if weights is None or world == 1:
+        return row_block(half, world, rank, align=align)
+    import numpy as np
+    w = np.asarray(weights, dtype=float)
+    assert w.shape == (half,) and np.all(w > 0)
+    cum = np.concatenate(([0.0], np.cumsum(w)))
+    edges = [0]
+    for k in range(1, world):
+        q = int(np.searchsorted(cum, cum[-1] * k / world))
+        q = int(round(q / align)) * align
+        edges.append(min(max(q, edges[-1]), half))
+    edges.append(half)
+    return edges[rank], edges[rank + 1]
 
 
 def mirrored_rows(n_rows, q0, q1):

@@ -24,6 +24,19 @@ def test_mirrored_blocks_cover_everything():
                 assert np.array_equal(rows + rows[::-1], np.full(rows.size, n - 1))
 
 
+def test_weighted_mirrored_blocks():
+    n, world = 2048, 8
+    x = (np.arange(n // 2) - (n - 1) / 2) * 1.0
+    w = 3.2 + 0.8 * np.minimum(2 * np.sqrt(np.maximum(700.0 ** 2 - x ** 2, 0)) / n, 1.0)
+    blocks = [dist.mirrored_block(n, world, r, weights=w) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n // 2
+    assert all(a[1] == b[0] for a, b in zip(blocks[:-1], blocks[1:]))
+    cost = [w[a:b].sum() for a, b in blocks]
+    assert max(cost) / (sum(cost) / world) < 1.05        # balanced to the 8-row granularity
+    sizes = [b - a for a, b in blocks]
+    assert sizes[0] > sizes[-1]                          # rim ranks get more (cheaper) rows
+
+
 def test_row_block_partitions_cover_everything():
     for n in (1, 15, 16, 400, 2048, 2897, 8192):
         for world in (1, 2, 3, 4, 8):
