@@ -159,7 +159,8 @@ struct ml_ctx {
     ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
     ml::DevBuf rot_table, tie_table, ring_rot_center, ring_rot_half;
     ml::DevBuf ring_i2, ring_t2;
-    ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables     // per-ring location on the table's period axis
+    ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables
+    ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     int lut_buckets = 0;
     double lut_inv_h = 0;

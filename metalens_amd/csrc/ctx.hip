@@ -153,6 +153,24 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     ML_TRY(h2d(ctx, ctx->ring_tab_off, tab_off.data(), tab_off.size() * sizeof(long long)));
     ML_TRY(h2d(ctx, ctx->ring_ok, ok.data(), ok.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_ok_off, ok_off.data(), ok_off.size() * sizeof(int32_t)));
+    // centre table for the fast kernel: [order][n0][n1][4][K] instead of [order][n0][n1][K][4],
+    // so that the K cell types of one amplitude are contiguous (lanes of a wave hold many
+    // different cell types; this way one load instruction touches 3 cache lines, not 12)
+    std::vector<double> cq;
+    if (ctx->center.present) {
+        const TableSlot &t = ctx->center;
+        const size_t nodes = (size_t)t.n_orders * t.n0 * t.n1;
+        cq.resize(nodes * t.n2 * 4 * 2);
+        for (size_t nd = 0; nd < nodes; ++nd)
+            for (int k = 0; k < t.n2; ++k)
+                for (int q = 0; q < 4; ++q) {
+                    const double *src = t.h_values.data() + ((nd * t.n2 + k) * 4 + q) * 2;
+                    double *dst = cq.data() + ((nd * 4 + q) * t.n2 + k) * 2;
+                    dst[0] = src[0];
+                    dst[1] = src[1];
+                }
+        ML_TRY(h2d(ctx, ctx->center_qmajor, cq.data(), cq.size() * sizeof(double)));
+    }
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return ML_OK;
 }
@@ -220,7 +238,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
                       &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
-                      &ctx->ring_ok_off, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
+                      &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,

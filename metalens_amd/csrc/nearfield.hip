@@ -261,6 +261,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.cwhich = ctx->cell_which.as<int>();
     a.cindex = ctx->cell_index.as<int>();
     a.cxy = ctx->cell_xy.as<double2>();
+    a.center_tab = ctx->center_qmajor.as<double2>();
 
     a.bin_start = ctx->bin_start.as<int>();
     a.bins_x = ctx->bins_x;

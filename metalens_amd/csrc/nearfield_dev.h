@@ -29,7 +29,8 @@ struct NfArgs {
     int n_cells;
     const double *cx, *cy;
     const int *cwhich, *cindex, *bin_start;
-    const double2 *cxy;   // (x, y) of the bin-sorted cells, one 16-byte load per candidate
+    const double2 *cxy;
+    const double2 *center_tab;   // centre table re-laid out [order][n0][n1][4][K] (fast kernel)   // (x, y) of the bin-sorted cells, one 16-byte load per candidate
     int bins_x, bins_y;
     double bx0, by0, bh;
     // tables

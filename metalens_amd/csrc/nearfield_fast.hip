@@ -73,8 +73,11 @@ struct Acc {
 };
 
 // one diffraction order: bilinear table read at 4 nodes, both polarisations, phase multiply
+// (`qs` = distance in double2 between the four amplitudes of one node: 1 for the per-ring
+// periphery tables, K for the centre table, which is stored amplitude-major so that lanes
+// with different cell types still read neighbouring addresses)
 __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int stride0,
-                                           int stride1, double t0, double t1, double Hw_x,
+                                           int stride1, int qs, double t0, double t1, double Hw_x,
                                            double Hw_y, double kx, double ky, double kz2,
                                            double k_glass, double inv_n, double Z0, double arg) {
     const double w00 = (1 - t0) * (1 - t1), w01 = (1 - t0) * t1, w10 = t0 * (1 - t1), w11 = t0 * t1;
@@ -85,7 +88,8 @@ __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int 
     const double w[4] = {w00, w01, w10, w11};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const double2 xfy = nodes[c][0], xfx = nodes[c][1], yfy = nodes[c][2], yfx = nodes[c][3];
+        const double2 xfy = nodes[c][0], xfx = nodes[c][qs], yfy = nodes[c][2 * qs],
+                      yfx = nodes[c][3 * qs];
         const double wx = w[c] * Hw_x, wy = w[c] * Hw_y;
         ufy_r = fma(wx, xfy.x, fma(wy, yfy.x, ufy_r));
         ufy_i = fma(wx, xfy.y, fma(wy, yfy.y, ufy_i));
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                     if (kt2 <= p.kvac2) {
                         check_bounds(a, T, slot, o, uxp, uyp, period, true);
                         order_term(pr, tab + o * stride_o + i0 * stride0 + i1 * stride1, stride0,
-                                   stride1, t0, t1, Hw_x, Hw_y, kxp, kyp, p.k_glass2 - kt2,
+                                   stride1, 1, t0, t1, Hw_x, Hw_y, kxp, kyp, p.k_glass2 - kt2,
                                    p.k_glass, inv_n, p.Z0, kxp * xp + kyp * yp);
                     }
                 }
@@ -216,7 +220,8 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 double t0, t1;
                 locate_fast(T.axis0, T.n0, ux, i0, t0);
                 locate_fast(T.axis1, T.n1, uy, i1, t1);
-                const double2 *tab = reinterpret_cast<const double2 *>(T.values);
+                // centre table, amplitude-major: [order][i0][i1][4][K]
+                const double2 *tab = a.center_tab;
                 const int stride1 = T.n2 * 4, stride0 = T.n1 * T.n2 * 4;
                 const size_t stride_o = (size_t)T.n0 * T.n1 * T.n2 * 4;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
@@ -229,8 +234,9 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                         check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
                         // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
                         order_term(acc, tab + o * stride_o + (size_t)i0 * stride0 + i1 * stride1 +
-                                            which * 4,
-                                   stride0, stride1, t0, t1, Hy_i, Hx_i, kx, ky, p.k_glass2 - kt2,
+                                            which,
+                                   stride0, stride1, T.n2, t0, t1, Hy_i, Hx_i, kx, ky,
+                                   p.k_glass2 - kt2,
                                    p.k_glass, inv_n, p.Z0, kx * ox_ + ky * oy_);
                     }
                 }
