@@ -50,9 +50,8 @@ __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY>
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT>
 __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a) {
-    constexpr int BKT = 16;
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LDAS = BKT + 2, LDBS = BN + 16;
@@ -267,13 +266,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
         }
 }
 
-template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false>
+template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16>
 static int launch_fold(hipStream_t stream, FoldArgs &a) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
@@ -306,7 +305,7 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     // give >= 2 workgroups per CU, else 32 x 64
     const long wide = (long)((M + 31) / 32) * ((S + 127) / 128);
     // (the on-the-fly-rotation variants 21 / 26 are 2-5 % faster than the table variants 9 / 8)
-    int pick = wide >= 512 ? 21 : 26;
+    int pick = wide >= 512 ? 21 : 31;   // 31: K step 32 (half the barriers), +6 % on small grids
     if (forced >= 0) pick = forced;
     switch (pick) {
         case 1: return launch_fold<64, 64, 2, 2>(stream, a);
@@ -327,6 +326,10 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         case 25: return launch_fold<64, 128, 2, 4, 2, true>(stream, a);
         case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a);
         case 27: return launch_fold<64, 128, 2, 2, 1, true>(stream, a);
+        case 30: return launch_fold<32, 128, 2, 2, 2, true, 32>(stream, a);
+        case 31: return launch_fold<32, 64, 2, 2, 2, true, 32>(stream, a);
+        case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a);
+        case 33: return launch_fold<32, 64, 2, 2, 1, true, 32>(stream, a);
         default: return launch_fold<64, 128, 2, 4>(stream, a);
     }
 }
