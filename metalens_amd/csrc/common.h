@@ -175,6 +175,8 @@ struct ml_ctx {
 
     // near-field scratch
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
+    ml::DevBuf row_first;          // see note_row_extent(); valid only for synthesised fields
+    bool row_first_valid = false;
     int nf_blocks = 0;
 
     ml::FarfieldPlan plan;
@@ -213,7 +215,8 @@ int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *
 // zfold.hip: stage 1 with both mirror symmetries folded (real cos/sin kernel)
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
-                 const double *D, double *C, int64_t ldc, int my);
+                 const double *D, double *C, int64_t ldc, int my, const int *row_first = nullptr,
+                 int nxl = 1);
 // comm.hip
 void comm_release(ml_ctx *ctx);
 

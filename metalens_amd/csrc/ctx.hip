@@ -242,7 +242,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
-                      &ctx->violations, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
+                      &ctx->violations, &ctx->row_first, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
                       &ctx->plan.amplitudes, &ctx->comm_scratch, &ctx->lattice_in,
                       &ctx->plan.fold_cm, &ctx->plan.fold_sm, &ctx->plan.fold_E, &ctx->plan.fold_D,
@@ -454,6 +454,8 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     const size_t viol_bytes = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
     ML_TRY(ctx->violations.reserve(viol_bytes));
     ML_HIP(hipMemsetAsync(ctx->violations.p, 0, viol_bytes, ctx->stream));
+    ML_TRY(ctx->row_first.reserve((size_t)nx * sizeof(int)));
+    ctx->row_first_valid = true;
     return nearfield_launch(ctx, p, nx, ny);
 }
 
@@ -554,6 +556,7 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
     ML_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nx = nx;
     ctx->ny = ny;
+    ctx->row_first_valid = false;   // caller-supplied fields: nothing known about zeros
     return ML_OK;
 }
 

@@ -478,7 +478,8 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                                 pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
                                 pl.fold_r4.as<double>(), pl.fold_T,
                                 pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
-                                pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my));
+                                pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my,
+                                ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl));
         else
             ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
                          pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));

@@ -218,6 +218,40 @@ __global__ __launch_bounds__(256) void nearfield_exact_kernel(const NfArgs a) {
     block_power(a, power_here);
 }
 
+// Per aperture row: how far from the row's two ends the first sample inside the lens is,
+// min(j, ny-1-j).  Samples outside the lens are exactly zero, so the far-field GEMM skips that
+// outer part of each row (zfold.hip).  Inside-the-lens is the kernels' own test
+// sqrt(x^2 + y^2) <= outer boundary, which is monotone in |y|: two binary searches per row.
+__global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nx) return;
+    const double x = a.x_pts[i], rmax = a.B[a.n_rings];
+    auto inside = [&](int j) { return !(sqrt(x * x + a.y_pts[j] * a.y_pts[j]) > rmax); };
+    // sample closest to y = 0 (y_pts ascends)
+    int lo = 0, hi = a.ny - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (a.y_pts[mid] < 0.0) lo = mid + 1; else hi = mid;
+    }
+    int jc = lo;
+    if (jc > 0 && fabs(a.y_pts[jc - 1]) < fabs(a.y_pts[jc])) --jc;
+    int first = 0x7f7f7f7f;
+    if (inside(jc)) {
+        int l = 0, r = jc;               // smallest j in [0, jc] that is inside
+        while (l < r) {
+            const int mid = (l + r) / 2;
+            if (inside(mid)) r = mid; else l = mid + 1;
+        }
+        int l2 = jc, r2 = a.ny - 1;      // largest j in [jc, ny-1] that is inside
+        while (l2 < r2) {
+            const int mid = (l2 + r2 + 1) / 2;
+            if (inside(mid)) l2 = mid; else r2 = mid - 1;
+        }
+        first = min(l, a.ny - 1 - l2);
+    }
+    a.row_first[i] = first;
+}
+
 // deterministic tree sum of the per-block partials
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const double *partial, int n,
                                                             double *out) {
@@ -276,6 +310,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.ring_ok_off = ctx->ring_ok_off.as<int>();
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
+    a.row_first = ctx->row_first.as<int>();
     a.viol = ctx->violations.as<unsigned long long>();
 }
 
@@ -301,6 +336,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
         ProfScope scope(ctx, ML_K_NEARFIELD);
         ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
     }
+    hipLaunchKernelGGL(row_extent_kernel, dim3((nx + 255) / 256), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->partial_power.as<double>(), n_partials, ctx->power.as<double>());
     ML_HIP(hipGetLastError());

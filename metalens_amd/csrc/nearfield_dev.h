@@ -45,6 +45,7 @@ struct NfArgs {
     // outputs
     double *fields;
     double *partial_power;
+    int *row_first;   // per aperture row: smallest min(j, ny-1-j) over samples inside the lens
     unsigned long long *viol;
 };
 

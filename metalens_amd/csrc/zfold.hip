@@ -44,6 +44,8 @@ struct FoldArgs {
     int64_t ldc;
     int my;
     int tiles_m, tiles_n, chunk;
+    const int *row_first;   // [nxl] or nullptr: first pair index with a non-zero sample per row
+    int nxl;
 };
 
 __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
@@ -71,6 +73,19 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 15, fk = lane >> 4;
+
+    // Rows of a synthesised near field are exactly zero outside the lens circle: start the
+    // reduction at the first pair (counted from the row ends) that can be non-zero for any row
+    // of this tile.
+    int t_begin = 0;
+    if (a.row_first) {
+        __shared__ int s_first;
+        if (tid == 0) s_first = 0x7fffffff;
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) atomicMin(&s_first, a.row_first[(m0 + tid) % a.nxl]);
+        __syncthreads();
+        t_begin = (min(s_first, a.T) / BKT) * BKT;
+    }
 
     double2 gm[A_PER], gp[A_PER];   // F[k-], F[k+] (already modulated)
     double2 rc[B_PER], rs[B_PER];
@@ -171,17 +186,17 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
             r4c[j] = s < a.S ? a.R4c[s] : 1.0;
             r4s[j] = s < a.S ? a.R4s[s] : 0.0;
         }
-        load_seed(0);
+        load_seed(t_begin);
     }
 
-    load_tile(0);
-    for (int t0 = 0; t0 < a.T; t0 += BKT) {
+    load_tile(t_begin);
+    for (int t0 = t_begin; t0 < a.T; t0 += BKT) {
         __syncthreads();
         store_tile();
         __syncthreads();
         if (t0 + BKT < a.T) load_tile(t0 + BKT);
         if (FLY) {
-            if (t0 % RESEED == 0) {
+            if (t0 % RESEED == 0 || t0 == t_begin) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bc[j] = seed_c[j];
@@ -280,7 +295,7 @@ static int launch_fold(hipStream_t stream, FoldArgs &a) {
 
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
-                 const double *D, double *C, int64_t ldc, int my) {
+                 const double *D, double *C, int64_t ldc, int my, const int *row_first, int nxl) {
     FoldArgs a;
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
@@ -297,6 +312,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.C = reinterpret_cast<double2 *>(C);
     a.ldc = ldc;
     a.my = my;
+    a.row_first = row_first;
+    a.nxl = nxl;
     static const int forced = [] {
         const char *e = getenv("ML_ZFOLD_TILE");
         return e ? atoi(e) : -1;
