@@ -216,7 +216,9 @@ int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
                  const double *D, double *C, int64_t ldc, int my, const int *row_first = nullptr,
-                 int nxl = 1);
+                 int nxl = 1, int ksplit = 1, int64_t split_stride = 0);
+// number of split-K slabs zfold_stage1 will actually write for (T, ksplit)
+int zfold_splits(int T, int ksplit);
 // comm.hip
 void comm_release(ml_ctx *ctx);
 

@@ -101,8 +101,10 @@ struct Alpha4f {
 
 // V[3 - f][a][j] (+)= alpha_f * in[f][j][a]: transposes the folded stage-2 result back into
 // the radiation-vector layout, applies the reference's signs x dA and the field -> vector map
+// (in may hold `splits` split-K slabs of 4*my*mx elements each; they are summed here)
 __global__ __launch_bounds__(256) void zunfold_out_kernel(const double2 *in, double2 *out, int my,
-                                                          int mx, Alpha4f alpha, int accumulate) {
+                                                          int mx, Alpha4f alpha, int accumulate,
+                                                          int splits) {
     __shared__ double2 tile[32][33];
     const int f = blockIdx.z;
     const size_t plane = (size_t)mx * my;
@@ -112,7 +114,15 @@ __global__ __launch_bounds__(256) void zunfold_out_kernel(const double2 *in, dou
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int a0 = blockIdx.x * 32, j0 = blockIdx.y * 32;   // in is [j][a]
     for (int k = ty; k < 32; k += 8)
-        if (j0 + k < my && a0 + tx < mx) tile[k][tx] = in[(size_t)(j0 + k) * mx + a0 + tx];
+        if (j0 + k < my && a0 + tx < mx) {
+            double2 v = in[(size_t)(j0 + k) * mx + a0 + tx];
+            for (int sp = 1; sp < splits; ++sp) {
+                const double2 w = in[(size_t)sp * 4 * plane + (size_t)(j0 + k) * mx + a0 + tx];
+                v.x += w.x;
+                v.y += w.y;
+            }
+            tile[k][tx] = v;
+        }
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
         if (a0 + k < mx && j0 + tx < my) {
@@ -331,7 +341,11 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     const int nxl = ctx->nx, mx = pl.mx, my = pl.my, S = pl.fold2_S, T = (nxl + 1) / 2;
     const size_t g_elems = (size_t)4 * nxl * my;
     ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
-    ML_TRY(pl.fold2_ot.reserve((size_t)4 * my * mx * 2 * sizeof(double)));
+    // few rows (4*my) and a long reduction: split the pairs over several workgroups per tile
+    const long tiles = (long)((4 * my + 31) / 32) * ((S + 63) / 64);
+    const int want_split = (int)std::min<long>(8, std::max<long>(1, 768 / std::max<long>(tiles, 1)));
+    const int splits = zfold_splits(T, want_split);
+    ML_TRY(pl.fold2_ot.reserve((size_t)splits * 4 * my * mx * 2 * sizeof(double)));
     ML_TRY(pl.fold2_cm.reserve((size_t)T * S * sizeof(double)));
     ML_TRY(pl.fold2_sm.reserve((size_t)T * S * sizeof(double)));
     ML_TRY(pl.fold2_r4.reserve((size_t)S * 2 * sizeof(double)));
@@ -370,12 +384,13 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     ML_TRY(zfold_stage1(ctx->stream, 4 * my, nxl, pl.fold2_gt.as<double>(), nxl,
                         pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), pl.fold2_r4.as<double>(),
                         T, S, pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr,
-                        pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx));
+                        pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx, nullptr, 1,
+                        want_split, (int64_t)4 * my * mx));
     Alpha4f al;
     for (int k = 0; k < 4; ++k) al.v[k] = alpha[k];
     hipLaunchKernelGGL(zunfold_out_kernel, dim3((mx + 31) / 32, (my + 31) / 32, 4), dim3(256), 0,
                        ctx->stream, pl.fold2_ot.as<double2>(), pl.vectors.as<double2>(), my, mx, al,
-                       accumulate);
+                       accumulate, splits);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
@@ -490,7 +505,11 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     const bool whole = (row0 == 0 && nxl == pl.nx_total);
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
-    const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= 256;
+    static const long fold2_min_tiles = [] {
+        const char *e = getenv("ML_FOLD2_MIN_TILES");
+        return e ? atol(e) : 32L;   // with split-K the folded path wins from ~32 tiles up
+    }();
+    const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
     if (!pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole)) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha));

@@ -46,6 +46,8 @@ struct FoldArgs {
     int tiles_m, tiles_n, chunk;
     const int *row_first;   // [nxl] or nullptr: first pair index with a non-zero sample per row
     int nxl;
+    int t_chunk;            // split-K: blockIdx.y handles pairs [y*t_chunk, (y+1)*t_chunk) and
+    int64_t split_stride;   // writes its partial result to C + y*split_stride (double2 units)
 };
 
 __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
@@ -86,6 +88,9 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
         __syncthreads();
         t_begin = (min(s_first, a.T) / BKT) * BKT;
     }
+    // split-K (few rows, long reduction: the folded stage 2): this workgroup's share of pairs
+    const int t_end = min(a.T, (int)(blockIdx.y + 1) * a.t_chunk);
+    t_begin = max(t_begin, (int)blockIdx.y * a.t_chunk);
 
     double2 gm[A_PER], gp[A_PER];   // F[k-], F[k+] (already modulated)
     double2 rc[B_PER], rs[B_PER];
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
             const int row = m0 + e / BKT, t = t0 + e % BKT;
             const int km = t, kp = a.ny - 1 - t;
             double2 fm = make_double2(0.0, 0.0), fp = make_double2(0.0, 0.0);
-            if (row < a.M && t < a.T) {
+            if (row < a.M && t < t_end) {
                 const double2 *Ar = a.A + (int64_t)row * a.lda;
                 fp = Ar[kp];
                 if (a.E) fp = zmul(fp, a.E[kp]);
@@ -190,11 +195,11 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
     }
 
     load_tile(t_begin);
-    for (int t0 = t_begin; t0 < a.T; t0 += BKT) {
+    for (int t0 = t_begin; t0 < t_end; t0 += BKT) {
         __syncthreads();
         store_tile();
         __syncthreads();
-        if (t0 + BKT < a.T) load_tile(t0 + BKT);
+        if (t0 + BKT < t_end) load_tile(t0 + BKT);
         if (FLY) {
             if (t0 % RESEED == 0 || t0 == t_begin) {
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
                     bs[j] = seed_s[j];
                 }
             }
-            if ((t0 + BKT) % RESEED == 0 && t0 + BKT < a.T) load_seed(t0 + BKT);
+            if ((t0 + BKT) % RESEED == 0 && t0 + BKT < t_end) load_seed(t0 + BKT);
         }
 #pragma unroll UNR
         for (int s = 0; s < BKT / 4; ++s) {
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
                 // +v: Pc - i Ps ; -v: Pc + i Ps
                 const double2 plus = make_double2(cr + si, ci - sr);
                 const double2 minus = make_double2(cr - si, ci + sr);
-                double2 *Crow = a.C + (int64_t)row * a.ldc;
+                double2 *Crow = a.C + blockIdx.y * a.split_stride + (int64_t)row * a.ldc;
                 Crow[jp] = zmul(plus, dp);
                 if (jm != jp) Crow[jm] = zmul(minus, dm);
             }
@@ -282,12 +287,13 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
 }
 
 template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16>
-static int launch_fold(hipStream_t stream, FoldArgs &a) {
+static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT>), dim3(a.chunk * 8), dim3(WM * WN * 64), 0,
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT>), dim3(a.chunk * 8, ksplit),
+                       dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
@@ -295,7 +301,8 @@ static int launch_fold(hipStream_t stream, FoldArgs &a) {
 
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
-                 const double *D, double *C, int64_t ldc, int my, const int *row_first, int nxl) {
+                 const double *D, double *C, int64_t ldc, int my, const int *row_first, int nxl,
+                 int ksplit, int64_t split_stride) {
     FoldArgs a;
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
@@ -314,6 +321,11 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.my = my;
     a.row_first = row_first;
     a.nxl = nxl;
+    ksplit = ksplit < 1 ? 1 : ksplit;
+    // chunks are multiples of 64 pairs so that every K tile and re-seed point stays aligned
+    a.t_chunk = ((T + ksplit - 1) / ksplit + 63) / 64 * 64;
+    ksplit = (T + a.t_chunk - 1) / a.t_chunk;
+    a.split_stride = split_stride;
     static const int forced = [] {
         const char *e = getenv("ML_ZFOLD_TILE");
         return e ? atoi(e) : -1;
@@ -325,30 +337,36 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     int pick = wide >= 512 ? 21 : 31;   // 31: K step 32 (half the barriers), +6 % on small grids
     if (forced >= 0) pick = forced;
     switch (pick) {
-        case 1: return launch_fold<64, 64, 2, 2>(stream, a);
-        case 2: return launch_fold<32, 64, 2, 2>(stream, a);
-        case 3: return launch_fold<128, 64, 4, 2>(stream, a);
-        case 4: return launch_fold<64, 64, 2, 2, 1>(stream, a);
-        case 5: return launch_fold<64, 64, 2, 2, 2>(stream, a);
-        case 6: return launch_fold<64, 128, 2, 4, 1>(stream, a);
-        case 7: return launch_fold<64, 128, 2, 4, 2>(stream, a);
-        case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a);
-        case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a);
-        case 10: return launch_fold<32, 128, 2, 2, 1>(stream, a);
-        case 20: return launch_fold<32, 128, 2, 2, 2, true>(stream, a);
-        case 21: return launch_fold<32, 128, 2, 2, 1, true>(stream, a);
-        case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a);
-        case 23: return launch_fold<64, 64, 2, 2, 1, true>(stream, a);
-        case 24: return launch_fold<64, 64, 2, 2, 2, true>(stream, a);
-        case 25: return launch_fold<64, 128, 2, 4, 2, true>(stream, a);
-        case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a);
-        case 27: return launch_fold<64, 128, 2, 2, 1, true>(stream, a);
-        case 30: return launch_fold<32, 128, 2, 2, 2, true, 32>(stream, a);
-        case 31: return launch_fold<32, 64, 2, 2, 2, true, 32>(stream, a);
-        case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a);
-        case 33: return launch_fold<32, 64, 2, 2, 1, true, 32>(stream, a);
-        default: return launch_fold<64, 128, 2, 4>(stream, a);
+        case 1: return launch_fold<64, 64, 2, 2>(stream, a, ksplit);
+        case 2: return launch_fold<32, 64, 2, 2>(stream, a, ksplit);
+        case 3: return launch_fold<128, 64, 4, 2>(stream, a, ksplit);
+        case 4: return launch_fold<64, 64, 2, 2, 1>(stream, a, ksplit);
+        case 5: return launch_fold<64, 64, 2, 2, 2>(stream, a, ksplit);
+        case 6: return launch_fold<64, 128, 2, 4, 1>(stream, a, ksplit);
+        case 7: return launch_fold<64, 128, 2, 4, 2>(stream, a, ksplit);
+        case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a, ksplit);
+        case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a, ksplit);
+        case 10: return launch_fold<32, 128, 2, 2, 1>(stream, a, ksplit);
+        case 20: return launch_fold<32, 128, 2, 2, 2, true>(stream, a, ksplit);
+        case 21: return launch_fold<32, 128, 2, 2, 1, true>(stream, a, ksplit);
+        case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a, ksplit);
+        case 23: return launch_fold<64, 64, 2, 2, 1, true>(stream, a, ksplit);
+        case 24: return launch_fold<64, 64, 2, 2, 2, true>(stream, a, ksplit);
+        case 25: return launch_fold<64, 128, 2, 4, 2, true>(stream, a, ksplit);
+        case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a, ksplit);
+        case 27: return launch_fold<64, 128, 2, 2, 1, true>(stream, a, ksplit);
+        case 30: return launch_fold<32, 128, 2, 2, 2, true, 32>(stream, a, ksplit);
+        case 31: return launch_fold<32, 64, 2, 2, 2, true, 32>(stream, a, ksplit);
+        case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a, ksplit);
+        case 33: return launch_fold<32, 64, 2, 2, 1, true, 32>(stream, a, ksplit);
+        default: return launch_fold<64, 128, 2, 4>(stream, a, ksplit);
     }
+}
+
+int zfold_splits(int T, int ksplit) {
+    ksplit = ksplit < 1 ? 1 : ksplit;
+    const int chunk = ((T + ksplit - 1) / ksplit + 63) / 64 * 64;
+    return (T + chunk - 1) / chunk;
 }
 
 }  // namespace ml
