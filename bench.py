@@ -214,6 +214,12 @@ def main():
         # flop per complex (sample, direction) pair (both mirror symmetries), the generic 3M
         # kernel 6, against the 8 of the textbook complex multiply-add that `achieved` counts
         executed = flops * (0.25 if folded.value else 0.75)
+        if folded.value:
+            # the folded kernel also skips the all-zero outer part of each aperture row (samples
+            # outside the lens circle): kept fraction of each row = chord / window width
+            r_lens = float(lens['lens_periphery_summary']['r_max_list'][-1])
+            chord = 2 * np.sqrt(np.maximum(r_lens ** 2 - hp.x_local ** 2, 0.0))
+            executed *= float(np.minimum(chord / (x[-1] - x[0]), 1.0).mean())
         roofs['zgemm_stage1'] = {
             'bound': 'mfma',
             'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',

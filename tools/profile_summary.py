@@ -49,16 +49,24 @@ def main():
         out.append('%-46s %14s %6d %12.1f %12.1f' % (k, g, len(v), sum(v) / len(v), min(v)))
     for label, d in zip(('FETCH_SIZE', 'WRITE_SIZE'), sys.argv[2:4]):
         cc = find(d, '*counter_collection.csv')
+        # grid shape per dispatch from the same run's kernel trace (separates launches of one
+        # kernel that have the same total size, e.g. the two folded GEMM stages)
+        shape = {}
+        kt2 = find(d, '*kernel_trace.csv')
+        if kt2:
+            for r in csv.DictReader(open(kt2)):
+                shape[r['Dispatch_Id']] = r['Grid_Size_X'] + 'x' + r['Grid_Size_Y']
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(cc)):
-            acc[(short(r['Kernel_Name']), r['Grid_Size'])].append(float(r['Counter_Value']))
+            acc[(short(r['Kernel_Name']), shape.get(r['Dispatch_Id'], r['Grid_Size']))].append(
+                float(r['Counter_Value']))
         out.append('')
         out.append('== rocprofv3 --pmc %s (KiB per dispatch)' % label)
-        out.append('%-46s %12s %6s %14s %14s' % ('kernel', 'grid', 'calls', 'avg_KiB', 'avg_MB(x2)' if label == 'FETCH_SIZE' else 'avg_MB'))
+        out.append('%-46s %14s %6s %14s %14s' % ('kernel', 'grid', 'calls', 'avg_KiB', 'avg_MB(x2)' if label == 'FETCH_SIZE' else 'avg_MB'))
         for (k, g), v in sorted(acc.items()):
             avg = sum(v) / len(v)
             mb = avg * 1024 / 1e6 * (2 if label == 'FETCH_SIZE' else 1)
-            out.append('%-46s %12s %6d %14.1f %14.2f' % (k, g, len(v), avg, mb))
+            out.append('%-46s %14s %6d %14.1f %14.2f' % (k, g, len(v), avg, mb))
     print('\n'.join(out))
 
 
