@@ -10,6 +10,7 @@ exposing ``.grating_list[i].data``, ``.grating_list[0].n_glass / .grating_period
 ``RegularGridInterpolator`` or this package's ``TrilinearTable``) and
 ``.interpolator_bounds``.
 """
+import hashlib
 from math import pi
 
 import numpy as np
@@ -54,37 +55,46 @@ def pack_table(obj, wavelength_in_nm):
             'values': values, 'bounds': bounds}
 
 
+def _digest(t):
+    """content hash of one packed table (axes, orders, values, bounds)"""
+    h = hashlib.blake2b(digest_size=16)
+    for a in t['axes'] + [t['orders'], t['order_k'], t['values'], t['bounds']]:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.digest()
+
+
 def upload_tables(ctx, gratingcollection_list, hexgridset, wavelength_in_nm):
     if len(gratingcollection_list) > MAX_SLOTS:
         raise ValueError('at most %d grating collections per lens' % MAX_SLOTS)
-    token = ('tables', wavelength_in_nm, tuple(id(gc) for gc in gratingcollection_list),
-             id(hexgridset),
-             tuple(id(gc.interpolators) for gc in gratingcollection_list),
-             id(getattr(hexgridset, 'interpolators', None)))
+    # pack first, then compare CONTENT with what is already on the GPU: object identity is not a
+    # safe cache key (tables can be edited in place, ids are reused after garbage collection)
+    packed = [pack_table(gc, wavelength_in_nm) for gc in gratingcollection_list]
+    center = pack_table(hexgridset, wavelength_in_nm) if hexgridset is not None else None
+    periods = None
+    if center is not None:
+        g0 = hexgridset.grating_list[0]
+        periods = np.array([g0.grating_period, g0.lateral_period], dtype=np.float64)
+    token = ('tables', wavelength_in_nm, tuple(_digest(t) for t in packed),
+             _digest(center) if center is not None else None,
+             periods.tobytes() if periods is not None else None)
     if ctx.tables_token == token:
         return
     lib = ctx.lib
-    packed = []
-    for slot, gc in enumerate(gratingcollection_list):
-        t = pack_table(gc, wavelength_in_nm)
-        packed.append(t)
+    for slot, t in enumerate(packed):
         a0, a1, a2 = t['axes']
         _lib.check(lib.ml_upload_table(
             ctx.handle, slot, _lib.dptr(a0), a0.size, _lib.dptr(a1), a1.size, _lib.dptr(a2), a2.size,
             _lib.iptr(t['orders']), _lib.dptr(t['order_k']), len(t['orders']),
             _lib.dptr(t['values']), _lib.dptr(t['bounds']), None))
-    if hexgridset is not None:
-        t = pack_table(hexgridset, wavelength_in_nm)
+    if center is not None:
+        t = center
         a0, a1, a2 = t['axes']
-        g0 = hexgridset.grating_list[0]
-        periods = np.array([g0.grating_period, g0.lateral_period], dtype=np.float64)
         _lib.check(lib.ml_upload_table(
             ctx.handle, -1, _lib.dptr(a0), a0.size, _lib.dptr(a1), a1.size, _lib.dptr(a2), a2.size,
             _lib.iptr(t['orders']), _lib.dptr(t['order_k']), len(t['orders']),
             _lib.dptr(t['values']), _lib.dptr(t['bounds']), _lib.dptr(periods)))
-        packed.append(t)
     ctx.tables_token = token
-    ctx.table_orders = [p['orders'] for p in packed]
+    ctx.table_orders = [p['orders'] for p in packed] + ([center['orders']] if center is not None else [])
 
 
 def pack_layout(lens_periphery_summary, lens_center_summary):

@@ -35,6 +35,7 @@ class HotPath:
         self.n_glass, self.wavelength = n_glass, wavelength
         packing.upload_tables(self.ctx, S['gratingcollection_list'], hexgridset, wl_nm)
         packing.upload_layout(self.ctx, S, lens_center_summary)
+        self.dipole_moment = dipole_moment
         self.params = nearfield_params(source_x, source_y, source_z, source_pol, wavelength,
                                        n_glass, dipole_moment, self.c0, self.Z0)
         self.x_all = _lib.f64(x_pts)
@@ -62,6 +63,15 @@ class HotPath:
         self.shape = (self.ux.size,) if pair_list else (self.ux.size, self.uy.size)
         self.dxp = x_pts[1] - x_pts[0]
         self.dyp = y_pts[1] - y_pts[0]
+
+    def set_source(self, source):
+        """switch to another dipole / plane-wave source; tables, layout and grids stay resident"""
+        source_x, source_y, source_z, source_pol = source
+        assert source_z < 0 and source_pol in ('x', 'y', 'z')
+        if source_z == -float('inf'):
+            assert source_pol != 'z'
+        self.params = nearfield_params(source_x, source_y, source_z, source_pol, self.wavelength,
+                                       self.n_glass, self.dipole_moment, self.c0, self.Z0)
 
     def step(self):
         """queue one pass of the hot path on the context's stream (asynchronous)"""

@@ -1,0 +1,77 @@
+"""Batched source sweeps.
+
+The reference's docstring describes the use (nearfield.py:69-73): an isotropic or Lambertian
+emitter is the INCOHERENT sum of x-, y- and z-polarised dipoles, possibly at several positions
+or wavelengths - i.e. many runs of near field -> far field whose POWERS are added.  A sweep
+re-uses the resident tables and layout and keeps two passes in flight on two GPU streams: the
+near-field kernel (L1/latency-bound, matrix cores idle) of one source overlaps the folded GEMMs
+(matrix-core-bound) of the previous one (measured +15 % throughput at 2048^2 -> 256^2).
+"""
+import numpy as np
+
+from . import _lib
+from .pipeline import HotPath
+
+
+class SourceSweep:
+    def __init__(self, wavelength, lens_periphery_summary, lens_center_summary, hexgridset,
+                 x_pts, y_pts, ux, uy, dipole_moment=1e-30, c0=None, Z0=None, n_streams=2,
+                 device=None):
+        self.ux = np.asarray(ux, dtype=float).ravel()
+        self.uy = np.asarray(uy, dtype=float).ravel()
+        self.lanes = []
+        for _ in range(max(1, n_streams)):
+            ctx = _lib.Context(device)
+            # the source is replaced per pass; any valid one will do for set-up
+            hp = HotPath((0.0, 0.0, -1.0, 'x'), wavelength, lens_periphery_summary,
+                         lens_center_summary, hexgridset, x_pts, y_pts, self.ux, self.uy,
+                         dipole_moment=dipole_moment, c0=c0, Z0=Z0, ctx=ctx)
+            self.lanes.append(hp)
+
+    def close(self):
+        for hp in self.lanes:
+            hp.ctx.close()
+
+    def run(self, sources, keep_each=False):
+        """``sources`` = iterable of ``(source_x, source_y, source_z, source_pol)``.
+        Returns a dict: ``P_sum`` (incoherent sum of the far-field power maps, NaN outside the
+        unit circle), ``power_in`` (incident power through the lens per source,
+        nearfield.py:474-477), ``total_P`` (radiated power per source: sum of the finite
+        ``P * dux * duy``, nearfield_farfield.py:74), ``efficiency`` = sum(total_P) /
+        sum(power_in), and ``P_each`` if ``keep_each``."""
+        sources = list(sources)
+        dux = self.ux[1] - self.ux[0] if self.ux.size > 1 else 1.0
+        duy = self.uy[1] - self.uy[0] if self.uy.size > 1 else 1.0
+        P_sum = None
+        power_in, total_P, each = [], [], []
+        pending = [None] * len(self.lanes)
+
+        def collect(slot):
+            nonlocal P_sum
+            hp = self.lanes[slot]
+            hp.sync()
+            res = hp.results()
+            P = res['P']
+            P_sum = P.copy() if P_sum is None else P_sum + P
+            power_in.append(res['power_local_rows'])
+            total_P.append(float((P * dux * duy)[np.isfinite(P)].sum()))
+            if keep_each:
+                each.append(P)
+            pending[slot] = None
+
+        for k, src in enumerate(sources):
+            slot = k % len(self.lanes)
+            if pending[slot] is not None:
+                collect(slot)
+            self.lanes[slot].set_source(src)
+            self.lanes[slot].step()
+            pending[slot] = k
+        # drain in issue order
+        order = sorted((k, s) for s, k in enumerate(pending) if k is not None)
+        for _, slot in order:
+            collect(slot)
+        out = {'P_sum': P_sum, 'power_in': np.array(power_in), 'total_P': np.array(total_P)}
+        out['efficiency'] = out['total_P'].sum() / out['power_in'].sum() if power_in else np.nan
+        if keep_each:
+            out['P_each'] = each
+        return out

@@ -343,6 +343,36 @@ def test_rgb_wavelengths_vs_oracle(ma, wl_nm, n_glass):
         assert np.abs(ff[k] - ref[k]).max() <= TOL * np.abs(ref[k]).max()
 
 
+def test_source_sweep_incoherent_sum_vs_oracle(ma):
+    """x + y + z dipoles summed incoherently (the reference's isotropic-emitter recipe,
+    nearfield.py:69-73), two passes in flight on two streams"""
+    from oracle import farfield_oracle, nearfield_oracle
+    wl = 580e-9
+    lens = _synthetic_lens(18e-6, 0.35, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    x = np.linspace(-R, R, 150)
+    u = np.linspace(-0.2, 0.2, 36)
+    f = lens['source_distance']
+    sources = [(0.2e-6, 0.1e-6, -f, 'x'), (0.2e-6, 0.1e-6, -f, 'y'), (0.2e-6, 0.1e-6, -f, 'z'),
+               (-1.0e-6, 0.5e-6, -1.05 * f, 'x')]
+    sw = ma.SourceSweep(wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                        lens['hexgridset'], x, x, u, u)
+    got = sw.run(sources, keep_each=True)
+    sw.close()
+    P_ref, pin_ref = 0, []
+    for k, (sx, sy, sz, pol) in enumerate(sources):
+        nf = nearfield_oracle.build_nearfield(sx, sy, sz, pol, wl, lens['lens_periphery_summary'],
+                                              lens['lens_center_summary'], lens['hexgridset'],
+                                              x_pts=x, y_pts=x)
+        ff = farfield_oracle.farfield_direct(*nf[:4], x, x, wl, nf[7], u, u)
+        assert np.nanmax(np.abs(got['P_each'][k] - ff['P'])) <= 1e-11 * np.nanmax(ff['P'])
+        P_ref = P_ref + ff['P']
+        pin_ref.append(nf[6])
+    assert np.nanmax(np.abs(got['P_sum'] - P_ref)) <= 1e-11 * np.nanmax(P_ref)
+    np.testing.assert_allclose(got['power_in'], pin_ref, rtol=1e-12)
+    assert 0 < got['efficiency'] < 10
+
+
 def test_rccl_path_single_rank():
     """the multi-GPU code path (RCCL loaded with dlopen, unique-id exchange through /tmp,
     communicator, all-reduce of the radiation vectors, max/sum reductions) run for real with
