@@ -125,6 +125,7 @@ struct FarfieldPlan {
     DevBuf power;        // double  [mx][my]
     DevBuf amplitudes;   // complex [2][mx][my]  (a_theta, a_phi)
     bool have_vectors = false;
+    int stage1_splits = 1;   // split-K slabs currently held in `stage1`
     // folded (even/odd) stage 1, see zfold.hip; used when uy is centre-symmetric
     bool fold = false, fold_has_E = false;
     int fold_T = 0, fold_S = 0;

@@ -79,9 +79,10 @@ __global__ __launch_bounds__(256) void phase_table_kernel(double2 *out, double *
     }
 }
 
-// out[b][c][r] = in[b][r][c] (complex), 32 x 32 tiles through LDS
+// out[b][c][r] = sum_s in[s][b][r][c] (complex), 32 x 32 tiles through LDS; `splits` split-K
+// slabs of `slab` elements each are summed on the way
 __global__ __launch_bounds__(256) void ztranspose_kernel(const double2 *in, double2 *out, int rows,
-                                                         int cols) {
+                                                         int cols, int splits, size_t slab) {
     __shared__ double2 tile[32][33];
     const size_t plane = (size_t)rows * cols;
     in += blockIdx.z * plane;
@@ -89,10 +90,32 @@ __global__ __launch_bounds__(256) void ztranspose_kernel(const double2 *in, doub
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     for (int k = ty; k < 32; k += 8)
-        if (r0 + k < rows && c0 + tx < cols) tile[k][tx] = in[(size_t)(r0 + k) * cols + c0 + tx];
+        if (r0 + k < rows && c0 + tx < cols) {
+            double2 v = in[(size_t)(r0 + k) * cols + c0 + tx];
+            for (int sp = 1; sp < splits; ++sp) {
+                const double2 w = in[sp * slab + (size_t)(r0 + k) * cols + c0 + tx];
+                v.x += w.x;
+                v.y += w.y;
+            }
+            tile[k][tx] = v;
+        }
     __syncthreads();
     for (int k = ty; k < 32; k += 8)
         if (c0 + k < cols && r0 + tx < rows) out[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
+}
+
+// in[0] += in[1] + ... + in[splits-1]  (split-K slabs of stage 1 when the consumer is not the
+// transposing kernel)
+__global__ __launch_bounds__(256) void zsum_slabs_kernel(double2 *in, size_t n, int splits) {
+    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (at >= n) return;
+    double2 v = in[at];
+    for (int sp = 1; sp < splits; ++sp) {
+        const double2 w = in[sp * n + at];
+        v.x += w.x;
+        v.y += w.y;
+    }
+    in[at] = v;
 }
 
 struct Alpha4f {
@@ -379,7 +402,9 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
                        delta, 0.0, s_hi, s_lo, pl.ux.as<double>(), (const double *)nullptr);
     // G[(f, n1)][j] -> GT[(f, j)][n1]
     hipLaunchKernelGGL(ztranspose_kernel, dim3((my + 31) / 32, (nxl + 31) / 32, 4), dim3(256), 0,
-                       ctx->stream, pl.stage1.as<double2>(), pl.fold2_gt.as<double2>(), nxl, my);
+                       ctx->stream, pl.stage1.as<double2>(), pl.fold2_gt.as<double2>(), nxl, my,
+                       pl.stage1_splits, (size_t)4 * nxl * my);
+    pl.stage1_splits = 1;   // consumed
     ML_HIP(hipGetLastError());
     ML_TRY(zfold_stage1(ctx->stream, 4 * my, nxl, pl.fold2_gt.as<double>(), nxl,
                         pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), pl.fold2_r4.as<double>(),
@@ -483,7 +508,17 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     ML_REQUIRE(!accumulate || pl.have_vectors, "accumulate requested but nothing to add to");
     ML_HIP(hipSetDevice(ctx->device));
     const int nxl = ctx->nx, ny = pl.ny, mx = pl.mx, my = pl.my;
-    ML_TRY(pl.stage1.reserve((size_t)4 * nxl * my * 2 * sizeof(double)));
+    // few resident rows (multi-GPU shards) and a long reduction: split the pairs of stage 1 over
+    // several workgroups per tile; the slabs are summed by the next kernel
+    pl.stage1_splits = 1;
+    int want_split1 = 1;
+    if (pl.fold) {
+        const long tiles1 = (long)((4 * nxl + 31) / 32) * ((pl.fold_S + 63) / 64);
+        want_split1 = (int)std::min<long>(8, std::max<long>(1, (640 + tiles1 - 1) / std::max<long>(tiles1, 1)));
+        if (tiles1 >= 480) want_split1 = 1;   // already two workgroups per CU
+        pl.stage1_splits = zfold_splits(pl.fold_T, want_split1);
+    }
+    ML_TRY(pl.stage1.reserve((size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
     const double one[4] = {1.0, 1.0, 1.0, 1.0};
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
@@ -494,7 +529,8 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                                 pl.fold_r4.as<double>(), pl.fold_T,
                                 pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
                                 pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my,
-                                ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl));
+                                ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl,
+                                want_split1, (int64_t)4 * nxl * my));
         else
             ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
                          pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
@@ -503,6 +539,16 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     // fields are stored Ex,Ey,Hx,Hy; radiation vectors Nx,Ny,Lx,Ly = -Hy, Hx, Ey, -Ex (x dA)
     const double alpha[4] = {-dA, dA, dA, -dA};
     const bool whole = (row0 == 0 && nxl == pl.nx_total);
+    auto collapse_stage1 = [&]() -> int {
+        if (pl.stage1_splits > 1) {
+            const size_t n = (size_t)4 * nxl * my;
+            hipLaunchKernelGGL(zsum_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                               ctx->stream, pl.stage1.as<double2>(), n, pl.stage1_splits);
+            ML_HIP(hipGetLastError());
+            pl.stage1_splits = 1;
+        }
+        return ML_OK;
+    };
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
     static const long fold2_min_tiles = [] {
@@ -516,6 +562,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     } else if (!pl.pair_list && mirrored) {
         // generic stage 2 on the two runs of a mirrored shard
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        ML_TRY(collapse_stage1());
         const int h = nxl / 2;
         double *slot3 = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
         for (int run = 0; run < 2; ++run) {
@@ -529,12 +576,14 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
         // stage 2: V_f[a][b] = alpha_f * sum_n1 exp(-i k x'_n1 ux_a) * G[(f, n1)][b];
         // batch entry f writes radiation-vector slot 3 - f
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        ML_TRY(collapse_stage1());
         double *slot3 = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
         ML_TRY(zgemm(ctx->stream, mx, my, nxl, alpha, pl.tw_x.as<double>() + (size_t)row0 * 2,
                      pl.nx_total, 0, pl.stage1.as<double>(), my, (int64_t)nxl * my, slot3, my,
                      -(int64_t)mx * my, 4, accumulate));
     } else {
         ProfScope scope(ctx, ML_K_COLDOT);
+        ML_TRY(collapse_stage1());
         ML_TRY(zcoldot(ctx->stream, 4, nxl, mx, alpha, pl.tw_x.as<double>(), mx, row0,
                        pl.stage1.as<double>(), pl.vectors.as<double>(), accumulate));
     }
