@@ -125,6 +125,7 @@ struct FarfieldPlan {
     DevBuf power;        // double  [mx][my]
     DevBuf amplitudes;   // complex [2][mx][my]  (a_theta, a_phi)
     bool have_vectors = false;
+    bool tw_x_ready = false;  // complex x twiddles built for the current plan
     int stage1_splits = 1;   // split-K slabs currently held in `stage1`
     // folded (even/odd) stage 1, see zfold.hip; used when uy is centre-symmetric
     bool fold = false, fold_has_E = false;

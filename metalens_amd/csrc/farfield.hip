@@ -420,6 +420,21 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     return ML_OK;
 }
 
+// tw_x: direction-major [mx][nx_total] (A operand of the generic stage 2) for a tensor grid,
+// sample-major [nx_total][mx] for a pair list (column dot)
+static int need_tw_x(ml_ctx *ctx) {
+    FarfieldPlan &pl = ctx->plan;
+    if (pl.tw_x_ready) return ML_OK;
+    if (pl.pair_list)
+        ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), pl.nx_total, pl.mx, 1, pl.nx_total, pl.dxp,
+                              pl.wavelength, pl.n_glass, pl.ux.as<double>()));
+    else
+        ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), pl.mx, pl.nx_total, 0, pl.nx_total, pl.dxp,
+                              pl.wavelength, pl.n_glass, pl.ux.as<double>()));
+    pl.tw_x_ready = true;
+    return ML_OK;
+}
+
 static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id) {
     ProfScope scope(ctx, kernel_id);
     hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0, ctx->stream,
@@ -469,14 +484,9 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
         ML_TRY(launch_twiddle(ctx, pl.tw_y.as<double>(), ny, my, 1, ny, dyp, wavelength, n_glass,
                               pl.uy.as<double>()));
     }
-    // tw_x: direction-major [mx][nx_total] (A operand of stage 2) for a tensor grid,
-    // sample-major [nx_total][mx] for a pair list (column dot)
-    if (pair_list)
-        ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), nx_total, mx, 1, nx_total, dxp, wavelength,
-                              n_glass, pl.ux.as<double>()));
-    else
-        ML_TRY(launch_twiddle(ctx, pl.tw_x.as<double>(), mx, nx_total, 0, nx_total, dxp, wavelength,
-                              n_glass, pl.ux.as<double>()));
+    // the complex x twiddles are only needed by the generic stage 2 / the pair-list column dot;
+    // they are built on first use (need_tw_x) after each plan call
+    pl.tw_x_ready = false;
     ML_TRY(plan_fold2(ctx, ux));
     pl.ready = true;
     return ML_OK;
@@ -561,6 +571,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
         ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha));
     } else if (!pl.pair_list && mirrored) {
         // generic stage 2 on the two runs of a mirrored shard
+        ML_TRY(need_tw_x(ctx));
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(collapse_stage1());
         const int h = nxl / 2;
@@ -575,6 +586,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     } else if (!pl.pair_list) {
         // stage 2: V_f[a][b] = alpha_f * sum_n1 exp(-i k x'_n1 ux_a) * G[(f, n1)][b];
         // batch entry f writes radiation-vector slot 3 - f
+        ML_TRY(need_tw_x(ctx));
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(collapse_stage1());
         double *slot3 = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
@@ -582,6 +594,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                      pl.nx_total, 0, pl.stage1.as<double>(), my, (int64_t)nxl * my, slot3, my,
                      -(int64_t)mx * my, 4, accumulate));
     } else {
+        ML_TRY(need_tw_x(ctx));
         ProfScope scope(ctx, ML_K_COLDOT);
         ML_TRY(collapse_stage1());
         ML_TRY(zcoldot(ctx->stream, 4, nxl, mx, alpha, pl.tw_x.as<double>(), mx, row0,
