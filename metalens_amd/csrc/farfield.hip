@@ -523,9 +523,22 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     pl.stage1_splits = 1;
     int want_split1 = 1;
     if (pl.fold) {
-        const long tiles1 = (long)((4 * nxl + 31) / 32) * ((pl.fold_S + 63) / 64);
-        want_split1 = (int)std::min<long>(8, std::max<long>(1, (640 + tiles1 - 1) / std::max<long>(tiles1, 1)));
-        if (tiles1 >= 480) want_split1 = 1;   // already two workgroups per CU
+        // Measured (tools/zfold_shape_sweep.py): tiles of 128 half-directions read the aperture
+        // fewer times and win when at most a 2-way split fills the chip; otherwise 64-wide
+        // tiles with as many splits as it takes to reach ~2.5 workgroups per CU.
+        const long t128 = (long)((4 * nxl + 31) / 32) * ((pl.fold_S + 127) / 128);
+        const long t64 = (long)((4 * nxl + 31) / 32) * ((pl.fold_S + 63) / 64);
+        if (t128 >= 480)
+            want_split1 = 1;
+        else if (2 * t128 >= 480)
+            want_split1 = 2;
+        else
+            want_split1 = (int)std::min<long>(8, std::max<long>(1, (640 + t64 - 1) / std::max<long>(t64, 1)));
+        static const int forced_split = [] {
+            const char *e = getenv("ML_STAGE1_SPLIT");
+            return e ? atoi(e) : 0;
+        }();
+        if (forced_split > 0) want_split1 = forced_split;
         pl.stage1_splits = zfold_splits(pl.fold_T, want_split1);
     }
     ML_TRY(pl.stage1.reserve((size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));

@@ -332,9 +332,11 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     }();
     // measured (tools/zgemm_sweep.py): 32 x 128 tiles (4 waves, 2 workgroups per CU) once they
     // give >= 2 workgroups per CU, else 32 x 64
-    const long wide = (long)((M + 31) / 32) * ((S + 127) / 128);
-    // (the on-the-fly-rotation variants 21 / 26 are 2-5 % faster than the table variants 9 / 8)
-    int pick = wide >= 512 ? 21 : 31;   // 31: K step 32 (half the barriers), +6 % on small grids
+    // 128 half-directions per tile read the aperture fewer times (once when S <= 128); take them
+    // whenever tiles x split-K slabs still give ~2 workgroups per CU, else 64-wide tiles.
+    // (the on-the-fly-rotation variants are 2-5 % faster than the table variants 9 / 8)
+    const long wide = (long)((M + 31) / 32) * ((S + 127) / 128) * ksplit;
+    int pick = wide >= 1024 ? 21 : (wide >= 480 ? 32 : 31);
     if (forced >= 0) pick = forced;
     switch (pick) {
         case 1: return launch_fold<64, 64, 2, 2>(stream, a, ksplit);
