@@ -54,8 +54,8 @@ __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT>
-__global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a) {
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB>
+__global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs a) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LDAS = BKT + 2, LDBS = BN + 16;
@@ -286,13 +286,14 @@ __global__ __launch_bounds__(WM *WN * 64, 2) void zfold_kernel(const FoldArgs a)
         }
 }
 
-template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16>
+
+template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16, int MINB = 2>
 static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT>), dim3(a.chunk * 8, ksplit),
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT, MINB>), dim3(a.chunk * 8, ksplit),
                        dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
@@ -336,7 +337,10 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     // whenever tiles x split-K slabs still give ~2 workgroups per CU, else 64-wide tiles.
     // (the on-the-fly-rotation variants are 2-5 % faster than the table variants 9 / 8)
     const long wide = (long)((M + 31) / 32) * ((S + 127) / 128) * ksplit;
-    int pick = wide >= 1024 ? 21 : (wide >= 480 ? 32 : 31);
+    static const int pick_wide = getenv("ML_ZFOLD_PICK_WIDE") ? atoi(getenv("ML_ZFOLD_PICK_WIDE")) : 40;
+    static const int pick_mid = getenv("ML_ZFOLD_PICK_MID") ? atoi(getenv("ML_ZFOLD_PICK_MID")) : 40;
+    static const int pick_small = getenv("ML_ZFOLD_PICK_SMALL") ? atoi(getenv("ML_ZFOLD_PICK_SMALL")) : 31;
+    int pick = wide >= 1024 ? pick_wide : (wide >= 480 ? pick_mid : pick_small);
     if (forced >= 0) pick = forced;
     switch (pick) {
         case 1: return launch_fold<64, 64, 2, 2>(stream, a, ksplit);
@@ -361,6 +365,10 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         case 31: return launch_fold<32, 64, 2, 2, 2, true, 32>(stream, a, ksplit);
         case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a, ksplit);
         case 33: return launch_fold<32, 64, 2, 2, 1, true, 32>(stream, a, ksplit);
+        case 48: return launch_fold<32, 64, 2, 4, 1, true, 32, 4>(stream, a, ksplit);
+        case 40: return launch_fold<32, 128, 2, 4, 1, true, 32, 4>(stream, a, ksplit);
+        case 42: return launch_fold<32, 128, 2, 4, 1, true, 16, 4>(stream, a, ksplit);
+        case 44: return launch_fold<32, 64, 2, 2, 1, true, 16, 4>(stream, a, ksplit);
         default: return launch_fold<64, 128, 2, 4>(stream, a, ksplit);
     }
 }
