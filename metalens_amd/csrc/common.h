@@ -177,6 +177,7 @@ struct ml_ctx {
 
     // near-field scratch
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
+    std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see note_row_extent(); valid only for synthesised fields
     bool row_first_valid = false;
     int nf_blocks = 0;

@@ -442,8 +442,16 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
         ML_TRY(refresh_table_desc(ctx));
         ML_TRY(refresh_ring_locations(ctx));
     }
-    ML_TRY(h2d(ctx, ctx->x_pts, x_pts, nx * sizeof(double)));
-    ML_TRY(h2d(ctx, ctx->y_pts, y_pts, ny * sizeof(double)));
+    // the grid usually repeats from call to call (sweeps over sources): upload only on change
+    auto grid_axis = [&](DevBuf &dev, std::vector<double> &host, const double *src, int n) -> int {
+        if ((int)host.size() == n && dev.p && memcmp(host.data(), src, n * sizeof(double)) == 0)
+            return ML_OK;
+        ML_HIP(hipStreamSynchronize(ctx->stream));   // an earlier async copy may still read `host`
+        host.assign(src, src + n);
+        return h2d(ctx, dev, host.data(), n * sizeof(double));
+    };
+    ML_TRY(grid_axis(ctx->x_pts, ctx->h_x_pts, x_pts, nx));
+    ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
     ML_TRY(ctx->fields.reserve(4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
@@ -452,8 +460,7 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
     ML_TRY(ctx->power.reserve(sizeof(double)));
     const size_t viol_bytes = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
-    ML_TRY(ctx->violations.reserve(viol_bytes));
-    ML_HIP(hipMemsetAsync(ctx->violations.p, 0, viol_bytes, ctx->stream));
+    ML_TRY(ctx->violations.reserve(viol_bytes));   // cleared by row_extent_kernel
     ML_TRY(ctx->row_first.reserve((size_t)nx * sizeof(int)));
     ctx->row_first_valid = true;
     return nearfield_launch(ctx, p, nx, ny);

@@ -47,36 +47,79 @@ __global__ __launch_bounds__(256) void twiddle_kernel(double2 *out, int rows, in
 
 // General phase table: out[r][c] = exp(-2 pi i frac(s * coord * u)) with
 // coord = coord0 + coord_step * (sample index), u = u_hi[dir] + u_lo[dir] (u_lo may be null),
-// (sample, dir) = (r, c) if sample_major else (c, r).  real_planes != 0 writes cos and +sin
+// (sample, dir) = (r, c) if sample_major else (c, r).  outc != null writes cos and +sin
 // into two REAL planes (outc, outs) instead of one complex array.
-__global__ __launch_bounds__(256) void phase_table_kernel(double2 *out, double *outc, double *outs,
-                                                          int rows, int cols, int sample_major,
-                                                          double coord0, double coord_step,
-                                                          double s_hi, double s_lo,
-                                                          const double *u_hi, const double *u_lo) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= cols) return;
-    const int sample = sample_major ? r : c;
-    const int dir = sample_major ? c : r;
-    const double kk = coord0 + coord_step * (double)sample;   // exact: (half-)integers
-    const double uh = u_hi[dir], ul = u_lo ? u_lo[dir] : 0.0;
-    const double p_hi = kk * s_hi;
-    const double p_lo = fma(kk, s_hi, -p_hi) + kk * s_lo;
+// Several phase tables in ONE launch (a plan needs 3-5 small ones; launched separately they
+// cost more in launch latency than in arithmetic).  Job j owns blocks [block0[j], block0[j+1]).
+constexpr int MAX_PHASE_JOBS = 6;
+struct PhaseJob {
+    double2 *out;
+    double *outc, *outs;
+    int rows, cols, sample_major, block0;
+    double coord0, coord_step, s_hi, s_lo;
+    const double *u_hi, *u_lo;
+};
+struct PhaseBatch {
+    PhaseJob job[MAX_PHASE_JOBS];
+    int n, blocks;
+};
+
+__global__ __launch_bounds__(256) void phase_batch_kernel(const PhaseBatch b) {
+    int j = 0;
+    for (int k = 1; k < b.n; ++k)
+        if ((int)blockIdx.x >= b.job[k].block0) j = k;
+    const PhaseJob &q = b.job[j];
+    const int per_row = (q.cols + 255) / 256;
+    const int local = blockIdx.x - q.block0;
+    const int r = local / per_row, c = (local % per_row) * 256 + threadIdx.x;
+    if (c >= q.cols) return;
+    const int sample = q.sample_major ? r : c;
+    const int dir = q.sample_major ? c : r;
+    const double kk = q.coord0 + q.coord_step * (double)sample;   // exact: (half-)integers
+    const double uh = q.u_hi[dir], ul = q.u_lo ? q.u_lo[dir] : 0.0;
+    const double p_hi = kk * q.s_hi;
+    const double p_lo = fma(kk, q.s_hi, -p_hi) + kk * q.s_lo;
     const double q_hi = p_hi * uh;
     const double q_lo = fma(p_hi, uh, -q_hi) + (p_lo * uh + p_hi * ul);
-    const double f = (q_hi - rint(q_hi)) + q_lo;
-    const double a_hi = f * ML_TWO_PI_HI;
-    const double ang = a_hi + (fma(f, ML_TWO_PI_HI, -a_hi) + f * ML_TWO_PI_LO);
+    const double fr = (q_hi - rint(q_hi)) + q_lo;
+    const double a_hi = fr * ML_TWO_PI_HI;
+    const double ang = a_hi + (fma(fr, ML_TWO_PI_HI, -a_hi) + fr * ML_TWO_PI_LO);
     double sn, cs;
     sincos(ang, &sn, &cs);
-    const size_t at = (size_t)r * cols + c;
-    if (outc) {
-        outc[at] = cs;
-        outs[at] = sn;
+    const size_t at = (size_t)r * q.cols + c;
+    if (q.outc) {
+        q.outc[at] = cs;
+        q.outs[at] = sn;
     } else {
-        out[at] = make_double2(cs, -sn);
+        q.out[at] = make_double2(cs, -sn);
     }
+}
+
+static void batch_add(PhaseBatch &b, double2 *out, double *outc, double *outs, int rows, int cols,
+                      int sample_major, double coord0, double coord_step, double s_hi, double s_lo,
+                      const double *u_hi, const double *u_lo) {
+    PhaseJob &q = b.job[b.n++];
+    q.out = out;
+    q.outc = outc;
+    q.outs = outs;
+    q.rows = rows;
+    q.cols = cols;
+    q.sample_major = sample_major;
+    q.block0 = b.blocks;
+    q.coord0 = coord0;
+    q.coord_step = coord_step;
+    q.s_hi = s_hi;
+    q.s_lo = s_lo;
+    q.u_hi = u_hi;
+    q.u_lo = u_lo;
+    b.blocks += ((cols + 255) / 256) * rows;
+}
+
+static int batch_launch(ml_ctx *ctx, const PhaseBatch &b) {
+    if (b.n == 0) return ML_OK;
+    hipLaunchKernelGGL(phase_batch_kernel, dim3(b.blocks), dim3(256), 0, ctx->stream, b);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
 }
 
 // out[b][c][r] = sum_s in[s][b][r][c] (complex), 32 x 32 tiles through LDS; `splits` split-K
@@ -291,30 +334,27 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
     const double s_hi = (double)s, s_lo = (double)(s - (long double)s_hi);
     const double half = 0.5 * (ny - 1);
     ProfScope scope(ctx, ML_K_TWIDDLE);
+    PhaseBatch pb;
+    pb.n = pb.blocks = 0;
     // cos / sin of kappa p_t v_s, p_t = (half - t) dy
-    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, T), dim3(256), 0, ctx->stream,
-                       (double2 *)nullptr, pl.fold_cm.as<double>(), pl.fold_sm.as<double>(), T, S,
-                       1, half, -1.0, s_hi, s_lo, pl.fold_v.as<double>(),
-                       pl.fold_v.as<double>() + S);
+    batch_add(pb, nullptr, pl.fold_cm.as<double>(), pl.fold_sm.as<double>(), T, S, 1, half, -1.0,
+              s_hi, s_lo, pl.fold_v.as<double>(), pl.fold_v.as<double>() + S);
     // rotation that advances the table by four samples: cos / sin of kappa (4 dy) v_s
-    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, 1), dim3(256), 0, ctx->stream,
-                       (double2 *)nullptr, pl.fold_r4.as<double>(), pl.fold_r4.as<double>() + S, 1,
-                       S, 1, 4.0, 0.0, s_hi, s_lo, pl.fold_v.as<double>(),
-                       pl.fold_v.as<double>() + S);
+    batch_add(pb, nullptr, pl.fold_r4.as<double>(), pl.fold_r4.as<double>() + S, 1, S, 1, 4.0, 0.0,
+              s_hi, s_lo, pl.fold_v.as<double>(), pl.fold_v.as<double>() + S);
     // input modulation E_k = exp(-i kappa p_k u_c), p_k = (k - half) dy; skipped when u_c == 0
     pl.fold_has_E = (uc != 0);
     if (pl.fold_has_E) {
         // the single direction u_c travels behind v in fold_v
         const double *tail = pl.fold_v.as<double>() + 2 * (size_t)S;
-        hipLaunchKernelGGL(phase_table_kernel, dim3((ny + 255) / 256, 1), dim3(256), 0, ctx->stream,
-                           pl.fold_E.as<double2>(), (double *)nullptr, (double *)nullptr, 1, ny, 0,
-                           -half, 1.0, s_hi, s_lo, tail, tail + 1);
+        batch_add(pb, pl.fold_E.as<double2>(), nullptr, nullptr, 1, ny, 0, -half, 1.0, s_hi, s_lo,
+                  tail, tail + 1);
     }
     // output diagonal D_j = exp(-i kappa delta u_j), delta = (half - ceil(ny/2)) dy
     const double delta = half - (double)(ny - ny / 2);
-    hipLaunchKernelGGL(phase_table_kernel, dim3((my + 255) / 256, 1), dim3(256), 0, ctx->stream,
-                       pl.fold_D.as<double2>(), (double *)nullptr, (double *)nullptr, 1, my, 1,
-                       delta, 0.0, s_hi, s_lo, pl.uy.as<double>(), (const double *)nullptr);
+    batch_add(pb, pl.fold_D.as<double2>(), nullptr, nullptr, 1, my, 1, delta, 0.0, s_hi, s_lo,
+              pl.uy.as<double>(), nullptr);
+    ML_TRY(batch_launch(ctx, pb));
     ML_HIP(hipGetLastError());
     pl.fold = true;
     pl.fold_T = T;
@@ -378,28 +418,25 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     const double s_hi = (double)sl, s_lo = (double)(sl - (long double)s_hi);
     const double half = 0.5 * (pl.nx_total - 1);
     const double *v_hi = pl.fold2_v.as<double>(), *v_lo = v_hi + S, *uc = v_hi + 2 * (size_t)S;
-    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, T), dim3(256), 0, ctx->stream,
-                       (double2 *)nullptr, pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), T, S,
-                       1, half - row0, -1.0, s_hi, s_lo, v_hi, v_lo);
-    hipLaunchKernelGGL(phase_table_kernel, dim3((S + 255) / 256, 1), dim3(256), 0, ctx->stream,
-                       (double2 *)nullptr, pl.fold2_r4.as<double>(), pl.fold2_r4.as<double>() + S, 1,
-                       S, 1, 4.0, 0.0, s_hi, s_lo, v_hi, v_lo);
+    PhaseBatch pb;
+    pb.n = pb.blocks = 0;
+    batch_add(pb, nullptr, pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), T, S, 1, half - row0,
+              -1.0, s_hi, s_lo, v_hi, v_lo);
+    batch_add(pb, nullptr, pl.fold2_r4.as<double>(), pl.fold2_r4.as<double>() + S, 1, S, 1, 4.0,
+              0.0, s_hi, s_lo, v_hi, v_lo);
     if (pl.fold2_has_E) {
         // E_k = exp(-i kappa p_k u_c) at the resident rows: one run, or two for a mirrored shard
         const int h = mirrored ? nxl / 2 : nxl;
-        hipLaunchKernelGGL(phase_table_kernel, dim3((h + 255) / 256, 1), dim3(256), 0, ctx->stream,
-                           pl.fold2_E.as<double2>(), (double *)nullptr, (double *)nullptr, 1, h, 0,
-                           row0 - half, 1.0, s_hi, s_lo, uc, uc + 1);
+        batch_add(pb, pl.fold2_E.as<double2>(), nullptr, nullptr, 1, h, 0, row0 - half, 1.0, s_hi,
+                  s_lo, uc, uc + 1);
         if (mirrored)
-            hipLaunchKernelGGL(phase_table_kernel, dim3((h + 255) / 256, 1), dim3(256), 0,
-                               ctx->stream, pl.fold2_E.as<double2>() + h, (double *)nullptr,
-                               (double *)nullptr, 1, h, 0,
-                               (double)(pl.nx_total - row0 - h) - half, 1.0, s_hi, s_lo, uc, uc + 1);
+            batch_add(pb, pl.fold2_E.as<double2>() + h, nullptr, nullptr, 1, h, 0,
+                      (double)(pl.nx_total - row0 - h) - half, 1.0, s_hi, s_lo, uc, uc + 1);
     }
     const double delta = half - (double)(pl.nx_total - pl.nx_total / 2);
-    hipLaunchKernelGGL(phase_table_kernel, dim3((mx + 255) / 256, 1), dim3(256), 0, ctx->stream,
-                       pl.fold2_D.as<double2>(), (double *)nullptr, (double *)nullptr, 1, mx, 1,
-                       delta, 0.0, s_hi, s_lo, pl.ux.as<double>(), (const double *)nullptr);
+    batch_add(pb, pl.fold2_D.as<double2>(), nullptr, nullptr, 1, mx, 1, delta, 0.0, s_hi, s_lo,
+              pl.ux.as<double>(), nullptr);
+    ML_TRY(batch_launch(ctx, pb));
     // G[(f, n1)][j] -> GT[(f, j)][n1]
     hipLaunchKernelGGL(ztranspose_kernel, dim3((my + 31) / 32, (nxl + 31) / 32, 4), dim3(256), 0,
                        ctx->stream, pl.stage1.as<double2>(), pl.fold2_gt.as<double2>(), nxl, my,

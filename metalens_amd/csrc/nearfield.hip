@@ -13,6 +13,7 @@
 //                                            amplitudes of one grid node
 //   ring arrays     float64 [n_rings]        + a uniform-in-r lookup table for the ring search
 //   centre cells    sorted by spatial bin    (uniform grid, exact nearest neighbour)
+#include <algorithm>
 #include <cstdlib>
 
 #include "nearfield_dev.h"
@@ -221,33 +222,35 @@ __global__ __launch_bounds__(256) void nearfield_exact_kernel(const NfArgs a) {
 // Per aperture row: how far from the row's two ends the first sample inside the lens is,
 // min(j, ny-1-j).  Samples outside the lens are exactly zero, so the far-field GEMM skips that
 // outer part of each row (zfold.hip).  Inside-the-lens is the kernels' own test
-// sqrt(x^2 + y^2) <= outer boundary, which is monotone in |y|: two binary searches per row.
-__global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a) {
+// sqrt(x^2 + y^2) <= outer boundary, which is monotone in |y|.
+// Runs BEFORE the synthesis kernel and also clears the bound-violation keys (one launch less
+// than a separate memset).
+__global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a, int n_viol_keys) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_viol_keys) a.viol[i] = 0ull;
     if (i >= a.nx) return;
     const double x = a.x_pts[i], rmax = a.B[a.n_rings];
     auto inside = [&](int j) { return !(sqrt(x * x + a.y_pts[j] * a.y_pts[j]) > rmax); };
-    // sample closest to y = 0 (y_pts ascends)
-    int lo = 0, hi = a.ny - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi) / 2;
-        if (a.y_pts[mid] < 0.0) lo = mid + 1; else hi = mid;
-    }
-    int jc = lo;
-    if (jc > 0 && fabs(a.y_pts[jc - 1]) < fabs(a.y_pts[jc])) --jc;
+    // The grid is uniform (the host checks the pitch), so the chord ends are known to +/- 1
+    // sample in closed form; the kernels' own test then settles the last sample (a few loads
+    // instead of three dependent binary searches).  A non-uniform y_pts only costs more steps.
+    const int ny = a.ny;
+    const double y0 = a.y_pts[0], dy = ny > 1 ? (a.y_pts[ny - 1] - y0) / (ny - 1) : 1.0;
+    const double half_chord = sqrt(fmax(rmax * rmax - x * x, 0.0));
+    auto clampi = [&](double v) { return (int)fmin(fmax(v, 0.0), (double)(ny - 1)); };
+    // sample closest to y = 0: if it is outside, the whole row is
+    int jc = clampi(rint(-y0 / dy));
+    while (jc > 0 && fabs(a.y_pts[jc - 1]) < fabs(a.y_pts[jc])) --jc;
+    while (jc < ny - 1 && fabs(a.y_pts[jc + 1]) < fabs(a.y_pts[jc])) ++jc;
     int first = 0x7f7f7f7f;
     if (inside(jc)) {
-        int l = 0, r = jc;               // smallest j in [0, jc] that is inside
-        while (l < r) {
-            const int mid = (l + r) / 2;
-            if (inside(mid)) r = mid; else l = mid + 1;
-        }
-        int l2 = jc, r2 = a.ny - 1;      // largest j in [jc, ny-1] that is inside
-        while (l2 < r2) {
-            const int mid = (l2 + r2 + 1) / 2;
-            if (inside(mid)) l2 = mid; else r2 = mid - 1;
-        }
-        first = min(l, a.ny - 1 - l2);
+        int lo = min(clampi(ceil((-half_chord - y0) / dy)), jc);
+        int hi = max(clampi(floor((half_chord - y0) / dy)), jc);
+        while (lo > 0 && inside(lo - 1)) --lo;
+        while (!inside(lo)) ++lo;                  // smallest inside index (<= jc)
+        while (hi < ny - 1 && inside(hi + 1)) ++hi;
+        while (!inside(hi)) --hi;                  // largest inside index (>= jc)
+        first = min(lo, ny - 1 - hi);
     }
     a.row_first[i] = first;
 }
@@ -329,6 +332,10 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
     fill_nf_args(ctx, p, nx, ny, a);
     const dim3 grid((ny + 255) / 256, nx);
     int n_partials = (int)(grid.x * grid.y);
+    // row extents for the far-field GEMM + reset of the violation keys, ahead of the synthesis
+    const int n_keys = (MAX_SLOTS + 1) * MAX_ORDERS * 6;
+    hipLaunchKernelGGL(row_extent_kernel, dim3((std::max(nx, n_keys) + 255) / 256), dim3(256), 0,
+                       ctx->stream, a, n_keys);
     if (use_exact_kernel()) {
         ProfScope scope(ctx, ML_K_NEARFIELD);
         hipLaunchKernelGGL(nearfield_exact_kernel, grid, dim3(256), 0, ctx->stream, a);
@@ -336,7 +343,6 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
         ProfScope scope(ctx, ML_K_NEARFIELD);
         ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
     }
-    hipLaunchKernelGGL(row_extent_kernel, dim3((nx + 255) / 256), dim3(256), 0, ctx->stream, a);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream,
                        ctx->partial_power.as<double>(), n_partials, ctx->power.as<double>());
     ML_HIP(hipGetLastError());
