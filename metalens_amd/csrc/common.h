@@ -72,6 +72,7 @@ struct DevBuf {
 
 constexpr int MAX_SLOTS = 32;      // grating collections per lens (+1 centre)
 constexpr int MAX_ORDERS = 32;     // diffraction orders per table
+constexpr int PACKED_AXIS = 8;     // nodes of an inline (ux or uy) table axis, see TableDesc
 
 // Device-side view of one packed table (GratingCollection or HexGridSet).
 struct TableDesc {
@@ -83,13 +84,19 @@ struct TableDesc {
     double bounds[6];
     double center_kx[MAX_ORDERS];  // centre only: ox*2*pi/x_period, per order
     double center_ky[MAX_ORDERS];
+    // (ux, uy) axes inline for the fast kernel when both have <= PACKED_AXIS nodes: node a for
+    // a <= n-2 (+inf beyond, so a running compare never selects a padded node) and
+    // 1 / (node[a+1] - node[a]); one round of independent loads instead of a pointer chase
+    // followed by a dependent search loop
+    int packed;
+    double ax0[PACKED_AXIS], inv0[PACKED_AXIS], ax1[PACKED_AXIS], inv1[PACKED_AXIS];
 };
 
 struct TableSlot {
     bool present = false;
     int n0 = 0, n1 = 0, n2 = 0, n_orders = 0;
     DevBuf axis0, axis1, values, order_k;
-    std::vector<double> h_axis2;
+    std::vector<double> h_axis0, h_axis1, h_axis2;
     std::vector<double> h_order_k;
     std::vector<double> h_values;   // host copy, for the per-ring pre-interpolation
     double bounds[6] = {0, 0, 0, 0, 0, 0};

@@ -82,6 +82,18 @@ static int refresh_table_desc(ml_ctx *ctx) {
         d.n2 = t.n2;
         d.n_orders = t.n_orders;
         for (int k = 0; k < 6; ++k) d.bounds[k] = t.bounds[k];
+        d.packed = (t.n0 >= 2 && t.n1 >= 2 && t.n0 <= PACKED_AXIS && t.n1 <= PACKED_AXIS) ? 1 : 0;
+        if (d.packed) {
+            auto pack = [](const std::vector<double> &axis, double *node, double *inv) {
+                const int n = (int)axis.size();
+                for (int a = 0; a < PACKED_AXIS; ++a) {
+                    node[a] = a <= n - 2 ? axis[a] : INFINITY;
+                    inv[a] = a <= n - 2 ? 1.0 / (axis[a + 1] - axis[a]) : 0.0;
+                }
+            };
+            pack(t.h_axis0, d.ax0, d.inv0);
+            pack(t.h_axis1, d.ax1, d.inv1);
+        }
         if (s == MAX_SLOTS) {
             // nearfield.py:395-396: ox * 2*pi/x_period - a scalar in the reference
             for (int o = 0; o < t.n_orders; ++o) {
@@ -297,6 +309,8 @@ int ml_upload_table(ml_ctx *ctx, int slot, const double *axis0, int n0, const do
     t.n1 = n1;
     t.n2 = n2;
     t.n_orders = n_orders;
+    t.h_axis0.assign(axis0, axis0 + n0);
+    t.h_axis1.assign(axis1, axis1 + n1);
     t.h_axis2.assign(axis2, axis2 + n2);
     t.h_order_k.assign(order_k, order_k + 2 * n_orders);
     t.h_values.assign(values, values + (size_t)n_orders * n0 * n1 * n2 * 4 * 2);

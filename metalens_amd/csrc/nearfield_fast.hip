@@ -68,6 +68,33 @@ __device__ __forceinline__ void locate_fast(const double *axis, int n, double x,
     t = (x - lo) * recip(hi - lo);
 }
 
+// the same for an inline axis (TableDesc::ax / inv): independent loads, running select
+__device__ __forceinline__ void locate_packed(const double *node, const double *inv, double x,
+                                              int &i, double &t) {
+    double lo = node[0], r = inv[0];
+    i = 0;
+#pragma unroll
+    for (int a = 1; a < PACKED_AXIS - 1; ++a) {
+        const double na = node[a], ra = inv[a];
+        const bool c = na <= x;
+        lo = c ? na : lo;
+        r = c ? ra : r;
+        i += c ? 1 : 0;
+    }
+    t = (x - lo) * r;
+}
+
+__device__ __forceinline__ void locate_uv(const TableDesc &T, double u, double v, int &i0,
+                                          double &t0, int &i1, double &t1) {
+    if (T.packed) {
+        locate_packed(T.ax0, T.inv0, u, i0, t0);
+        locate_packed(T.ax1, T.inv1, v, i1, t1);
+    } else {
+        locate_fast(T.axis0, T.n0, u, i0, t0);
+        locate_fast(T.axis1, T.n1, v, i1, t1);
+    }
+}
+
 struct Acc {
     c2 Ex, Ey, Hx, Hy;
 };
@@ -174,8 +201,7 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 const double Hw_x = fma(Hy_i, cosr, -Hx_i * sinr);   // H along y' <-> x table
                 int i0, i1;
                 double t0, t1;
-                locate_fast(T.axis0, T.n0, uxp, i0, t0);
-                locate_fast(T.axis1, T.n1, uyp, i1, t1);
+                locate_uv(T, uxp, uyp, i0, t0, i1, t1);
                 const double *ok = a.ring_ok + a.ring_ok_off[ring];
                 const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
                 const int stride1 = 4, stride0 = T.n1 * 4, stride_o = T.n0 * T.n1 * 4;
@@ -218,8 +244,7 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 const int which = min(max(a.cwhich[s], 0), T.n2 - 1);
                 int i0, i1;
                 double t0, t1;
-                locate_fast(T.axis0, T.n0, ux, i0, t0);
-                locate_fast(T.axis1, T.n1, uy, i1, t1);
+                locate_uv(T, ux, uy, i0, t0, i1, t1);
                 // centre table, amplitude-major: [order][i0][i1][4][K]
                 const double2 *tab = a.center_tab;
                 const int stride1 = T.n2 * 4, stride0 = T.n1 * T.n2 * 4;
