@@ -225,8 +225,9 @@ def main():
             'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
             'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
-            # PMC, profiles/r01c_summary.txt: FETCH_SIZE x2 + WRITE_SIZE per launch [bytes]
-            'traffic': 303.5e6 if default_cfg else None,
+            # PMC, profiles/r01e_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.3 MB: two
+            # split-K slabs) per launch [bytes]
+            'traffic': 345.5e6 if default_cfg else None,
             'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
             'executed_flops_per_launch': executed,
             'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
@@ -241,8 +242,8 @@ def main():
         roofs['nearfield'] = {
             'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            # PMC, profiles/r01c_summary.txt: FETCH_SIZE x2 (51.8 MB) + WRITE_SIZE (269.0 MB) per launch
-            'traffic': 320.8e6 if default_cfg else None,
+            # PMC, profiles/r01e_summary.txt: FETCH_SIZE x2 (51.6 MB) + WRITE_SIZE (269.0 MB) per launch
+            'traffic': 320.5e6 if default_cfg else None,
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
             'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by L1 '
                     'gather throughput and fp64 VALU work, not by HBM (DESIGN.md 4.1)'}
