@@ -36,6 +36,7 @@ import numpy as np  # noqa: E402
 # fp64); MI355X_MICROARCH.md lists no fp64 MFMA row.  = 256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk
 # (one v_mfma_f64_16x16x4_f64 = 2048 flop per 64 cycles per SIMD).
 FP64_MFMA_PEAK_TFLOPS = 78.6
+FP32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
@@ -110,6 +111,9 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=1024,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--check', type=int, default=1, help='verify a sample against the oracle')
+    ap.add_argument('--precision', choices=('f64', 'f32'), default='f64',
+                    help="arithmetic of the far-field GEMMs: f64 (BASELINE metric, 1e-12) or f32 "
+                         "(fp32 matrix cores, 1e-4; near field, storage and projection stay fp64)")
     args = ap.parse_args()
 
     from metalens_amd import _lib, dist
@@ -133,7 +137,7 @@ def main():
     source = (0.0, 0.0, -lens['source_distance'], 'x')
     hp = HotPath(source, args.wavelength, lens['lens_periphery_summary'],
                  lens['lens_center_summary'], lens['hexgridset'], x, x, u, u, ctx=ctx,
-                 rank=rank, world=world)
+                 rank=rank, world=world, precision=args.precision)
 
     for _ in range(args.warmup):
         hp.step()
@@ -182,7 +186,9 @@ def main():
         'unit': 'pair-evals/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
-        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'vs_baseline': None,
+        'dtype': 'f64' if args.precision == 'f64' else 'f32 GEMMs (f64 near field and storage)',
+        'data': 'synthetic',
         'config': {'workload': '%.3g mm dia NA=%.2g lens, lambda=%.0f nm, %dx%d aperture window at '
                                'pitch lambda/2.2 -> %dx%d far-field directions, fp64, on-axis '
                                'x-dipole at the focus'
@@ -206,6 +212,7 @@ def main():
     s1 = prof['zgemm_stage1']
     if s1['launches']:
         flops = 8.0 * 4 * local_rows * side * u.size
+        mfma_peak = FP64_MFMA_PEAK_TFLOPS if args.precision == 'f64' else FP32_MFMA_PEAK_TFLOPS
         avg_ms = s1['total_ms'] / s1['launches']
         achieved = flops / (avg_ms * 1e-3) / 1e12
         folded = _lib.c_int(0)
@@ -223,17 +230,19 @@ def main():
         roofs['zgemm_stage1'] = {
             'bound': 'mfma',
             'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
-            'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / FP64_MFMA_PEAK_TFLOPS,
+            'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
+            'frac': achieved / mfma_peak,
             # PMC, profiles/r01e_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.3 MB: two
             # split-K slabs) per launch [bytes]
-            'traffic': 345.5e6 if default_cfg else None,
+            'traffic': 345.5e6 if default_cfg and args.precision == 'f64' else None,
             'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
             'executed_flops_per_launch': executed,
-            'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / mfma_peak,
             'note': 'achieved = algorithmic flops (8 per complex MAC) / time; the kernel executes '
                     'executed_flops_per_launch of them, so frac can exceed 1; mfma_pipe_frac is '
                     'the matrix-pipe occupancy at 2.4 GHz'}
+        if args.precision == 'f32':
+            roofs['zgemm_stage1']['kernel'] += ', fp32 matrix cores'
     nf = prof['nearfield']
     if nf['launches']:
         nf_bytes = 64.0 * local_rows * side

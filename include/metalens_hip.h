@@ -184,6 +184,16 @@ int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double
 /* which stage-1 kernel the current plan uses: *stage1_kernel = 0 generic complex GEMM (3M),
  * 1 folded even/odd real-kernel GEMM (centre-symmetric uy grid).                          */
 int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel);
+/* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",
+ * configs[4] "fp32 GEMM-cast MFMA path").  ML_PRECISION_F64 (default): fp64 matrix cores.
+ * ML_PRECISION_F32_GEMM: the folded GEMMs of both stages round their operands to fp32 and
+ * accumulate in fp32 on v_mfma_f32_16x16x4_f32 (twice the matrix rate); near-field synthesis,
+ * phase reduction of the twiddle seeds, storage and the projection stay fp64.  Direction grids
+ * that are not centre-symmetric (generic complex GEMM) are always computed in fp64.  The
+ * setting belongs to the context and persists across ml_farfield_plan calls.               */
+#define ML_PRECISION_F64 0
+#define ML_PRECISION_F32_GEMM 1
+int ml_farfield_set_precision(ml_ctx *ctx, int precision);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
  * ml_comm_unique_id fills id[128] on rank 0; the host passes it to the other ranks by

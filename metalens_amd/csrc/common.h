@@ -183,6 +183,7 @@ struct ml_ctx {
     ml::DevBuf lattice_in;   // staging for ml_farfield_lattice_power
 
     // near-field scratch
+    int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see note_row_extent(); valid only for synthesised fields
@@ -226,7 +227,7 @@ int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
                  const double *D, double *C, int64_t ldc, int my, const int *row_first = nullptr,
-                 int nxl = 1, int ksplit = 1, int64_t split_stride = 0);
+                 int nxl = 1, int ksplit = 1, int64_t split_stride = 0, bool f32 = false);
 // number of split-K slabs zfold_stage1 will actually write for (T, ksplit)
 int zfold_splits(int T, int ksplit);
 // comm.hip

@@ -447,7 +447,7 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
                         pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), pl.fold2_r4.as<double>(),
                         T, S, pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr,
                         pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx, nullptr, 1,
-                        want_split, (int64_t)4 * my * mx));
+                        want_split, (int64_t)4 * my * mx, ctx->gemm_f32 != 0));
     Alpha4f al;
     for (int k = 0; k < 4; ++k) al.v[k] = alpha[k];
     hipLaunchKernelGGL(zunfold_out_kernel, dim3((mx + 31) / 32, (my + 31) / 32, 4), dim3(256), 0,
@@ -590,7 +590,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                                 pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
                                 pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my,
                                 ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl,
-                                want_split1, (int64_t)4 * nxl * my));
+                                want_split1, (int64_t)4 * nxl * my, ctx->gemm_f32 != 0));
         else
             ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
                          pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
@@ -729,6 +729,14 @@ int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel) {
         return ML_ESTATE;
     }
     *stage1_kernel = ctx->plan.fold ? 1 : 0;
+    return ML_OK;
+}
+
+int ml_farfield_set_precision(ml_ctx *ctx, int precision) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(precision == ML_PRECISION_F64 || precision == ML_PRECISION_F32_GEMM,
+               "unknown precision %d", precision);
+    ctx->gemm_f32 = precision == ML_PRECISION_F32_GEMM;
     return ML_OK;
 }
 

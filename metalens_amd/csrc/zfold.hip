@@ -30,6 +30,29 @@
 namespace ml {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Compute type of the real GEMMs.  double: v_mfma_f64_16x16x4_f64.  float (opt-in per plan,
+// ml_farfield_set_precision): the fields stay complex128 in HBM and are rounded to fp32 when
+// the folded planes are staged in LDS; cos/sin seeds are rounded from the double-double-reduced
+// tables, rotated in fp32 (re-seeded every 64 samples), products accumulate in fp32 on
+// v_mfma_f32_16x16x4_f32 (twice the matrix rate) and the result is written back as complex128.
+// Same A/B fragment maps; the C/D row map differs (cdna_hip_programming.md, fragment layout).
+template <typename CT> struct Mma;
+template <> struct Mma<double> {
+    typedef v4d acc_t;
+    static __device__ __forceinline__ acc_t mma(double x, double y, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+template <> struct Mma<float> {
+    typedef v4f acc_t;
+    static __device__ __forceinline__ acc_t mma(float x, float y, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
+};
 
 struct FoldArgs {
     const double2 *A;       // [M][ny] complex, k contiguous
@@ -54,8 +77,10 @@ __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB>
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT>
 __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs a) {
+    typedef typename Mma<CT>::acc_t acc_t;
+    static_assert(FLY || sizeof(CT) == 8, "the table-operand variants are fp64 only");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LDAS = BKT + 2, LDBS = BN + 16;
@@ -63,7 +88,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
     constexpr int B_PER = BKT * BN / 2 / NT;      // double2 per thread per plane
     static_assert(BM * BKT % NT == 0 && (BKT * BN / 2) % NT == 0, "tile/threads mismatch");
 
-    __shared__ double sGer[BM * LDAS], sGei[BM * LDAS], sGor[BM * LDAS], sGoi[BM * LDAS];
+    __shared__ CT sGer[BM * LDAS], sGei[BM * LDAS], sGor[BM * LDAS], sGoi[BM * LDAS];
     __shared__ __align__(16) double sC[FLY ? 2 : BKT * LDBS], sS[FLY ? 2 : BKT * LDBS];
 
     const int b = blockIdx.x;
@@ -143,10 +168,10 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
         for (int p = 0; p < A_PER; ++p) {
             const int e = tid + p * NT;
             const int at = (e / BKT) * LDAS + e % BKT;
-            sGer[at] = gp[p].x + gm[p].x;
-            sGei[at] = gp[p].y + gm[p].y;
-            sGor[at] = gp[p].x - gm[p].x;
-            sGoi[at] = gp[p].y - gm[p].y;
+            sGer[at] = (CT)(gp[p].x + gm[p].x);
+            sGei[at] = (CT)(gp[p].y + gm[p].y);
+            sGor[at] = (CT)(gp[p].x - gm[p].x);
+            sGoi[at] = (CT)(gp[p].y - gm[p].y);
         }
 #pragma unroll
         for (int p = 0; p < (FLY ? 0 : B_PER); ++p) {
@@ -157,15 +182,15 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
         }
     };
 
-    v4d pcr[TM][TN], pci[TM][TN], psr[TM][TN], psi[TM][TN];
+    acc_t pcr[TM][TN], pci[TM][TN], psr[TM][TN], psi[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            pcr[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-            pci[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-            psr[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-            psi[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+            pcr[i][j] = (acc_t){0, 0, 0, 0};
+            pci[i][j] = (acc_t){0, 0, 0, 0};
+            psr[i][j] = (acc_t){0, 0, 0, 0};
+            psi[i][j] = (acc_t){0, 0, 0, 0};
         }
 
     // FLY: the cos/sin operand never touches LDS.  Lane (fk, frow) needs, for each of its TN
@@ -174,22 +199,22 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
     // after every s-step, and re-seeds it from the exact table every RESEED samples (rounding
     // drift stays below ~16 rotations).
     constexpr int RESEED = 64;
-    double bc[TN], bs[TN], r4c[TN], r4s[TN], seed_c[TN], seed_s[TN];
+    CT bc[TN], bs[TN], r4c[TN], r4s[TN], seed_c[TN], seed_s[TN];
     auto load_seed = [&](int t0) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int s = s0 + (wn * TN + j) * 16 + frow, t = t0 + fk;
             const bool ok = s < a.S && t < a.T;
-            seed_c[j] = ok ? a.Cm[(int64_t)t * a.S + s] : 0.0;
-            seed_s[j] = ok ? a.Sm[(int64_t)t * a.S + s] : 0.0;
+            seed_c[j] = (CT)(ok ? a.Cm[(int64_t)t * a.S + s] : 0.0);
+            seed_s[j] = (CT)(ok ? a.Sm[(int64_t)t * a.S + s] : 0.0);
         }
     };
     if (FLY) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int s = s0 + (wn * TN + j) * 16 + frow;
-            r4c[j] = s < a.S ? a.R4c[s] : 1.0;
-            r4s[j] = s < a.S ? a.R4s[s] : 0.0;
+            r4c[j] = (CT)(s < a.S ? a.R4c[s] : 1.0);
+            r4s[j] = (CT)(s < a.S ? a.R4s[s] : 0.0);
         }
         load_seed(t_begin);
     }
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
         }
 #pragma unroll UNR
         for (int s = 0; s < BKT / 4; ++s) {
-            double ger[TM], gei[TM], gor[TM], goi[TM], cc[TN], ss[TN];
+            CT ger[TM], gei[TM], gor[TM], goi[TM], cc[TN], ss[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int at = ((wm * TM + i) * 16 + frow) * LDAS + s * 4 + fk;
@@ -227,41 +252,40 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
                     cc[j] = bc[j];
                     ss[j] = bs[j];
                     // advance t by 4: angle decreases by 4 kappa dy v_s
-                    const double nc = fma(bc[j], r4c[j], bs[j] * r4s[j]);
-                    const double ns = fma(bs[j], r4c[j], -bc[j] * r4s[j]);
+                    const CT nc = fma(bc[j], r4c[j], bs[j] * r4s[j]);
+                    const CT ns = fma(bs[j], r4c[j], -bc[j] * r4s[j]);
                     bc[j] = nc;
                     bs[j] = ns;
                 } else {
                     const int at = (s * 4 + fk) * LDBS + (wn * TN + j) * 16 + frow;
-                    cc[j] = sC[at];
-                    ss[j] = sS[at];
+                    cc[j] = (CT)sC[at];
+                    ss[j] = (CT)sS[at];
                 }
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    pcr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ger[i], cc[j], pcr[i][j], 0, 0, 0);
+                    pcr[i][j] = Mma<CT>::mma(ger[i], cc[j], pcr[i][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    pci[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gei[i], cc[j], pci[i][j], 0, 0, 0);
+                    pci[i][j] = Mma<CT>::mma(gei[i], cc[j], pci[i][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    psr[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(gor[i], ss[j], psr[i][j], 0, 0, 0);
+                    psr[i][j] = Mma<CT>::mma(gor[i], ss[j], psr[i][j]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    psi[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(goi[i], ss[j], psi[i][j], 0, 0, 0);
+                    psi[i][j] = Mma<CT>::mma(goi[i], ss[j], psi[i][j]);
         }
     }
 
-    // epilogue: unfold the directions.  f64 MFMA C/D layout: col = lane & 15,
-    // row = (lane >> 4) + 4 * reg.
+    // epilogue: unfold the directions (C/D layout: col = lane & 15, row = Mma<CT>::row)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -272,10 +296,10 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             const double2 dm = a.D[jm], dp = a.D[jp];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + (wm * TM + i) * 16 + (lane >> 4) + 4 * r;
+                const int row = m0 + (wm * TM + i) * 16 + Mma<CT>::row(lane, r);
                 if (row >= a.M) continue;
-                const double cr = pcr[i][j][r], ci = pci[i][j][r];
-                const double sr = psr[i][j][r], si = psi[i][j][r];
+                const double cr = (double)pcr[i][j][r], ci = (double)pci[i][j][r];
+                const double sr = (double)psr[i][j][r], si = (double)psi[i][j][r];
                 // +v: Pc - i Ps ; -v: Pc + i Ps
                 const double2 plus = make_double2(cr + si, ci - sr);
                 const double2 minus = make_double2(cr - si, ci + sr);
@@ -287,13 +311,14 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
 }
 
 
-template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16, int MINB = 2>
+template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16, int MINB = 2,
+          typename CT = double>
 static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT, MINB>), dim3(a.chunk * 8, ksplit),
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT>), dim3(a.chunk * 8, ksplit),
                        dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
@@ -303,7 +328,7 @@ static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
                  const double *D, double *C, int64_t ldc, int my, const int *row_first, int nxl,
-                 int ksplit, int64_t split_stride) {
+                 int ksplit, int64_t split_stride, bool f32) {
     FoldArgs a;
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
@@ -331,45 +356,39 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         const char *e = getenv("ML_ZFOLD_TILE");
         return e ? atoi(e) : -1;
     }();
-    // measured (tools/zgemm_sweep.py): 32 x 128 tiles (4 waves, 2 workgroups per CU) once they
-    // give >= 2 workgroups per CU, else 32 x 64
-    // 128 half-directions per tile read the aperture fewer times (once when S <= 128); take them
-    // whenever tiles x split-K slabs still give ~2 workgroups per CU, else 64-wide tiles.
-    // (the on-the-fly-rotation variants are 2-5 % faster than the table variants 9 / 8)
+    // Measured (tools/zfold_shape_sweep.py, bench.py): 128 half-directions per tile read the
+    // aperture fewer times (once when S <= 128); 8 waves per workgroup at 4 waves per SIMD beat 4
+    // waves at 2 by 6-9 %; take them whenever tiles x split-K slabs give ~2 workgroups per CU,
+    // else 64-wide tiles of 4 waves (the folded stage 2: few rows, long reduction).  The
+    // on-the-fly-rotation variants are 2-5 % faster than the table variants (8, 9).
     const long wide = (long)((M + 31) / 32) * ((S + 127) / 128) * ksplit;
     static const int pick_wide = getenv("ML_ZFOLD_PICK_WIDE") ? atoi(getenv("ML_ZFOLD_PICK_WIDE")) : 40;
-    static const int pick_mid = getenv("ML_ZFOLD_PICK_MID") ? atoi(getenv("ML_ZFOLD_PICK_MID")) : 40;
     static const int pick_small = getenv("ML_ZFOLD_PICK_SMALL") ? atoi(getenv("ML_ZFOLD_PICK_SMALL")) : 31;
-    int pick = wide >= 1024 ? pick_wide : (wide >= 480 ? pick_mid : pick_small);
+    int pick = wide >= 480 ? pick_wide : pick_small;
     if (forced >= 0) pick = forced;
+    if (f32) {
+        static const int f32_wide = getenv("ML_ZFOLD_F32_WIDE") ? atoi(getenv("ML_ZFOLD_F32_WIDE")) : 140;
+        static const int f32_small = getenv("ML_ZFOLD_F32_SMALL") ? atoi(getenv("ML_ZFOLD_F32_SMALL")) : 132;
+        switch (wide >= 480 ? f32_wide : f32_small) {
+            case 131: return launch_fold<32, 64, 2, 2, 2, true, 32, 2, float>(stream, a, ksplit);
+            case 132: return launch_fold<32, 64, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+            case 141: return launch_fold<64, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+            case 142: return launch_fold<64, 128, 2, 4, 2, true, 32, 4, float>(stream, a, ksplit);
+            case 143: return launch_fold<64, 128, 4, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+            default: return launch_fold<32, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+        }
+    }
     switch (pick) {
-        case 1: return launch_fold<64, 64, 2, 2>(stream, a, ksplit);
-        case 2: return launch_fold<32, 64, 2, 2>(stream, a, ksplit);
-        case 3: return launch_fold<128, 64, 4, 2>(stream, a, ksplit);
-        case 4: return launch_fold<64, 64, 2, 2, 1>(stream, a, ksplit);
-        case 5: return launch_fold<64, 64, 2, 2, 2>(stream, a, ksplit);
-        case 6: return launch_fold<64, 128, 2, 4, 1>(stream, a, ksplit);
-        case 7: return launch_fold<64, 128, 2, 4, 2>(stream, a, ksplit);
         case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a, ksplit);
         case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a, ksplit);
-        case 10: return launch_fold<32, 128, 2, 2, 1>(stream, a, ksplit);
-        case 20: return launch_fold<32, 128, 2, 2, 2, true>(stream, a, ksplit);
         case 21: return launch_fold<32, 128, 2, 2, 1, true>(stream, a, ksplit);
         case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a, ksplit);
-        case 23: return launch_fold<64, 64, 2, 2, 1, true>(stream, a, ksplit);
-        case 24: return launch_fold<64, 64, 2, 2, 2, true>(stream, a, ksplit);
-        case 25: return launch_fold<64, 128, 2, 4, 2, true>(stream, a, ksplit);
         case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a, ksplit);
-        case 27: return launch_fold<64, 128, 2, 2, 1, true>(stream, a, ksplit);
-        case 30: return launch_fold<32, 128, 2, 2, 2, true, 32>(stream, a, ksplit);
         case 31: return launch_fold<32, 64, 2, 2, 2, true, 32>(stream, a, ksplit);
         case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a, ksplit);
-        case 33: return launch_fold<32, 64, 2, 2, 1, true, 32>(stream, a, ksplit);
-        case 48: return launch_fold<32, 64, 2, 4, 1, true, 32, 4>(stream, a, ksplit);
-        case 40: return launch_fold<32, 128, 2, 4, 1, true, 32, 4>(stream, a, ksplit);
         case 42: return launch_fold<32, 128, 2, 4, 1, true, 16, 4>(stream, a, ksplit);
         case 44: return launch_fold<32, 64, 2, 2, 1, true, 16, 4>(stream, a, ksplit);
-        default: return launch_fold<64, 128, 2, 4>(stream, a, ksplit);
+        default: return launch_fold<32, 128, 2, 4, 1, true, 32, 4>(stream, a, ksplit);
     }
 }
 

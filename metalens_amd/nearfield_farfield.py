@@ -7,6 +7,9 @@ per-bin projection (``farfield_from_nearfield_helper``, nearfield_farfield.py:77
 runs in the HIP kernel ``project_kernel``; the axis bookkeeping, ``fftshift`` and the
 finite-sum of :68-74 stay in NumPy exactly as the reference has them.
 
+``FarfieldTransform(..., precision='f32')`` runs the GEMMs on the fp32 matrix cores
+(BASELINE.json tolerance 1e-4 instead of 1e-12); storage and everything else stay fp64.
+
 ``FarfieldTransform`` / ``farfield_direct`` are new: they evaluate the
 aperture -> direction sum that the reference derives in its docstring
 (nearfield_farfield.py:97-138) for an ARBITRARY grid (or list) of direction
@@ -82,8 +85,10 @@ class FarfieldTransform:
     """
 
     def __init__(self, num_x_total, num_y, dxp, dyp, wavelength, n_glass, ux, uy,
-                 pair_list=False, ctx=None):
+                 pair_list=False, ctx=None, precision=None):
         self.ctx = ctx or _lib.default_context()
+        if precision is not None:   # 'f64' | 'f32' (GEMM arithmetic; a property of the context)
+            self.ctx.set_precision(precision)
         self.ux = _lib.f64(np.ravel(ux))
         self.uy = _lib.f64(np.ravel(uy))
         self.pair_list = bool(pair_list)

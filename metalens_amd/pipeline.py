@@ -18,8 +18,10 @@ from .nearfield import _check_axis, _raise_violation, nearfield_params
 class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
-                 c0=None, Z0=None, ctx=None, rank=0, world=1):
+                 c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None):
         self.ctx = ctx or _lib.default_context()
+        if precision is not None:   # 'f64' | 'f32': arithmetic of the far-field GEMMs
+            self.ctx.set_precision(precision)
         self.rank, self.world = rank, world
         self.c0 = constants.c0 if c0 is None else c0
         self.Z0 = constants.Z0 if Z0 is None else Z0

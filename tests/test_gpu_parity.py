@@ -417,3 +417,69 @@ def test_full_size_roundtrip_properties(ma):
     assert np.abs(got['Lx'] - 2 * want).max() <= TOL * 2 * scale  # Lx = F[Ey]
     assert np.abs(got['Ny'] - (-want)).max() <= TOL * scale      # Ny = F[Hx]
     assert np.abs(got['Nx'] - (-0.5 * want)).max() <= TOL * scale  # Nx = -F[Hy]
+
+
+# ---- fp32 GEMM mode (BASELINE.json: |dE|/|E| < 1e-4 for the fp32 path) ---------------------
+TOL_F32 = 1e-4
+
+
+@pytest.fixture
+def f32_gemm():
+    """switch the default context's far-field GEMMs to fp32 for one test"""
+    from metalens_amd import _lib
+    ctx = _lib.default_context()
+    ctx.set_precision('f32')
+    yield ctx
+    ctx.set_precision('f64')
+
+
+@pytest.mark.parametrize('shape', [(48, 40, 37, 29), (130, 70, 65, 130), (64, 64, 64, 64),
+                                   (33, 45, 12, 18), (256, 512, 96, 200), (45, 33, 18, 12)])
+def test_f32_gemm_vs_oracle(ma, f32_gemm, shape):
+    """fp32 matrix-core GEMMs (both stages folded: uniform direction grids, whole aperture)
+    against the fp64 oracle at the fp32 tolerance; the error must also be LARGER than fp64
+    round-off, i.e. the fp32 kernels really ran"""
+    from oracle import farfield_oracle
+    nx, ny, mx, my = shape
+    rng = np.random.default_rng(nx * 1000 + ny + 7)
+    F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+    wl, n = 580e-9, 1.459
+    x = (np.arange(nx) - 3.3) * (wl / 2.2)
+    y = (np.arange(ny) + 11.1) * (wl / 2.3)
+    ux = np.linspace(-0.61, 0.55, mx)
+    uy = np.linspace(-0.3, 0.72, my)
+    got = ma.farfield_direct(*F, x, y, wl, n, ux, uy)
+    want = farfield_oracle.farfield_direct(*F, x, y, wl, n, ux, uy)
+    worst = 0.0
+    for key in ('Nx', 'Ny', 'Lx', 'Ly', 'a_theta', 'a_phi'):
+        err = np.abs(got[key] - want[key]).max() / np.abs(want[key]).max()
+        assert err <= TOL_F32, (key, err)
+        worst = max(worst, err)
+    assert worst > 1e-9, 'fp32 mode produced fp64-accurate results: the fp32 kernels did not run'
+    ok = ~np.isnan(want['P'])
+    assert np.array_equal(np.isnan(got['P']), ~ok)
+    assert np.abs(got['P'][ok] - want['P'][ok]).max() <= 4 * TOL_F32 * want['P'][ok].max()
+
+
+def test_f32_gemm_hot_path_vs_f64(ma, f32_gemm):
+    """the GPU-resident pipeline on a synthetic lens: far-field amplitudes of the fp32-GEMM
+    mode against the fp64 mode of the same kernels"""
+    from metalens_amd.pipeline import HotPath
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    N = 384
+    x = np.linspace(-R, R, N)
+    u = np.linspace(-0.2, 0.2, 96)
+    source = (0.3e-6, -0.2e-6, -lens['source_distance'], 'y')
+    out = {}
+    for prec in ('f32', 'f64'):
+        hp = HotPath(source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                     lens['hexgridset'], x, x, u, u, ctx=f32_gemm, precision=prec)
+        hp.step()
+        hp.sync()
+        out[prec] = hp.results()
+    for key in ('a_theta', 'a_phi', 'Nx', 'Ly'):
+        scale = np.abs(out['f64'][key]).max()
+        err = np.abs(out['f32'][key] - out['f64'][key]).max() / scale
+        assert 1e-10 < err <= TOL_F32, (key, err)

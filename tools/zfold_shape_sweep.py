@@ -9,6 +9,7 @@ import metalens_amd as ma
 nxl, ny, my = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 ctx = _lib.default_context()
+ctx.set_precision(os.environ.get('ML_PRECISION', 'f64'))
 rng = np.random.default_rng(0)
 F = [(rng.standard_normal((nxl, ny)) + 1j * rng.standard_normal((nxl, ny))) for _ in range(4)]
 _lib.check(ctx.lib.ml_fields_upload(ctx.handle, nxl, ny, *[_lib.dptr(a) for a in F]))
