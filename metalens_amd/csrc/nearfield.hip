@@ -306,6 +306,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.bx0 = ctx->bin_x0;
     a.by0 = ctx->bin_y0;
     a.bh = ctx->bin_h;
+    a.inv_bh = 1.0 / ctx->bin_h;
     a.tables = ctx->table_desc.as<TableDesc>();
     a.ring_tab = ctx->ring_tab.as<double2>();
     a.ring_tab_off = ctx->ring_tab_off.as<long long>();

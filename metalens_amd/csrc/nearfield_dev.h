@@ -32,7 +32,7 @@ struct NfArgs {
     const double2 *cxy;
     const double2 *center_tab;   // centre table re-laid out [order][n0][n1][4][K] (fast kernel)   // (x, y) of the bin-sorted cells, one 16-byte load per candidate
     int bins_x, bins_y;
-    double bx0, by0, bh;
+    double bx0, by0, bh, inv_bh;   // inv_bh = 1 / bh, rounded (fast kernel's bin lookup)
     // tables
     const TableDesc *tables;
     // per-ring tables for the fast kernel: period axis already interpolated, complex
@@ -121,8 +121,11 @@ __device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y)
 // same rule as nearest_cell), otherwise the ring-growing search runs; ties resolve to the
 // lowest original index.
 __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, double y) {
-    int bx = (int)floor((x - a.bx0) / a.bh);
-    int by = (int)floor((y - a.by0) / a.bh);
+    // bin of the sample by multiplication with 1/bh (two fp64 divisions saved).  A sample within
+    // an ulp of a bin edge may land in the neighbouring bin; the acceptance test below allows
+    // for that by requiring the winner to be closer than bh (1 - 1e-9).
+    int bx = (int)floor((x - a.bx0) * a.inv_bh);
+    int by = (int)floor((y - a.by0) * a.inv_bh);
     bx = min(max(bx, 0), a.bins_x - 1);
     by = min(max(by, 0), a.bins_y - 1);
     const int gy_lo = max(by - 1, 0), gy_hi = min(by + 1, a.bins_y - 1);
@@ -181,7 +184,8 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
                 }
             }
     }
-    if (best_slot < 0 || !(best <= a.bh * a.bh)) return nearest_cell(a, x, y);
+    const double reach = a.bh * (1.0 - 1e-9);
+    if (best_slot < 0 || !(best <= reach * reach)) return nearest_cell(a, x, y);
     return best_slot;
 }
 
@@ -192,10 +196,12 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
 // theta = (k + 1/2) dphi from the host's extended-precision table,
 //   phi = theta + atan((y cos theta - x sin theta) / (x cos theta + y sin theta)),
 // and rounded: the correctly rounded arctan2, which is what NumPy returns on these arguments.
+// `inv_dphi` != 0 (fast kernel): the first quotient is phi * inv_dphi; it differs from phi / dphi by
+// ~1e-16 relative, 1e7 times less than the width of the tie window, so the decision is the same.
 __device__ __forceinline__ int sector_of(const NfArgs &a, int ring, double x, double y,
-                                         double dphi) {
+                                         double dphi, double inv_dphi = 0.0) {
     const int half = a.rot_half[ring];
-    double q = atan2(y, x) / dphi;
+    double q = inv_dphi != 0.0 ? atan2(y, x) * inv_dphi : atan2(y, x) / dphi;
     const double fl = floor(q);
     if (fabs((q - fl) - 0.5) < 1e-9) {
         const int k = min(max((int)fl, -half - 1), half);

@@ -51,6 +51,17 @@ __device__ __forceinline__ void sincos_cw(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// 1 / sqrt(x) to ~1 ulp for well-scaled x (no denormal / overflow handling): hardware estimate
+// + two Newton steps.  Amplitude-type quantities only.
+__device__ __forceinline__ double rsqrt_fast(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    return y;
+}
+
 // Accurate reciprocal: hardware estimate + two Newton steps (~1 ulp).
 __device__ __forceinline__ double recip(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -132,8 +143,7 @@ __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int 
     acc.Hx.i += vy_i;
     acc.Hy.r += vx_r;
     acc.Hy.i += vx_i;
-    const double kz = sqrt(kz2);
-    const double g = Z0 * inv_n * recip(k_glass * kz);
+    const double g = Z0 * inv_n * recip(k_glass) * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
     const double cxy = kx * ky * g, cxx = fma(ky, ky, kz2) * g, cyy = -fma(kx, kx, kz2) * g;
     acc.Ex.r += fma(cxy, vy_r, cxx * vx_r);
     acc.Ex.i += fma(cxy, vy_i, cxx * vx_i);
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 Hy_i = p.pol[0] * p.dipole_moment / p.Z0;
             } else {
                 const double dx = x - p.source_x, dy = y - p.source_y;
-                const double inv = recip(sqrt(dx * dx + dy * dy + p.dz2));
+                const double inv = rsqrt_fast(dx * dx + dy * dy + p.dz2);
                 ux = dx * inv;
                 uy = dy * inv;
                 uz = p.dz * inv;
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 const TableDesc &T = a.tables[slot];
                 const double dphi = a.dphi[ring], rcen = a.rc[ring];
                 // sector decision: exact (nearfield.py:169)
-                const int sector = sector_of(a, ring, x, y, dphi);
+                const int sector = sector_of(a, ring, x, y, dphi, recip(dphi));
                 const double2 cs = a.rot_table[a.rot_center[ring] + sector];
                 const double cosr = cs.x, sinr = cs.y;
                 // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
@@ -206,13 +216,17 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
                 const int stride1 = 4, stride0 = T.n1 * 4, stride_o = T.n0 * T.n1 * 4;
                 const double period = a.period[ring];
+                // the table-bound tests do not depend on the order: evaluate them once, and only
+                // take the reporting path (per order, in the reference's check order) on failure
+                const bool outside = uxp < T.bounds[0] || uxp > T.bounds[1] || uyp < T.bounds[2] ||
+                                     uyp > T.bounds[3] || period < T.bounds[4] || period > T.bounds[5];
                 Acc pr = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
                 for (int o = 0; o < T.n_orders; ++o) {
                     const double kxp = fma(p.kvac, uxp, ok[2 * o]);
                     const double kyp = fma(p.kvac, uyp, ok[2 * o + 1]);
                     const double kt2 = fma(kxp, kxp, kyp * kyp);
                     if (kt2 <= p.kvac2) {
-                        check_bounds(a, T, slot, o, uxp, uyp, period, true);
+                        if (outside) check_bounds(a, T, slot, o, uxp, uyp, period, true);
                         order_term(pr, tab + o * stride_o + i0 * stride0 + i1 * stride1, stride0,
                                    stride1, 1, t0, t1, Hw_x, Hw_y, kxp, kyp, p.k_glass2 - kt2,
                                    p.k_glass, inv_n, p.Z0, kxp * xp + kyp * yp);
@@ -251,12 +265,14 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                 const size_t stride_o = (size_t)T.n0 * T.n1 * T.n2 * 4;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
                 const double ox_ = x - ccx, oy_ = y - ccy;
+                const bool outside = ux < T.bounds[0] || ux > T.bounds[1] || uy < T.bounds[2] ||
+                                     uy > T.bounds[3];
                 for (int o = 0; o < T.n_orders; ++o) {
                     const double kx = fma(p.kvac, ux, T.center_kx[o]);
                     const double ky = fma(p.kvac, uy, T.center_ky[o]);
                     const double kt2 = fma(kx, kx, ky * ky);
                     if (kt2 <= p.kvac2) {
-                        check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                        if (outside) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
                         // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
                         order_term(acc, tab + o * stride_o + (size_t)i0 * stride0 + i1 * stride1 +
                                             which,
