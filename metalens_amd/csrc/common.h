@@ -88,7 +88,7 @@ struct TableDesc {
     // a <= n-2 (+inf beyond, so a running compare never selects a padded node) and
     // 1 / (node[a+1] - node[a]); one round of independent loads instead of a pointer chase
     // followed by a dependent search loop
-    int packed;
+    int packed;   // 0 no, 1 both axes <= 5 nodes, 2 both <= PACKED_AXIS
     double ax0[PACKED_AXIS], inv0[PACKED_AXIS], ax1[PACKED_AXIS], inv1[PACKED_AXIS];
 };
 

@@ -82,7 +82,8 @@ static int refresh_table_desc(ml_ctx *ctx) {
         d.n2 = t.n2;
         d.n_orders = t.n_orders;
         for (int k = 0; k < 6; ++k) d.bounds[k] = t.bounds[k];
-        d.packed = (t.n0 >= 2 && t.n1 >= 2 && t.n0 <= PACKED_AXIS && t.n1 <= PACKED_AXIS) ? 1 : 0;
+        d.packed = (t.n0 < 2 || t.n1 < 2 || t.n0 > PACKED_AXIS || t.n1 > PACKED_AXIS) ? 0
+                   : (t.n0 <= 5 && t.n1 <= 5) ? 1 : 2;
         if (d.packed) {
             auto pack = [](const std::vector<double> &axis, double *node, double *inv) {
                 const int n = (int)axis.size();

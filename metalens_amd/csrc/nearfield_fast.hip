@@ -80,12 +80,13 @@ __device__ __forceinline__ void locate_fast(const double *axis, int n, double x,
 }
 
 // the same for an inline axis (TableDesc::ax / inv): independent loads, running select
+template <int NODES>
 __device__ __forceinline__ void locate_packed(const double *node, const double *inv, double x,
                                               int &i, double &t) {
     double lo = node[0], r = inv[0];
     i = 0;
 #pragma unroll
-    for (int a = 1; a < PACKED_AXIS - 1; ++a) {
+    for (int a = 1; a < NODES - 1; ++a) {
         const double na = node[a], ra = inv[a];
         const bool c = na <= x;
         lo = c ? na : lo;
@@ -97,9 +98,12 @@ __device__ __forceinline__ void locate_packed(const double *node, const double *
 
 __device__ __forceinline__ void locate_uv(const TableDesc &T, double u, double v, int &i0,
                                           double &t0, int &i1, double &t1) {
-    if (T.packed) {
-        locate_packed(T.ax0, T.inv0, u, i0, t0);
-        locate_packed(T.ax1, T.inv1, v, i1, t1);
+    if (T.packed == 1) {          // both axes have <= 5 nodes (the reference's default tables)
+        locate_packed<5>(T.ax0, T.inv0, u, i0, t0);
+        locate_packed<5>(T.ax1, T.inv1, v, i1, t1);
+    } else if (T.packed == 2) {   // <= PACKED_AXIS nodes
+        locate_packed<PACKED_AXIS>(T.ax0, T.inv0, u, i0, t0);
+        locate_packed<PACKED_AXIS>(T.ax1, T.inv1, v, i1, t1);
     } else {
         locate_fast(T.axis0, T.n0, u, i0, t0);
         locate_fast(T.axis1, T.n1, v, i1, t1);
