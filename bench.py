@@ -111,6 +111,9 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=1024,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--check', type=int, default=1, help='verify a sample against the oracle')
+    ap.add_argument('--reduce', choices=('amplitudes', 'vectors'), default='amplitudes',
+                    help='multi-GPU: all-reduce the 2 projected amplitudes (default) or the 4 '
+                         'radiation vectors')
     ap.add_argument('--precision', choices=('f64', 'f32'), default='f64',
                     help="arithmetic of the far-field GEMMs: f64 (BASELINE metric, 1e-12) or f32 "
                          "(fp32 matrix cores, 1e-4; near field, storage and projection stay fp64)")
@@ -137,7 +140,7 @@ def main():
     source = (0.0, 0.0, -lens['source_distance'], 'x')
     hp = HotPath(source, args.wavelength, lens['lens_periphery_summary'],
                  lens['lens_center_summary'], lens['hexgridset'], x, x, u, u, ctx=ctx,
-                 rank=rank, world=world, precision=args.precision)
+                 rank=rank, world=world, precision=args.precision, reduce=args.reduce)
 
     for _ in range(args.warmup):
         hp.step()
@@ -197,7 +200,10 @@ def main():
                    'aperture': side, 'farfield': u.size, 'rings': int(len(
                        lens['lens_periphery_summary']['r_center_list'])),
                    'centre_cells': int(len(lens['lens_center_summary'])),
-                   'parallelism': 'aperture rows sharded over %d GPU(s), 1 RCCL all-reduce' % world},
+                   'parallelism': 'aperture rows (mirrored pairs) sharded over %d GPU(s), 1 RCCL '
+                                  'all-reduce of the %s' % (world, 'two projected amplitudes'
+                                                            if args.reduce == 'amplitudes'
+                                                            else 'four radiation vectors')},
     }
     # ---- rooflines.  `roofline` describes the kernel that takes the most time per step; the
     # other of the two large kernels goes to `roofline_other`.
@@ -266,9 +272,16 @@ def main():
     if rank == 0 and world == 1 and args.cpu_rows > 0:
         line['cpu_baseline'] = cpu_baseline(lens, x, u, args.wavelength,
                                             min(args.cpu_rows, side), source)
-    if rank == 0:
-        print(json.dumps(line))
     ctx.close()
+    if rank == 0:
+        # anything native libraries left in C stdio buffers goes out first: the JSON line is the
+        # last (and, with RCCL's banner diverted in ml_comm_init, the only) line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

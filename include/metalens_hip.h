@@ -179,6 +179,14 @@ int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate);
  * Both transform stages then run folded; needs a tensor grid with centre-symmetric ux.      */
 int ml_farfield_transform_mirrored(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_allreduce(ml_ctx *ctx);
+/* Multi-GPU shortcut: the projection (nearfield_farfield.py:158-185) is linear up to the two
+ * complex amplitudes L_phi + Z N_theta and L_theta - Z N_phi, so instead of summing the four
+ * partial radiation vectors over the ranks (ml_farfield_allreduce, 4 complex planes) and then
+ * projecting, each rank projects its partial sums, ONE all-reduce sums the 2 amplitude planes,
+ * and the power is taken afterwards (asynchronous, on the context's stream).  A following
+ * ml_farfield_project[_async] returns these results; the radiation vectors stay local partial
+ * sums.  Without a communicator it is the plain projection.                                  */
+int ml_farfield_project_reduce(ml_ctx *ctx, double Z0);
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi);
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
 /* which stage-1 kernel the current plan uses: *stage1_kernel = 0 generic complex GEMM (3M),

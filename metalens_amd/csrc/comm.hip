@@ -9,6 +9,7 @@
 // librccl is loaded with dlopen the first time a communicator is needed, so single-GPU use
 // never touches it.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdlib>
 #include <rccl/rccl.h>
@@ -83,6 +84,10 @@ static int allreduce_dev(ml_ctx *ctx, double *buf, size_t count, int op) {
     return ML_OK;
 }
 
+int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count) {
+    return allreduce_dev(ctx, buf, count, 0);
+}
+
 }  // namespace ml
 
 using namespace ml;
@@ -114,7 +119,21 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     ncclUniqueId u;
     memcpy(&u, id, 128);
     ncclComm_t comm = nullptr;
-    ML_NCCL(g_rccl.CommInitRank(&comm, n_ranks, u, rank));
+    // RCCL prints a version banner ("RCCL version : ...") to STDOUT from rank 0 when the first
+    // communicator is created.  Programs built on this library report results on stdout
+    // (bench.py: one JSON line), so send whatever the library prints during initialisation to
+    // stderr instead: point fd 1 at fd 2 for the duration of the call and flush C stdio on both
+    // sides of the switch.
+    fflush(stdout);
+    const int saved_stdout = dup(1);
+    if (saved_stdout >= 0) dup2(2, 1);
+    const ncclResult_t rc = g_rccl.CommInitRank(&comm, n_ranks, u, rank);
+    fflush(stdout);
+    if (saved_stdout >= 0) {
+        dup2(saved_stdout, 1);
+        close(saved_stdout);
+    }
+    ML_NCCL(rc);
     ctx->comm = comm;
     return ML_OK;
 }
@@ -128,6 +147,7 @@ int ml_farfield_allreduce(ml_ctx *ctx) {
     }
     ML_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    pl.amplitudes_reduced = false;
     return allreduce_dev(ctx, pl.vectors.as<double>(), 4 * n * 2, 0);
 }
 

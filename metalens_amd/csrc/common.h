@@ -122,6 +122,7 @@ struct Profile {
 
 struct FarfieldPlan {
     bool ready = false;
+    bool amplitudes_reduced = false;   // ml_farfield_project_reduce ran on the current vectors
     int nx_total = 0, ny = 0, mx = 0, my = 0, pair_list = 0;
     double dxp = 0, dyp = 0, wavelength = 0, n_glass = 0;
     DevBuf ux, uy;       // direction cosines
@@ -232,6 +233,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
 int zfold_splits(int T, int ksplit);
 // comm.hip
 void comm_release(ml_ctx *ctx);
+// in-place sum of `count` doubles over the communicator, on the context's stream (no-op without one)
+int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count);
 
 // nearfield.hip
 int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny);

@@ -213,7 +213,10 @@ struct ProjArgs {
     double dxp, dyp;
     double Z, coef;                      // Z0/n_glass and (2 pi n/lambda)^2 / (32 pi^2 Z)
     double *P;
-    double2 *a_theta, *a_phi;            // may be null
+    double2 *a_theta, *a_phi;            // may be null (stage 0)
+    // 0: vectors -> amplitudes -> power in one go; 1: vectors -> amplitudes only (the linear
+    // part: a rank's partial sums, to be all-reduced); 2: amplitudes -> power
+    int stage;
 };
 
 __device__ __forceinline__ double2 cscale(double2 a, double s) {
@@ -231,6 +234,16 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     const size_t at = (size_t)i * a.my + j;
     const double ux = a.ux[i];
     const double uy = a.pair_list ? a.uy[i] : a.uy[j];
+    double uz = 1 - ux * ux - uy * uy;
+    uz = (uz < 0) ? NAN : sqrt(uz);
+    if (a.stage == 2) {
+        const double2 at_ = a.a_theta[at], ap_ = a.a_phi[at];
+        const double m1 = hypot(at_.x, at_.y), m2 = hypot(ap_.x, ap_.y);
+        double P = (a.coef * (m1 * m1 + m2 * m2)) / (uz + 1e-5);
+        P *= 2;
+        a.P[at] = P;
+        return;
+    }
     double2 Nx = a.Nx[at], Ny = a.Ny[at], Lx = a.Lx[at], Ly = a.Ly[at];
     if (a.from_fft) {
         // Nx = -fftHy*dxp*dyp, Ny = fftHx*dxp*dyp, Lx = fftEy*dxp*dyp, Ly = -fftEx*dxp*dyp
@@ -239,8 +252,6 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
         Lx = cscale(cscale(Lx, a.dxp), a.dyp);
         Ly = cscale(cscale(cneg(Ly), a.dxp), a.dyp);
     }
-    double uz = 1 - ux * ux - uy * uy;
-    uz = (uz < 0) ? NAN : sqrt(uz);
     const double sintheta = sqrt(ux * ux + uy * uy);
     const double scl = 1.0 / (sintheta + 1e-9);   // numpy: complex / real = multiply by 1/x
     double2 Nth, Nph, Lth, Lph;
@@ -257,6 +268,11 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     }
     const double2 at_ = cadd(Lph, cscale(Nth, a.Z));            // Lphi + Z*Ntheta
     const double2 ap_ = cadd(Lth, cneg(cscale(Nph, a.Z)));      // Ltheta - Z*Nphi
+    if (a.stage == 1) {
+        a.a_theta[at] = at_;
+        a.a_phi[at] = ap_;
+        return;
+    }
     const double m1 = hypot(at_.x, at_.y), m2 = hypot(ap_.x, ap_.y);
     double P = (a.coef * (m1 * m1 + m2 * m2)) / (uz + 1e-5);
     P *= 2;
@@ -497,6 +513,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     FarfieldPlan &pl = ctx->plan;
     pl.ready = false;
     pl.have_vectors = false;
+    pl.amplitudes_reduced = false;
     pl.nx_total = nx_total;
     pl.ny = ny;
     pl.mx = mx;
@@ -651,6 +668,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                        pl.stage1.as<double>(), pl.vectors.as<double>(), accumulate));
     }
     pl.have_vectors = true;
+    pl.amplitudes_reduced = false;
     return ML_OK;
 }
 
@@ -674,7 +692,7 @@ int ml_farfield_transform_mirrored(ml_ctx *ctx, int row0, int accumulate) {
     return prof_harvest(ctx);
 }
 
-int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
+static int project_stage(ml_ctx *ctx, double Z0, int stage) {
     ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready || !pl.have_vectors) {
@@ -702,7 +720,27 @@ int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
     a.P = pl.power.as<double>();
     a.a_theta = pl.amplitudes.as<double2>();
     a.a_phi = pl.amplitudes.as<double2>() + n;
+    a.stage = stage;
     return project_launch(ctx, a, ML_K_PROJECT);
+}
+
+int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
+    if (ctx && ctx->plan.amplitudes_reduced) return ML_OK;   // ml_farfield_project_reduce did it
+    return project_stage(ctx, Z0, 0);
+}
+
+// Multi-GPU: the projection is linear up to the two complex amplitudes, so the ranks' partial
+// radiation vectors need not be summed themselves: project locally, all-reduce 2 complex
+// planes instead of 4, then take the power (nearfield_farfield.py:184-189).  The radiation
+// vectors stay local partial sums (ml_farfield_allreduce sums those, if they are wanted).
+int ml_farfield_project_reduce(ml_ctx *ctx, double Z0) {
+    ML_TRY(project_stage(ctx, Z0, 1));
+    FarfieldPlan &pl = ctx->plan;
+    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    ML_TRY(comm_allreduce_sum(ctx, pl.amplitudes.as<double>(), 2 * n * 2));
+    ML_TRY(project_stage(ctx, Z0, 2));
+    pl.amplitudes_reduced = true;
+    return ML_OK;
 }
 
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi) {
@@ -789,6 +827,7 @@ int ml_farfield_lattice_power(ml_ctx *ctx, int nx, int ny, const double *fftEx,
     a.my = ny;
     a.pair_list = 0;
     a.from_fft = 1;
+    a.stage = 0;
     a.dxp = dxp;
     a.dyp = dyp;
     a.Z = Z0 / n_glass;

@@ -18,7 +18,13 @@ from .nearfield import _check_axis, _raise_violation, nearfield_params
 class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
-                 c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None):
+                 c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None,
+                 reduce='amplitudes'):
+        """``reduce`` (multi-GPU only): 'amplitudes' all-reduces the two projected complex
+        amplitudes (half the payload; the radiation vectors in ``results()`` are then this
+        rank's partial sums), 'vectors' all-reduces Nx, Ny, Lx, Ly and projects afterwards."""
+        assert reduce in ('amplitudes', 'vectors')
+        self.reduce = reduce
         self.ctx = ctx or _lib.default_context()
         if precision is not None:   # 'f64' | 'f32': arithmetic of the far-field GEMMs
             self.ctx.set_precision(precision)
@@ -92,9 +98,12 @@ class HotPath:
                 _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
             else:
                 _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
-        if self.world > 1 or dist.force_rccl():
-            _lib.check(lib.ml_farfield_allreduce(ctx.handle))
-        _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
+        if (self.world > 1 or dist.force_rccl()) and self.reduce == 'amplitudes':
+            _lib.check(lib.ml_farfield_project_reduce(ctx.handle, self.Z0))
+        else:
+            if self.world > 1 or dist.force_rccl():
+                _lib.check(lib.ml_farfield_allreduce(ctx.handle))
+            _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
 
     def sync(self):
         self.ctx.sync()

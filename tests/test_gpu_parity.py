@@ -373,21 +373,27 @@ def test_source_sweep_incoherent_sum_vs_oracle(ma):
     assert 0 < got['efficiency'] < 10
 
 
-def test_rccl_path_single_rank():
+@pytest.mark.parametrize('reduce', ['amplitudes', 'vectors'])
+def test_rccl_path_single_rank(reduce):
     """the multi-GPU code path (RCCL loaded with dlopen, unique-id exchange through /tmp,
-    communicator, all-reduce of the radiation vectors, max/sum reductions) run for real with
-    one rank: results must equal the plain single-GPU run"""
+    communicator, all-reduce of the projected amplitudes or of the radiation vectors, max/sum
+    reductions) run for real with one rank: results must equal the plain single-GPU run"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', '512', '--farfield', '64',
-           '--diameter', '3e-4', '--steps', '2', '--warmup', '1', '--cpu-rows', '0']
+           '--diameter', '3e-4', '--steps', '2', '--warmup', '1', '--cpu-rows', '0',
+           '--reduce', reduce]
     env = dict(os.environ, ML_FORCE_RCCL='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
-               MASTER_ADDR='127.0.0.1', MASTER_PORT='29511')
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29511' if reduce == 'vectors' else '29512')
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    # stdout must be the ONE JSON line and nothing else (RCCL's version banner, which the library
+    # prints to stdout when the first communicator is created, is diverted to stderr)
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
+    line = json.loads(lines[0])
     assert line['n_gpus'] == 1
     assert line['rel_err']['farfield_E_vs_oracle'] < 1e-12
     assert line['rel_err']['nearfield_vs_oracle'] < 1e-12
