@@ -238,7 +238,7 @@ def main():
             'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
             'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
             'frac': achieved / mfma_peak,
-            # PMC, profiles/r01e_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.3 MB: two
+            # PMC, profiles/r01g_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.3 MB: two
             # split-K slabs) per launch [bytes]
             'traffic': 345.5e6 if default_cfg and args.precision == 'f64' else None,
             'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
@@ -257,11 +257,12 @@ def main():
         roofs['nearfield'] = {
             'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            # PMC, profiles/r01e_summary.txt: FETCH_SIZE x2 (51.6 MB) + WRITE_SIZE (269.0 MB) per launch
-            'traffic': 320.5e6 if default_cfg else None,
+            # PMC, profiles/r01g_summary.txt: FETCH_SIZE x2 (51.7 MB) + WRITE_SIZE (269.0 MB) per launch
+            'traffic': 320.6e6 if default_cfg else None,
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-            'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by L1 '
-                    'gather throughput and fp64 VALU work, not by HBM (DESIGN.md 4.1)'}
+            'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by '
+                    'instruction issue (fp64 VALU) and dependent L1 gathers, not by HBM '
+                    '(DESIGN.md 4.1)'}
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
