@@ -1,0 +1,20 @@
+import sys, time, math
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+import metalens_amd as ma
+lens, x, u = bench.build_workload(2048, 256, 1e-3, 0.5, 580e-9, 1.0)
+src = (0.0, 0.0, -lens['source_distance'], 'x')
+args = (src[0], src[1], src[2], src[3], 580e-9, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'])
+for k in range(3):
+    t = time.perf_counter()
+    out = ma.build_nearfield(*args, x_pts=x, y_pts=x)
+    t1 = time.perf_counter()
+    print('build_nearfield 2048^2 (host arrays out): %.1f ms' % ((t1 - t) * 1e3))
+Ex, Ey, Hx, Hy = out[:4]
+t = time.perf_counter()
+ff = [np.fft.fft2(np.fft.fftshift(F)) for F in (Ex, Ey, Hx, Hy)]
+t1 = time.perf_counter()
+P = ma.farfield_from_nearfield(*ff, x, x, 580e-9, out[7])
+t2 = time.perf_counter()
+print('numpy fft2 x4: %.1f ms; farfield_from_nearfield (drop-in, host in/out): %.1f ms' % ((t1 - t) * 1e3, (t2 - t1) * 1e3))
