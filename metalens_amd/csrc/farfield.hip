@@ -422,7 +422,13 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
     // few rows (4*my) and a long reduction: split the pairs over several workgroups per tile
     const long tiles = (long)((4 * my + 31) / 32) * ((S + 63) / 64);
-    const int want_split = (int)std::min<long>(8, std::max<long>(1, 768 / std::max<long>(tiles, 1)));
+    static const int forced_split2 = [] {
+        const char *e = getenv("ML_STAGE2_SPLIT");
+        return e ? atoi(e) : 0;
+    }();
+    const int want_split = forced_split2 > 0
+                               ? forced_split2
+                               : (int)std::min<long>(8, std::max<long>(1, 1024 / std::max<long>(tiles, 1)));
     const int splits = zfold_splits(T, want_split);
     ML_TRY(pl.fold2_ot.reserve((size_t)splits * 4 * my * mx * 2 * sizeof(double)));
     ML_TRY(pl.fold2_cm.reserve((size_t)T * S * sizeof(double)));
