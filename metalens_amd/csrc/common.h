@@ -224,11 +224,18 @@ int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const do
 // out[f][d] (+)= alpha[f] * sum_j TX[d][j0 + j] * G[f][j][d]   (pair-list stage 2)
 int zcoldot(hipStream_t stream, int n_fields, int rows, int cols, const double *alpha4,
             const double *TX, int64_t ldtx, int j0, const double *G, double *out, int accumulate);
+// how zfold_stage1 reads and writes (defaults: one input array, row-major output)
+struct FoldIO {
+    int in_slabs = 1;            // A is the sum of this many arrays ...
+    int64_t in_slab_stride = 0;  // ... this many complex elements apart
+    int out_t_rows = 0;          // > 0: write C transposed per field, see zfold.hip FoldArgs
+};
 // zfold.hip: stage 1 with both mirror symmetries folded (real cos/sin kernel)
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
                  const double *D, double *C, int64_t ldc, int my, const int *row_first = nullptr,
-                 int nxl = 1, int ksplit = 1, int64_t split_stride = 0, bool f32 = false);
+                 int nxl = 1, int ksplit = 1, int64_t split_stride = 0, bool f32 = false,
+                 FoldIO io = FoldIO());
 // number of split-K slabs zfold_stage1 will actually write for (T, ksplit)
 int zfold_splits(int T, int ksplit);
 // comm.hip

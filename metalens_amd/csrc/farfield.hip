@@ -415,11 +415,14 @@ static int plan_fold2(ml_ctx *ctx, const double *ux) {
 // row nxl-1-k, pair t sits at +/-(half_x - row0 - t) dx.  G is transposed so that the
 // reduction index is contiguous, run through the same folded kernel as stage 1 (rows = 4*my
 // stage-1 columns, "directions" = ux), and transposed back with the signs applied.
-static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, const double *alpha) {
+// `gt_direct`: stage 1 already wrote its result transposed (GT layout, pl.stage1_splits slabs);
+// the slabs are summed while the folded kernel loads its tiles and no transposer runs.
+static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, const double *alpha,
+                         bool gt_direct) {
     FarfieldPlan &pl = ctx->plan;
     const int nxl = ctx->nx, mx = pl.mx, my = pl.my, S = pl.fold2_S, T = (nxl + 1) / 2;
     const size_t g_elems = (size_t)4 * nxl * my;
-    ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
+    if (!gt_direct) ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
     // few rows (4*my) and a long reduction: split the pairs over several workgroups per tile
     const long tiles = (long)((4 * my + 31) / 32) * ((S + 63) / 64);
     static const int forced_split2 = [] {
@@ -459,17 +462,25 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     batch_add(pb, pl.fold2_D.as<double2>(), nullptr, nullptr, 1, mx, 1, delta, 0.0, s_hi, s_lo,
               pl.ux.as<double>(), nullptr);
     ML_TRY(batch_launch(ctx, pb));
-    // G[(f, n1)][j] -> GT[(f, j)][n1]
-    hipLaunchKernelGGL(ztranspose_kernel, dim3((my + 31) / 32, (nxl + 31) / 32, 4), dim3(256), 0,
-                       ctx->stream, pl.stage1.as<double2>(), pl.fold2_gt.as<double2>(), nxl, my,
-                       pl.stage1_splits, (size_t)4 * nxl * my);
+    FoldIO io;
+    const double *gt = pl.fold2_gt.as<double>();
+    if (gt_direct) {
+        gt = pl.stage1.as<double>();
+        io.in_slabs = pl.stage1_splits;
+        io.in_slab_stride = (int64_t)4 * nxl * my;
+    } else {
+        // G[(f, n1)][j] -> GT[(f, j)][n1]
+        hipLaunchKernelGGL(ztranspose_kernel, dim3((my + 31) / 32, (nxl + 31) / 32, 4), dim3(256),
+                           0, ctx->stream, pl.stage1.as<double2>(), pl.fold2_gt.as<double2>(), nxl,
+                           my, pl.stage1_splits, (size_t)4 * nxl * my);
+        ML_HIP(hipGetLastError());
+    }
     pl.stage1_splits = 1;   // consumed
-    ML_HIP(hipGetLastError());
-    ML_TRY(zfold_stage1(ctx->stream, 4 * my, nxl, pl.fold2_gt.as<double>(), nxl,
+    ML_TRY(zfold_stage1(ctx->stream, 4 * my, nxl, gt, nxl,
                         pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), pl.fold2_r4.as<double>(),
                         T, S, pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr,
                         pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx, nullptr, 1,
-                        want_split, (int64_t)4 * my * mx, ctx->gemm_f32 != 0));
+                        want_split, (int64_t)4 * my * mx, ctx->gemm_f32 != 0, io));
     Alpha4f al;
     for (int k = 0; k < 4; ++k) al.v[k] = alpha[k];
     hipLaunchKernelGGL(zunfold_out_kernel, dim3((mx + 31) / 32, (my + 31) / 32, 4), dim3(256), 0,
@@ -602,6 +613,23 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
         pl.stage1_splits = zfold_splits(pl.fold_T, want_split1);
     }
     ML_TRY(pl.stage1.reserve((size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
+    // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
+    // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
+    static const long fold2_min_tiles = [] {
+        const char *e = getenv("ML_FOLD2_MIN_TILES");
+        return e ? atol(e) : 32L;   // with split-K the folded path wins from ~32 tiles up
+    }();
+    const bool whole = (row0 == 0 && nxl == pl.nx_total);
+    const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
+    const bool use_fold2 = !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole);
+    // both stages folded: stage 1 writes its result already transposed for stage 2
+    static const bool no_direct = [] {
+        const char *e = getenv("ML_NO_GT_DIRECT");
+        return e && atoi(e) != 0;
+    }();
+    const bool gt_direct = pl.fold && use_fold2 && !no_direct;
+    FoldIO io1;
+    if (gt_direct) io1.out_t_rows = nxl;
     const double one[4] = {1.0, 1.0, 1.0, 1.0};
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
@@ -613,7 +641,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                                 pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
                                 pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my,
                                 ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl,
-                                want_split1, (int64_t)4 * nxl * my, ctx->gemm_f32 != 0));
+                                want_split1, (int64_t)4 * nxl * my, ctx->gemm_f32 != 0, io1));
         else
             ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
                          pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
@@ -621,7 +649,6 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     const double dA = pl.dxp * pl.dyp;
     // fields are stored Ex,Ey,Hx,Hy; radiation vectors Nx,Ny,Lx,Ly = -Hy, Hx, Ey, -Ex (x dA)
     const double alpha[4] = {-dA, dA, dA, -dA};
-    const bool whole = (row0 == 0 && nxl == pl.nx_total);
     auto collapse_stage1 = [&]() -> int {
         if (pl.stage1_splits > 1) {
             const size_t n = (size_t)4 * nxl * my;
@@ -632,16 +659,9 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
         }
         return ML_OK;
     };
-    // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
-    // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
-    static const long fold2_min_tiles = [] {
-        const char *e = getenv("ML_FOLD2_MIN_TILES");
-        return e ? atol(e) : 32L;   // with split-K the folded path wins from ~32 tiles up
-    }();
-    const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
-    if (!pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole)) {
+    if (use_fold2) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
-        ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha));
+        ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha, gt_direct));
     } else if (!pl.pair_list && mirrored) {
         // generic stage 2 on the two runs of a mirrored shard
         ML_TRY(need_tw_x(ctx));

@@ -71,13 +71,22 @@ struct FoldArgs {
     int nxl;
     int t_chunk;            // split-K: blockIdx.y handles pairs [y*t_chunk, (y+1)*t_chunk) and
     int64_t split_stride;   // writes its partial result to C + y*split_stride (double2 units)
+    // A may arrive as `in_slabs` partial sums `in_slab_stride` elements apart (the split-K
+    // slabs of a previous pass): they are added while the tile is loaded
+    int in_slabs;
+    int64_t in_slab_stride;
+    // out_t_rows > 0: rows are (field, n1) with n1 < out_t_rows and the result is written
+    // TRANSPOSED per field, C[(field * my + j) * out_t_rows + n1] - the layout the folded
+    // stage 2 reads - instead of C[row * ldc + j]
+    int out_t_rows;
 };
 
 __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT>
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT,
+          bool IN_SUM, bool OUT_T>
 __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs a) {
     typedef typename Mma<CT>::acc_t acc_t;
     static_assert(FLY || sizeof(CT) == 8, "the table-operand variants are fp64 only");
@@ -129,9 +138,21 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             if (row < a.M && t < t_end) {
                 const double2 *Ar = a.A + (int64_t)row * a.lda;
                 fp = Ar[kp];
+                if (IN_SUM)
+                    for (int sl = 1; sl < a.in_slabs; ++sl) {
+                        const double2 w = Ar[sl * a.in_slab_stride + kp];
+                        fp.x += w.x;
+                        fp.y += w.y;
+                    }
                 if (a.E) fp = zmul(fp, a.E[kp]);
                 if (km != kp) {   // odd ny: the centre sample has no partner
                     fm = Ar[km];
+                    if (IN_SUM)
+                        for (int sl = 1; sl < a.in_slabs; ++sl) {
+                            const double2 w = Ar[sl * a.in_slab_stride + km];
+                            fm.x += w.x;
+                            fm.y += w.y;
+                        }
                     if (a.E) fm = zmul(fm, a.E[km]);
                 }
             }
@@ -303,33 +324,59 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
                 // +v: Pc - i Ps ; -v: Pc + i Ps
                 const double2 plus = make_double2(cr + si, ci - sr);
                 const double2 minus = make_double2(cr - si, ci + sr);
-                double2 *Crow = a.C + blockIdx.y * a.split_stride + (int64_t)row * a.ldc;
-                Crow[jp] = zmul(plus, dp);
-                if (jm != jp) Crow[jm] = zmul(minus, dm);
+                double2 *Cs = a.C + blockIdx.y * a.split_stride;
+                if (OUT_T) {
+                    const int fld = row / a.out_t_rows, n1 = row - fld * a.out_t_rows;
+                    const int64_t at = (int64_t)fld * a.my * a.out_t_rows + n1;
+                    Cs[at + (int64_t)jp * a.out_t_rows] = zmul(plus, dp);
+                    if (jm != jp) Cs[at + (int64_t)jm * a.out_t_rows] = zmul(minus, dm);
+                } else {
+                    double2 *Crow = Cs + (int64_t)row * a.ldc;
+                    Crow[jp] = zmul(plus, dp);
+                    if (jm != jp) Crow[jm] = zmul(minus, dm);
+                }
             }
         }
 }
 
 
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT>
+static int launch_fold_io(hipStream_t stream, FoldArgs &a, int ksplit);
+
 template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16, int MINB = 2,
-          typename CT = double>
+          typename CT = double, bool IN_SUM = false, bool OUT_T = false>
 static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT>), dim3(a.chunk * 8, ksplit),
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, IN_SUM, OUT_T>),
+                       dim3(a.chunk * 8, ksplit),
                        dim3(WM * WN * 64), 0,
                        stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
 
+// the production tiles come in three I/O flavours: plain, slab-summing input (stage 2 fed with
+// stage 1's split-K slabs), transposed output (stage 1 feeding the folded stage 2)
+template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT>
+static int launch_fold_io(hipStream_t stream, FoldArgs &a, int ksplit) {
+    if (a.out_t_rows > 0)
+        return launch_fold<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, false, true>(stream, a, ksplit);
+    if (a.in_slabs > 1)
+        return launch_fold<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, true, false>(stream, a, ksplit);
+    return launch_fold<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, false, false>(stream, a, ksplit);
+}
+
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
                  const double *Sm, const double *R4, int T, int S, const double *E,
                  const double *D, double *C, int64_t ldc, int my, const int *row_first, int nxl,
-                 int ksplit, int64_t split_stride, bool f32) {
+                 int ksplit, int64_t split_stride, bool f32, FoldIO io) {
     FoldArgs a;
+    a.in_slabs = io.in_slabs < 1 ? 1 : io.in_slabs;
+    a.in_slab_stride = io.in_slab_stride;
+    a.out_t_rows = io.out_t_rows;
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
     a.M = M;
@@ -370,25 +417,24 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         static const int f32_wide = getenv("ML_ZFOLD_F32_WIDE") ? atoi(getenv("ML_ZFOLD_F32_WIDE")) : 140;
         static const int f32_small = getenv("ML_ZFOLD_F32_SMALL") ? atoi(getenv("ML_ZFOLD_F32_SMALL")) : 132;
         switch (wide >= 480 ? f32_wide : f32_small) {
-            case 131: return launch_fold<32, 64, 2, 2, 2, true, 32, 2, float>(stream, a, ksplit);
-            case 132: return launch_fold<32, 64, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
-            case 141: return launch_fold<64, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
-            case 142: return launch_fold<64, 128, 2, 4, 2, true, 32, 4, float>(stream, a, ksplit);
-            case 143: return launch_fold<64, 128, 4, 4, 1, true, 32, 4, float>(stream, a, ksplit);
-            default: return launch_fold<32, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+            case 131: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, float>(stream, a, ksplit);
+            case 132: return launch_fold_io<32, 64, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+            default: return launch_fold_io<32, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
         }
     }
+    const bool special_io = a.out_t_rows > 0 || a.in_slabs > 1;
+    if (special_io && pick != 31) pick = 40;   // only the production tiles have the I/O flavours
     switch (pick) {
         case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a, ksplit);
         case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a, ksplit);
         case 21: return launch_fold<32, 128, 2, 2, 1, true>(stream, a, ksplit);
         case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a, ksplit);
         case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a, ksplit);
-        case 31: return launch_fold<32, 64, 2, 2, 2, true, 32>(stream, a, ksplit);
+        case 31: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, double>(stream, a, ksplit);
         case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a, ksplit);
         case 42: return launch_fold<32, 128, 2, 4, 1, true, 16, 4>(stream, a, ksplit);
         case 44: return launch_fold<32, 64, 2, 2, 1, true, 16, 4>(stream, a, ksplit);
-        default: return launch_fold<32, 128, 2, 4, 1, true, 32, 4>(stream, a, ksplit);
+        default: return launch_fold_io<32, 128, 2, 4, 1, true, 32, 4, double>(stream, a, ksplit);
     }
 }
 
