@@ -111,6 +111,10 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=1024,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--check', type=int, default=1, help='verify a sample against the oracle')
+    ap.add_argument('--profile', choices=('main', 'all', 'none'), default='main',
+                    help='kernels timed with HIP events inside the timed region: the two that '
+                         'carry the rooflines (default), all of them, or none; every timed launch '
+                         'serialises the stream for a few microseconds')
     ap.add_argument('--reduce', choices=('amplitudes', 'vectors'), default='amplitudes',
                     help='multi-GPU: all-reduce the 2 projected amplitudes (default) or the 4 '
                          'radiation vectors')
@@ -146,7 +150,8 @@ def main():
         hp.step()
     hp.sync()
     hp.results()                      # raises if the workload left the tables
-    ctx.profile(True)
+    ctx.profile(args.profile != 'none',
+                kernels=('nearfield', 'zgemm_stage1') if args.profile == 'main' else None)
     ctx.profile_reset()
     dist.barrier(ctx)
     hp.sync()

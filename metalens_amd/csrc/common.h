@@ -109,6 +109,7 @@ struct KernelTimer {
 
 struct Profile {
     bool on = false;
+    unsigned mask = 0xffffffffu;   // bit k: kernel id k is timed while `on`
     int64_t launches[ML_K_COUNT] = {0};
     double total_ms[ML_K_COUNT] = {0};
     // events are recorded around each launch and harvested lazily
@@ -185,6 +186,7 @@ struct ml_ctx {
 
     // near-field scratch
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
+    hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see note_row_extent(); valid only for synthesised fields

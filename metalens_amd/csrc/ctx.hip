@@ -37,8 +37,7 @@ static hipEvent_t take_event(ml_ctx *ctx) {
 }
 
 void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b) {
-    (void)kernel;
-    if (!ctx->prof.on) return;
+    if (!ctx->prof.on || !((ctx->prof.mask >> kernel) & 1u)) return;
     *a = take_event(ctx);
     *b = take_event(ctx);
     (void)hipEventRecord(*a, ctx->stream);
@@ -268,6 +267,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
         (void)hipEventDestroy(pd.b);
     }
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
+    if (ctx->peer_event) (void)hipEventDestroy(ctx->peer_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -585,6 +585,12 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
 int ml_profile_enable(ml_ctx *ctx, int on) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ctx->prof.on = on != 0;
+    return ML_OK;
+}
+
+int ml_profile_select(ml_ctx *ctx, unsigned mask) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ctx->prof.mask = mask;
     return ML_OK;
 }
 

@@ -147,6 +147,17 @@ __global__ __launch_bounds__(256) void ztranspose_kernel(const double2 *in, doub
         if (c0 + k < cols && r0 + tx < rows) out[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
 }
 
+// dst += src (radiation vectors of another context on the same GPU)
+__global__ __launch_bounds__(256) void zadd_kernel(double2 *dst, const double2 *src, size_t n) {
+    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (at >= n) return;
+    const double2 v = src[at];
+    double2 d = dst[at];
+    d.x += v.x;
+    d.y += v.y;
+    dst[at] = d;
+}
+
 // in[0] += in[1] + ... + in[splits-1]  (split-K slabs of stage 1 when the consumer is not the
 // transposing kernel)
 __global__ __launch_bounds__(256) void zsum_slabs_kernel(double2 *in, size_t n, int splits) {
@@ -793,6 +804,34 @@ int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel) {
         return ML_ESTATE;
     }
     *stage1_kernel = ctx->plan.fold ? 1 : 0;
+    return ML_OK;
+}
+
+int ml_farfield_add_vectors(ml_ctx *dst, ml_ctx *src) {
+    ML_REQUIRE(dst && src && dst != src, "need two different contexts");
+    ML_REQUIRE(dst->device == src->device, "contexts live on different GPUs (%d, %d)", dst->device,
+               src->device);
+    FarfieldPlan &pd = dst->plan, &ps = src->plan;
+    if (!pd.ready || !pd.have_vectors || !ps.ready || !ps.have_vectors) {
+        set_error("both contexts need radiation vectors (ml_farfield_transform)");
+        return ML_ESTATE;
+    }
+    ML_REQUIRE(pd.mx == ps.mx && pd.my == ps.my && pd.pair_list == ps.pair_list,
+               "the two plans have different direction grids");
+    ML_HIP(hipSetDevice(dst->device));
+    if (!dst->peer_event) ML_HIP(hipEventCreateWithFlags(&dst->peer_event, hipEventDisableTiming));
+    if (!src->peer_event) ML_HIP(hipEventCreateWithFlags(&src->peer_event, hipEventDisableTiming));
+    const size_t n = 4 * (size_t)pd.mx * (pd.pair_list ? 1 : pd.my);
+    // dst's stream waits for src's vectors, adds them, and src's stream waits for the add before
+    // it may overwrite them again: no host synchronisation
+    ML_HIP(hipEventRecord(src->peer_event, src->stream));
+    ML_HIP(hipStreamWaitEvent(dst->stream, src->peer_event, 0));
+    hipLaunchKernelGGL(zadd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dst->stream,
+                       pd.vectors.as<double2>(), ps.vectors.as<double2>(), n);
+    ML_HIP(hipGetLastError());
+    ML_HIP(hipEventRecord(dst->peer_event, dst->stream));
+    ML_HIP(hipStreamWaitEvent(src->stream, dst->peer_event, 0));
+    pd.amplitudes_reduced = false;
     return ML_OK;
 }
 

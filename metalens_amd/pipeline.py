@@ -83,6 +83,22 @@ class HotPath:
         self.params = nearfield_params(source_x, source_y, source_z, source_pol, self.wavelength,
                                        self.n_glass, self.dipole_moment, self.c0, self.Z0)
 
+    def step_local(self):
+        """near field + transform of this object's rows only (no reduction, no projection)"""
+        ctx, lib = self.ctx, self.ctx.lib
+        _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
+                                        self.dyp, self.wavelength, self.n_glass,
+                                        _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
+                                        self.uy.size, int(self.pair_list)))
+        if self.x_local.size:
+            _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(self.params),
+                                              _lib.dptr(self.x_local), self.x_local.size,
+                                              _lib.dptr(self.y), self.y.size))
+            if self.mirrored:
+                _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
+            else:
+                _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
+
     def step(self):
         """queue one pass of the hot path on the context's stream (asynchronous)"""
         ctx, lib = self.ctx, self.ctx.lib
@@ -129,3 +145,58 @@ class HotPath:
         local_power = power.value * self.dxp * self.dyp
         return {'P': P, 'a_theta': a_theta, 'a_phi': a_phi, 'Nx': vec[0], 'Ny': vec[1],
                 'Lx': vec[2], 'Ly': vec[3], 'power_local_rows': local_power}
+
+
+class HotPath2Stream:
+    """The same pass with the aperture rows of this rank split over TWO contexts (= two HIP
+    streams) on one GPU: while one half is in the matrix-core-bound GEMMs the other half's
+    near-field synthesis (latency / issue-bound, matrix cores idle) runs beside it.  The halves
+    are mirrored row-pair shards, exactly as two ranks would own them; the second half's
+    radiation vectors are added into the first's on the device (``ml_farfield_add_vectors``,
+    ordered by events) before the projection.  Single-GPU use only (world == 1)."""
+
+    def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
+                 hexgridset, x_pts, y_pts, ux, uy, ctx=None, precision=None, **kw):
+        self.ctx = ctx or _lib.default_context()
+        self.ctx_b = _lib.Context(self.ctx.device)
+        common = dict(kw)
+        self.a = HotPath(source, wavelength, lens_periphery_summary, lens_center_summary,
+                         hexgridset, x_pts, y_pts, ux, uy, ctx=self.ctx, rank=0, world=2,
+                         precision=precision, **common)
+        self.b = HotPath(source, wavelength, lens_periphery_summary, lens_center_summary,
+                         hexgridset, x_pts, y_pts, ux, uy, ctx=self.ctx_b, rank=1, world=2,
+                         precision=precision, **common)
+        self.Z0 = self.a.Z0
+        self.n_glass = self.a.n_glass
+        self.x_local = self.a.x_all          # all rows are resident on this GPU
+        self.shape = self.a.shape
+
+    def set_source(self, source):
+        self.a.set_source(source)
+        self.b.set_source(source)
+
+    def step(self):
+        lib = self.ctx.lib
+        self.a.step_local()
+        self.b.step_local()
+        _lib.check(lib.ml_farfield_add_vectors(self.ctx.handle, self.ctx_b.handle))
+        _lib.check(lib.ml_farfield_project_async(self.ctx.handle, self.Z0))
+
+    def sync(self):
+        self.ctx_b.sync()
+        self.ctx.sync()
+
+    def results(self):
+        out = self.a.results()
+        power_b = _lib.c_double(0)
+        viol = (_lib.BoundViolation * 8)()
+        n_viol = _lib.c_int(0)
+        _lib.check(self.ctx_b.lib.ml_nearfield_result(self.ctx_b.handle, _lib.byref(power_b), viol,
+                                                      8, _lib.byref(n_viol)))
+        if n_viol.value:
+            _raise_violation(viol[0], self.ctx_b)
+        out['power_local_rows'] += power_b.value * self.a.dxp * self.a.dyp
+        return out
+
+    def close(self):
+        self.ctx_b.close()
