@@ -10,6 +10,11 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_int, c_int3
 
 import numpy as np
 
+# The host driver of this GPU pool only supports dmabuf IPC; RCCL (multi-process runs) fails with
+# "hipIpcGetMemHandle: invalid argument" unless this is set before the HIP runtime initialises.
+# Harmless for single-process use; an explicit setting by the user wins.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 LIB_NAME = 'libmetalens_hip.so'
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
