@@ -243,7 +243,7 @@ def main():
             'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
             'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
             'frac': achieved / mfma_peak,
-            # PMC, profiles/r01g_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.3 MB: two
+            # PMC, profiles/r01h_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.3 MB: two
             # split-K slabs) per launch [bytes]
             'traffic': 345.5e6 if default_cfg and args.precision == 'f64' else None,
             'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
@@ -262,7 +262,7 @@ def main():
         roofs['nearfield'] = {
             'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            # PMC, profiles/r01g_summary.txt: FETCH_SIZE x2 (51.7 MB) + WRITE_SIZE (269.0 MB) per launch
+            # PMC, profiles/r01h_summary.txt: FETCH_SIZE x2 (51.7 MB) + WRITE_SIZE (269.0 MB) per launch
             'traffic': 320.6e6 if default_cfg else None,
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
             'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by '
