@@ -17,6 +17,8 @@ wl, n = 580e-9, 1.459
 pitch = wl / 2.2
 du = (wl / n) / (pitch * ny)
 u = (np.arange(my) - my // 2) * du
+if os.environ.get('ML_SYMMETRIC_GRID'):
+    u = (np.arange(my) - (my - 1) / 2) * du   # centre-symmetric about 0: no input modulation
 t = ma.FarfieldTransform(ny, ny, pitch, pitch, wl, n, u, u, ctx=ctx)
 q0 = (ny - nxl) // 2 // 2
 t.transform(row0=q0, mirrored=True)
