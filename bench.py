@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=1024,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--check', type=int, default=1, help='verify a sample against the oracle')
+    ap.add_argument('--dump', default=None,
+                    help='rank 0 saves the far field it ends with (P, a_theta, a_phi) to this .npz')
     ap.add_argument('--profile', choices=('main', 'all', 'none'), default='main',
                     help='kernels timed with HIP events inside the timed region: the two that '
                          'carry the rooflines (default), all of them, or none; every timed launch '
@@ -165,6 +167,8 @@ def main():
     prof = ctx.profile_get()
     ctx.profile(False)
     res = hp.results()
+    if args.dump and rank == 0:
+        np.savez(args.dump, P=res['P'], a_theta=res['a_theta'], a_phi=res['a_phi'])
 
     # ---- correctness of what was just timed (rank 0, N=1): a sample of directions against
     # the CPU oracle evaluated from the GPU's own near field rows

@@ -199,6 +199,11 @@ struct ml_ctx {
     // RCCL
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
+    // ML_COMM_BACKEND=file: TEST backend, all-reduce through files in /tmp (several ranks may
+    // then share one GPU, which RCCL refuses); never used unless asked for
+    bool comm_file = false;
+    std::string comm_file_key;
+    long comm_file_seq = 0;
     ml::DevBuf comm_scratch;
 };
 
