@@ -562,3 +562,37 @@ def test_two_ranks_sharing_one_gpu(tmp_path, reduce):
     ok = ~np.isnan(a['P'])
     assert np.array_equal(np.isnan(b['P']), ~ok)
     assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
+
+
+def test_full_size_nearfield_rows_and_determinism(ma):
+    """BASELINE config[1] (2048^2 window of the 1 mm NA 0.5 lens): 24 aperture rows spread over
+    the window against the CPU oracle, two runs bit-identical (fixed-order reductions, no float
+    atomics), and the incident power equal to the oracle's on those rows' share."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from metalens_amd import _lib
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens, x, u = bench.build_workload(2048, 256, 1e-3, 0.5, wl, 1.0)
+    src = (0.0, 0.0, -lens['source_distance'], 'x')
+    args = (src[0], src[1], src[2], src[3], wl, lens['lens_periphery_summary'],
+            lens['lens_center_summary'], lens['hexgridset'])
+    a = ma.build_nearfield(*args, x_pts=x, y_pts=x)
+    b = ma.build_nearfield(*args, x_pts=x, y_pts=x)
+    for p, q in zip(a[:4], b[:4]):
+        assert np.array_equal(p, q)
+    assert a[6] == b[6]
+    for block in (slice(0, 4), slice(511, 515), slice(1020, 1028), slice(1533, 1537),
+                  slice(2044, 2048)):                 # uniform pitch within each block
+        want = nearfield_oracle.build_nearfield(*args, x_pts=x[block], y_pts=x)
+        scale = max(np.abs(w).max() for w in want[:4]) or 1.0
+        for g, w in zip(a[:4], want[:4]):
+            assert np.abs(g[block] - w).max() <= TOL * scale
+    # the incident power is a sum over samples: the GPU's value for the last block alone
+    # (a separate call) equals the oracle's for that block
+    c = ma.build_nearfield(*args, x_pts=x[1020:1028], y_pts=x)
+    want = nearfield_oracle.build_nearfield(*args, x_pts=x[1020:1028], y_pts=x)
+    assert abs(c[6] - want[6]) <= 1e-12 * abs(want[6])
