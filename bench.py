@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--cpu-rows', type=int, default=1024,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--check', type=int, default=1, help='verify a sample against the oracle')
+    ap.add_argument('--fuse-modulation', type=int, default=1,
+                    help='1: the stage-1 input modulation rides in the synthesis kernel (default)')
     ap.add_argument('--dump', default=None,
                     help='rank 0 saves the far field it ends with (P, a_theta, a_phi) to this .npz')
     ap.add_argument('--profile', choices=('main', 'all', 'none'), default='main',
@@ -146,7 +148,8 @@ def main():
     source = (0.0, 0.0, -lens['source_distance'], 'x')
     hp = HotPath(source, args.wavelength, lens['lens_periphery_summary'],
                  lens['lens_center_summary'], lens['hexgridset'], x, x, u, u, ctx=ctx,
-                 rank=rank, world=world, precision=args.precision, reduce=args.reduce)
+                 rank=rank, world=world, precision=args.precision, reduce=args.reduce,
+                 fuse_modulation=bool(args.fuse_modulation))
 
     for _ in range(args.warmup):
         hp.step()

@@ -208,6 +208,16 @@ int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel);
 #define ML_PRECISION_F64 0
 #define ML_PRECISION_F32_GEMM 1
 int ml_farfield_set_precision(ml_ctx *ctx, int precision);
+/* Opt-in fusion for the GPU-resident pipeline (plan -> synthesis -> transform on one context).
+ * A direction grid that is centre-symmetric about u_c != 0 (e.g. the FFT sub-lattice, bins
+ * -M/2 .. M/2-1) needs the input modulation exp(-i kappa y' u_c) in front of stage 1, which
+ * costs that kernel ~11 %.  With this on, ml_nearfield[_async] multiplies it into the sample's
+ * propagation phasor (one more phasor product per sample, no extra pass) whenever a folded
+ * plan with the same ny is active, and the transform skips it.  The resident fields are then
+ * F[i][j] * E[j]; ml_fields_download undoes that first, so the host always sees the plain near
+ * field.  Re-planning between synthesis and transform makes the transform fail with
+ * ML_ESTATE instead of computing with the wrong modulation.  Default off.                    */
+int ml_nearfield_premodulate(ml_ctx *ctx, int on);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI -----------------------------------
  * ml_comm_unique_id fills id[128] on rank 0; the host passes it to the other ranks by

@@ -123,6 +123,7 @@ struct Profile {
 
 struct FarfieldPlan {
     bool ready = false;
+    long serial = 0;   // incremented by every ml_farfield_plan call
     bool amplitudes_reduced = false;   // ml_farfield_project_reduce ran on the current vectors
     int nx_total = 0, ny = 0, mx = 0, my = 0, pair_list = 0;
     double dxp = 0, dyp = 0, wavelength = 0, n_glass = 0;
@@ -187,6 +188,10 @@ struct ml_ctx {
     // near-field scratch
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
     hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
+    // ml_nearfield_premodulate: the synthesis applies the active plan's stage-1 input modulation;
+    // fields_premod_serial = serial of the plan whose modulation the resident fields carry (-1: none)
+    bool premod_enabled = false;
+    long fields_premod_serial = -1;
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see note_row_extent(); valid only for synthesised fields
@@ -247,6 +252,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
 int zfold_splits(int T, int ksplit);
 // comm.hip
 void comm_release(ml_ctx *ctx);
+// farfield.hip: undo ml_nearfield_premodulate on the resident fields (no-op if plain)
+int fields_unmodulate(ml_ctx *ctx);
 // in-place sum of `count` doubles over the communicator, on the context's stream (no-op without one)
 int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count);
 

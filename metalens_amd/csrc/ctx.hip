@@ -554,6 +554,7 @@ int ml_fields_download(ml_ctx *ctx, double *Ex, double *Ey, double *Hx, double *
         return ML_ESTATE;
     }
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(fields_unmodulate(ctx));   // the host always sees the plain near field
     const size_t plane_bytes = (size_t)ctx->nx * ctx->ny * 2 * sizeof(double);
     double *dst[4] = {Ex, Ey, Hx, Hy};
     for (int f = 0; f < 4; ++f)
@@ -572,6 +573,7 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
     const size_t plane_bytes = (size_t)nx * ny * 2 * sizeof(double);
     ML_TRY(ctx->fields.reserve(4 * plane_bytes));
     const double *src[4] = {Ex, Ey, Hx, Hy};
+    ctx->fields_premod_serial = -1;
     for (int f = 0; f < 4; ++f)
         ML_HIP(hipMemcpyAsync((char *)ctx->fields.p + f * plane_bytes, src[f], plane_bytes,
                               hipMemcpyHostToDevice, ctx->stream));

@@ -147,6 +147,15 @@ __global__ __launch_bounds__(256) void ztranspose_kernel(const double2 *in, doub
         if (c0 + k < cols && r0 + tx < rows) out[(size_t)(c0 + k) * rows + r0 + tx] = tile[tx][k];
 }
 
+// fields[f][i][j] *= conj(E[j]) (undo ml_nearfield_premodulate before the fields leave the GPU)
+__global__ __launch_bounds__(256) void zunmodulate_kernel(double2 *fields, const double2 *E, int ny,
+                                                          size_t n) {
+    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (at >= n) return;
+    const double2 e = E[at % ny], v = fields[at];
+    fields[at] = make_double2(v.x * e.x + v.y * e.y, v.y * e.x - v.x * e.y);
+}
+
 // dst += src (radiation vectors of another context on the same GPU)
 __global__ __launch_bounds__(256) void zadd_kernel(double2 *dst, const double2 *src, size_t n) {
     const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -524,6 +533,23 @@ static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id) {
     return ML_OK;
 }
 
+// called by ml_fields_download: give the host the plain fields
+int fields_unmodulate(ml_ctx *ctx) {
+    if (ctx->fields_premod_serial < 0) return ML_OK;
+    FarfieldPlan &pl = ctx->plan;
+    if (ctx->fields_premod_serial != pl.serial) {
+        set_error("the resident fields carry the input modulation of an earlier far-field plan and "
+                  "cannot be restored");
+        return ML_ESTATE;
+    }
+    const size_t n = (size_t)4 * ctx->nx * ctx->ny;
+    hipLaunchKernelGGL(zunmodulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, ctx->fields.as<double2>(), pl.fold_E.as<double2>(), ctx->ny, n);
+    ML_HIP(hipGetLastError());
+    ctx->fields_premod_serial = -1;
+    return ML_OK;
+}
+
 }  // namespace ml
 
 using namespace ml;
@@ -540,6 +566,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     ML_HIP(hipSetDevice(ctx->device));
     FarfieldPlan &pl = ctx->plan;
     pl.ready = false;
+    ++pl.serial;
     pl.have_vectors = false;
     pl.amplitudes_reduced = false;
     pl.nx_total = nx_total;
@@ -641,6 +668,17 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     const bool gt_direct = pl.fold && use_fold2 && !no_direct;
     FoldIO io1;
     if (gt_direct) io1.out_t_rows = nxl;
+    // resident fields that the synthesis already multiplied by this plan's input modulation
+    // (ml_nearfield_premodulate): stage 1 then runs without it
+    bool fields_premodulated = false;
+    if (ctx->fields_premod_serial >= 0) {
+        if (ctx->fields_premod_serial != pl.serial || !pl.fold) {
+            set_error("the resident fields carry the input modulation of an earlier far-field plan "
+                      "(ml_nearfield_premodulate): synthesise them again after ml_farfield_plan");
+            return ML_ESTATE;
+        }
+        fields_premodulated = true;
+    }
     const double one[4] = {1.0, 1.0, 1.0, 1.0};
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
@@ -649,7 +687,8 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
             ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->fields.as<double>(), ny,
                                 pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
                                 pl.fold_r4.as<double>(), pl.fold_T,
-                                pl.fold_S, pl.fold_has_E ? pl.fold_E.as<double>() : nullptr,
+                                pl.fold_S,
+                                pl.fold_has_E && !fields_premodulated ? pl.fold_E.as<double>() : nullptr,
                                 pl.fold_D.as<double>(), pl.stage1.as<double>(), my, my,
                                 ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl,
                                 want_split1, (int64_t)4 * nxl * my, ctx->gemm_f32 != 0, io1));
@@ -832,6 +871,12 @@ int ml_farfield_add_vectors(ml_ctx *dst, ml_ctx *src) {
     ML_HIP(hipEventRecord(dst->peer_event, dst->stream));
     ML_HIP(hipStreamWaitEvent(src->stream, dst->peer_event, 0));
     pd.amplitudes_reduced = false;
+    return ML_OK;
+}
+
+int ml_nearfield_premodulate(ml_ctx *ctx, int on) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ctx->premod_enabled = on != 0;
     return ML_OK;
 }
 

@@ -270,6 +270,8 @@ __global__ __launch_bounds__(1024) void sum_partials_kernel(const double *partia
     if (threadIdx.x == 0) *out = s[0];
 }
 
+static bool use_exact_kernel();
+
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a) {
     a.p = *p;
     a.x_pts = ctx->x_pts.as<double>();
@@ -316,6 +318,12 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.partial_power = ctx->partial_power.as<double>();
     a.row_first = ctx->row_first.as<int>();
     a.viol = ctx->violations.as<unsigned long long>();
+    // opt-in fusion: write the fields already multiplied by the plan's column phasors
+    const FarfieldPlan &pl = ctx->plan;
+    const bool premod = ctx->premod_enabled && !use_exact_kernel() && pl.ready && pl.fold &&
+                        pl.fold_has_E && pl.ny == ny;
+    a.premod = premod ? pl.fold_E.as<double2>() : nullptr;
+    ctx->fields_premod_serial = premod ? pl.serial : -1;
 }
 
 // ML_NEARFIELD_EXACT=1 selects the operation-by-operation restatement above; the default is

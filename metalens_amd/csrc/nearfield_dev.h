@@ -47,6 +47,9 @@ struct NfArgs {
     double *partial_power;
     int *row_first;   // per aperture row: smallest min(j, ny-1-j) over samples inside the lens
     unsigned long long *viol;
+    // fast kernel, opt-in (ml_nearfield_premodulate): column phasors E[ny] of the active far-field
+    // plan; the stored fields are F[i][j] * premod[j], which is what the plan's stage 1 needs
+    const double2 *premod;
 };
 
 // monotone map double -> uint64 (so that integer max == floating max)

@@ -205,6 +205,12 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
             }
             power_here = Ex_i * Hy_i - Ey_i * Hx_i;
             const double inv_n = recip(p.n_glass);
+            // input modulation of the far-field plan's stage 1, applied here for free (see NfArgs)
+            c2 tilt = {1.0, 0.0};
+            if (a.premod) {
+                const double2 t2 = a.premod[j];
+                tilt = {t2.x, t2.y};
+            }
 
             if (idx >= 1) {
                 // ================= periphery =================
@@ -251,11 +257,17 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double sn, cn;
                     sincos_cw(p.kvac * air, sn, cn);
-                    const c2 e = {cn, sn};
+                    c2 e = {cn, sn};
+                    if (a.premod) e = cmul(e, tilt);   // free ride: one more phasor product
                     pr.Ex = cmul(pr.Ex, e);
                     pr.Ey = cmul(pr.Ey, e);
                     pr.Hx = cmul(pr.Hx, e);
                     pr.Hy = cmul(pr.Hy, e);
+                } else if (a.premod) {
+                    pr.Ex = cmul(pr.Ex, tilt);
+                    pr.Ey = cmul(pr.Ey, tilt);
+                    pr.Hx = cmul(pr.Hx, tilt);
+                    pr.Hy = cmul(pr.Hy, tilt);
                 }
                 // back to the lab frame (nearfield.py:351-354)
                 acc.Ex = {fma(pr.Ex.r, cosr, -pr.Ey.r * sinr), fma(pr.Ex.i, cosr, -pr.Ey.i * sinr)};
@@ -299,11 +311,17 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double sn, cn;
                     sincos_cw(p.kvac * air, sn, cn);
-                    const c2 e = {cn, sn};
+                    c2 e = {cn, sn};
+                    if (a.premod) e = cmul(e, tilt);
                     acc.Ex = cmul(acc.Ex, e);
                     acc.Ey = cmul(acc.Ey, e);
                     acc.Hx = cmul(acc.Hx, e);
                     acc.Hy = cmul(acc.Hy, e);
+                } else if (a.premod) {
+                    acc.Ex = cmul(acc.Ex, tilt);
+                    acc.Ey = cmul(acc.Ey, tilt);
+                    acc.Hx = cmul(acc.Hx, tilt);
+                    acc.Hy = cmul(acc.Hy, tilt);
                 }
             }
         }

@@ -19,12 +19,15 @@ class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
                  c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None,
-                 reduce='amplitudes'):
+                 reduce='amplitudes', fuse_modulation=True):
         """``reduce`` (multi-GPU only): 'amplitudes' all-reduces the two projected complex
         amplitudes (half the payload; the radiation vectors in ``results()`` are then this
         rank's partial sums), 'vectors' all-reduces Nx, Ny, Lx, Ly and projects afterwards."""
         assert reduce in ('amplitudes', 'vectors')
         self.reduce = reduce
+        # the plan's stage-1 input modulation rides in the synthesis kernel (metalens_hip.h,
+        # ml_nearfield_premodulate); host downloads of the fields are un-modulated first
+        self.fuse_modulation = bool(fuse_modulation)
         self.ctx = ctx or _lib.default_context()
         if precision is not None:   # 'f64' | 'f32': arithmetic of the far-field GEMMs
             self.ctx.set_precision(precision)
@@ -86,6 +89,7 @@ class HotPath:
     def step_local(self):
         """near field + transform of this object's rows only (no reduction, no projection)"""
         ctx, lib = self.ctx, self.ctx.lib
+        _lib.check(lib.ml_nearfield_premodulate(ctx.handle, int(self.fuse_modulation)))
         _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
                                         self.dyp, self.wavelength, self.n_glass,
                                         _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
@@ -102,6 +106,7 @@ class HotPath:
     def step(self):
         """queue one pass of the hot path on the context's stream (asynchronous)"""
         ctx, lib = self.ctx, self.ctx.lib
+        _lib.check(lib.ml_nearfield_premodulate(ctx.handle, int(self.fuse_modulation)))
         _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
                                         self.dyp, self.wavelength, self.n_glass,
                                         _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
