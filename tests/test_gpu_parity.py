@@ -596,3 +596,56 @@ def test_full_size_nearfield_rows_and_determinism(ma):
     c = ma.build_nearfield(*args, x_pts=x[1020:1028], y_pts=x)
     want = nearfield_oracle.build_nearfield(*args, x_pts=x[1020:1028], y_pts=x)
     assert abs(c[6] - want[6]) <= 1e-12 * abs(want[6])
+
+
+def test_fused_input_modulation(ma):
+    """ml_nearfield_premodulate: with a direction grid symmetric about u_c != 0 the synthesis
+    kernel applies stage 1's input modulation; the far field must not change, the host must
+    still get the plain near field, and a re-plan between synthesis and transform is refused"""
+    from metalens_amd import _lib
+    from metalens_amd.pipeline import HotPath
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    u = (np.arange(96) - 48) * 0.004            # bins -48 .. 47: symmetric about -0.002
+    r_c = float(lens['lens_periphery_summary']['r_min_list'][0])
+    # a dipole over the whole lens; a plane wave over a window inside the centre disc (normal
+    # incidence lies outside the periphery tables, as in the reference)
+    for source, x in (((0.3e-6, -0.2e-6, -lens['source_distance'], 'y'), np.linspace(-R, R, 384)),
+                      ((0.0, 0.0, -float('inf'), 'x'), np.linspace(-0.6 * r_c, 0.6 * r_c, 160))):
+        args = (source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                lens['hexgridset'], x, x, u, u)
+        out = {}
+        for fuse in (False, True):
+            hp = HotPath(*args, ctx=_lib.default_context(), fuse_modulation=fuse)
+            hp.step()
+            hp.sync()
+            out[fuse] = hp.results()
+        for key in ('a_theta', 'a_phi', 'Nx', 'Ly'):
+            scale = np.abs(out[False][key]).max()
+            assert np.abs(out[True][key] - out[False][key]).max() <= 1e-13 * scale, key
+        # after the fused pass the resident fields are modulated; the download is not
+        ctx = _lib.default_context()
+        F = [np.empty((x.size, x.size), dtype=np.complex128) for _ in range(4)]
+        _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(a) for a in F]))
+        want = nearfield_oracle.build_nearfield(source[0], source[1], source[2], source[3], wl,
+                                                lens['lens_periphery_summary'],
+                                                lens['lens_center_summary'], lens['hexgridset'],
+                                                x_pts=x, y_pts=x)
+        scale = max(np.abs(w).max() for w in want[:4])
+        for g, w in zip(F, want[:4]):
+            assert np.abs(g - w).max() <= TOL * scale
+    # stale plan: synthesise for one plan, re-plan, transform -> refused
+    hp = HotPath(*args, ctx=_lib.default_context(), fuse_modulation=True)
+    ctx, lib = hp.ctx, hp.ctx.lib
+    _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 1))
+    plan = lambda: lib.ml_farfield_plan(ctx.handle, x.size, x.size, hp.dxp, hp.dyp, wl, hp.n_glass,
+                                        _lib.dptr(hp.ux), hp.ux.size, _lib.dptr(hp.uy), hp.uy.size, 0)
+    _lib.check(plan())
+    _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(hp.params), _lib.dptr(hp.x_local),
+                                      hp.x_local.size, _lib.dptr(hp.y), hp.y.size))
+    _lib.check(plan())
+    assert lib.ml_farfield_transform_async(ctx.handle, 0, 0) != 0
+    _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 0))
+    ctx.sync()
