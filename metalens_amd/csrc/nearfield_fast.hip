@@ -205,12 +205,6 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
             }
             power_here = Ex_i * Hy_i - Ey_i * Hx_i;
             const double inv_n = recip(p.n_glass);
-            // input modulation of the far-field plan's stage 1, applied here for free (see NfArgs)
-            c2 tilt = {1.0, 0.0};
-            if (a.premod) {
-                const double2 t2 = a.premod[j];
-                tilt = {t2.x, t2.y};
-            }
 
             if (idx >= 1) {
                 // ================= periphery =================
@@ -250,6 +244,13 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                                    stride1, 1, t0, t1, Hw_x, Hw_y, kxp, kyp, p.k_glass2 - kt2,
                                    p.k_glass, inv_n, p.Z0, kxp * xp + kyp * yp);
                     }
+                }
+                // input modulation of the far-field plan's stage 1, applied here for free (see
+                // NfArgs); loaded late so that it does not occupy registers through the order loop
+                c2 tilt = {1.0, 0.0};
+                if (a.premod) {
+                    const double2 t2 = a.premod[j];
+                    tilt = {t2.x, t2.y};
                 }
                 // phase-critical: propagation from the grating centre (nearfield.py:337-341)
                 if (!p.plane_wave) {
@@ -305,6 +306,12 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
                                    p.k_glass2 - kt2,
                                    p.k_glass, inv_n, p.Z0, kx * ox_ + ky * oy_);
                     }
+                }
+                // input modulation of the far-field plan's stage 1, (see the periphery branch)
+                c2 tilt = {1.0, 0.0};
+                if (a.premod) {
+                    const double2 t2 = a.premod[j];
+                    tilt = {t2.x, t2.y};
                 }
                 if (!p.plane_wave) {
                     const double gx = ccx - p.source_x, gy = ccy - p.source_y;
