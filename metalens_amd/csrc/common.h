@@ -241,6 +241,7 @@ struct FoldIO {
     int in_slabs = 1;            // A is the sum of this many arrays ...
     int64_t in_slab_stride = 0;  // ... this many complex elements apart
     int out_t_rows = 0;          // > 0: write C transposed per field, see zfold.hip FoldArgs
+    const double *out_E = nullptr;  // with out_t_rows: complex [out_t_rows], multiplied into row n1
 };
 // zfold.hip: stage 1 with both mirror symmetries folded (real cos/sin kernel)
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,

@@ -435,14 +435,11 @@ static int plan_fold2(ml_ctx *ctx, const double *ux) {
 // row nxl-1-k, pair t sits at +/-(half_x - row0 - t) dx.  G is transposed so that the
 // reduction index is contiguous, run through the same folded kernel as stage 1 (rows = 4*my
 // stage-1 columns, "directions" = ux), and transposed back with the signs applied.
-// `gt_direct`: stage 1 already wrote its result transposed (GT layout, pl.stage1_splits slabs);
-// the slabs are summed while the folded kernel loads its tiles and no transposer runs.
-static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, const double *alpha,
-                         bool gt_direct) {
+// Phase tables of the folded stage 2 for the resident rows (they do not depend on stage 1's
+// result, so they can be queued ahead of it).  Returns the split-K factor through *want_split.
+static int stage2_tables(ml_ctx *ctx, int row0, int mirrored, int *want_split_out) {
     FarfieldPlan &pl = ctx->plan;
     const int nxl = ctx->nx, mx = pl.mx, my = pl.my, S = pl.fold2_S, T = (nxl + 1) / 2;
-    const size_t g_elems = (size_t)4 * nxl * my;
-    if (!gt_direct) ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
     // few rows (4*my) and a long reduction: split the pairs over several workgroups per tile
     const long tiles = (long)((4 * my + 31) / 32) * ((S + 63) / 64);
     static const int forced_split2 = [] {
@@ -452,6 +449,7 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     const int want_split = forced_split2 > 0
                                ? forced_split2
                                : (int)std::min<long>(8, std::max<long>(1, 1024 / std::max<long>(tiles, 1)));
+    *want_split_out = want_split;
     const int splits = zfold_splits(T, want_split);
     ML_TRY(pl.fold2_ot.reserve((size_t)splits * 4 * my * mx * 2 * sizeof(double)));
     ML_TRY(pl.fold2_cm.reserve((size_t)T * S * sizeof(double)));
@@ -481,7 +479,20 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     const double delta = half - (double)(pl.nx_total - pl.nx_total / 2);
     batch_add(pb, pl.fold2_D.as<double2>(), nullptr, nullptr, 1, mx, 1, delta, 0.0, s_hi, s_lo,
               pl.ux.as<double>(), nullptr);
-    ML_TRY(batch_launch(ctx, pb));
+    return batch_launch(ctx, pb);
+}
+
+// `gt_direct`: stage 1 already wrote its result transposed (GT layout, pl.stage1_splits slabs)
+// AND multiplied by this stage's input modulation; the slabs are summed while the folded kernel
+// loads its tiles and no transposer runs.  `tables_ready`: stage2_tables has been queued.
+static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, const double *alpha,
+                         bool gt_direct, bool tables_ready, int want_split) {
+    FarfieldPlan &pl = ctx->plan;
+    const int nxl = ctx->nx, mx = pl.mx, my = pl.my, S = pl.fold2_S, T = (nxl + 1) / 2;
+    const size_t g_elems = (size_t)4 * nxl * my;
+    if (!gt_direct) ML_TRY(pl.fold2_gt.reserve(g_elems * 2 * sizeof(double)));
+    if (!tables_ready) ML_TRY(stage2_tables(ctx, row0, mirrored, &want_split));
+    const int splits = zfold_splits(T, want_split);
     FoldIO io;
     const double *gt = pl.fold2_gt.as<double>();
     if (gt_direct) {
@@ -498,7 +509,7 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     pl.stage1_splits = 1;   // consumed
     ML_TRY(zfold_stage1(ctx->stream, 4 * my, nxl, gt, nxl,
                         pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), pl.fold2_r4.as<double>(),
-                        T, S, pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr,
+                        T, S, pl.fold2_has_E && !gt_direct ? pl.fold2_E.as<double>() : nullptr,
                         pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx, nullptr, 1,
                         want_split, (int64_t)4 * my * mx, ctx->gemm_f32 != 0, io));
     Alpha4f al;
@@ -667,7 +678,14 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     }();
     const bool gt_direct = pl.fold && use_fold2 && !no_direct;
     FoldIO io1;
-    if (gt_direct) io1.out_t_rows = nxl;
+    int want_split2 = 1;
+    if (gt_direct) {
+        // stage 2's tables first: stage 1's epilogue applies stage 2's input modulation
+        ProfScope scope(ctx, ML_K_TWIDDLE);
+        ML_TRY(stage2_tables(ctx, row0, mirrored, &want_split2));
+        io1.out_t_rows = nxl;
+        io1.out_E = pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr;
+    }
     // resident fields that the synthesis already multiplied by this plan's input modulation
     // (ml_nearfield_premodulate): stage 1 then runs without it
     bool fields_premodulated = false;
@@ -711,7 +729,8 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     };
     if (use_fold2) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
-        ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha, gt_direct));
+        ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha, gt_direct, gt_direct,
+                             want_split2));
     } else if (!pl.pair_list && mirrored) {
         // generic stage 2 on the two runs of a mirrored shard
         ML_TRY(need_tw_x(ctx));

@@ -79,6 +79,8 @@ struct FoldArgs {
     // TRANSPOSED per field, C[(field * my + j) * out_t_rows + n1] - the layout the folded
     // stage 2 reads - instead of C[row * ldc + j]
     int out_t_rows;
+    const double2 *out_E;   // with out_t_rows: phasor per n1 multiplied into the output (the next
+                            // stage's input modulation), or nullptr
 };
 
 __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
@@ -328,8 +330,14 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
                 if (OUT_T) {
                     const int fld = row / a.out_t_rows, n1 = row - fld * a.out_t_rows;
                     const int64_t at = (int64_t)fld * a.my * a.out_t_rows + n1;
-                    Cs[at + (int64_t)jp * a.out_t_rows] = zmul(plus, dp);
-                    if (jm != jp) Cs[at + (int64_t)jm * a.out_t_rows] = zmul(minus, dm);
+                    double2 vp = zmul(plus, dp), vm = zmul(minus, dm);
+                    if (a.out_E) {
+                        const double2 e = a.out_E[n1];
+                        vp = zmul(vp, e);
+                        vm = zmul(vm, e);
+                    }
+                    Cs[at + (int64_t)jp * a.out_t_rows] = vp;
+                    if (jm != jp) Cs[at + (int64_t)jm * a.out_t_rows] = vm;
                 } else {
                     double2 *Crow = Cs + (int64_t)row * a.ldc;
                     Crow[jp] = zmul(plus, dp);
@@ -377,6 +385,7 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.in_slabs = io.in_slabs < 1 ? 1 : io.in_slabs;
     a.in_slab_stride = io.in_slab_stride;
     a.out_t_rows = io.out_t_rows;
+    a.out_E = reinterpret_cast<const double2 *>(io.out_E);
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
     a.M = M;
