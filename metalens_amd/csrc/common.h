@@ -186,6 +186,11 @@ struct ml_ctx {
     ml::DevBuf lattice_in;   // staging for ml_farfield_lattice_power
 
     // near-field scratch
+    // nearest-cell lattice shortcut (ctx.hip fit_lattice): cells = nodes c0 + a b1 + b b2
+    bool lat_ok = false;
+    double lat_c0x = 0, lat_c0y = 0, lat_inv[4] = {0, 0, 0, 0}, lat_accept_r2 = 0;
+    int lat_amin = 0, lat_bmin = 0, lat_na = 0, lat_nb = 0;
+    ml::DevBuf cell_lattice_map;
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
     hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
     // ml_nearfield_premodulate: the synthesis applies the active plan's stage-1 input modulation;

@@ -191,6 +191,151 @@ static int refresh_ring_locations(ml_ctx *ctx) {
 
 using namespace ml;
 
+namespace {
+
+// The centre cells are, in every design this code has seen, the nodes of a 2-D lattice (a
+// hexagonal grid, design_collimator.py:74-118), although the contract only promises "a list of
+// points in arbitrary order" (design_collimator.py:124-125).  If - and only if - every cell sits
+// within `tol` of a node of ONE lattice and no two cells share a node, the nearest-cell search
+// can start from the four nodes around the sample instead of scanning bins.  The result is
+// accepted only when it is provably nearest (see nearest_cell_fast), so a wrong fit can cost
+// time but never correctness; anything irregular simply reports `ok = false`.
+struct LatticeFit {
+    bool ok = false;
+    double c0x = 0, c0y = 0, inv[4] = {0, 0, 0, 0};   // (u, v) = inv * (p - c0)
+    int amin = 0, bmin = 0, na = 0, nb = 0;
+    double accept_r2 = 0;
+    std::vector<int32_t> map;                          // [na][nb] -> sorted slot, -1 empty
+};
+
+double seg_dist(double px, double py, double ax, double ay, double bx, double by) {
+    const double dx = bx - ax, dy = by - ay, l2 = dx * dx + dy * dy;
+    double t = l2 > 0 ? ((px - ax) * dx + (py - ay) * dy) / l2 : 0.0;
+    t = std::min(1.0, std::max(0.0, t));
+    return std::hypot(px - (ax + t * dx), py - (ay + t * dy));
+}
+
+LatticeFit fit_lattice(const std::vector<double> &sx, const std::vector<double> &sy) {
+    LatticeFit L;
+    const int n = (int)sx.size();
+    if (n < 16) return L;
+    // origin: the cell nearest to the centroid; basis: its nearest neighbour and the nearest
+    // neighbour that is not collinear with it (brute force, once per layout)
+    double mx = 0, my = 0;
+    for (int c = 0; c < n; ++c) {
+        mx += sx[c];
+        my += sy[c];
+    }
+    mx /= n;
+    my /= n;
+    int o = 0;
+    double best = INFINITY;
+    for (int c = 0; c < n; ++c) {
+        const double d = (sx[c] - mx) * (sx[c] - mx) + (sy[c] - my) * (sy[c] - my);
+        if (d < best) {
+            best = d;
+            o = c;
+        }
+    }
+    int i1 = -1;
+    best = INFINITY;
+    for (int c = 0; c < n; ++c) {
+        if (c == o) continue;
+        const double d = (sx[c] - sx[o]) * (sx[c] - sx[o]) + (sy[c] - sy[o]) * (sy[c] - sy[o]);
+        if (d < best) {
+            best = d;
+            i1 = c;
+        }
+    }
+    if (i1 < 0 || !(best > 0)) return L;
+    double b1x = sx[i1] - sx[o], b1y = sy[i1] - sy[o];
+    const double l1 = b1x * b1x + b1y * b1y;
+    int i2 = -1;
+    best = INFINITY;
+    for (int c = 0; c < n; ++c) {
+        if (c == o) continue;
+        const double dx = sx[c] - sx[o], dy = sy[c] - sy[o];
+        if (std::fabs(b1x * dy - b1y * dx) < 0.25 * l1) continue;   // (nearly) collinear with b1
+        const double d = dx * dx + dy * dy;
+        if (d < best) {
+            best = d;
+            i2 = c;
+        }
+    }
+    if (i2 < 0) return L;
+    double b2x = sx[i2] - sx[o], b2y = sy[i2] - sy[o];
+    // Gauss reduction: |b1| <= |b2|, |b1.b2| <= |b1|^2 / 2
+    for (int it = 0; it < 8; ++it) {
+        if (b2x * b2x + b2y * b2y < b1x * b1x + b1y * b1y) {
+            std::swap(b1x, b2x);
+            std::swap(b1y, b2y);
+        }
+        const double k = std::rint((b1x * b2x + b1y * b2y) / (b1x * b1x + b1y * b1y));
+        if (k == 0) break;
+        b2x -= k * b1x;
+        b2y -= k * b1y;
+    }
+    const double det = b1x * b2y - b1y * b2x;
+    if (!(std::fabs(det) > 0)) return L;
+    const double pitch = std::sqrt(b1x * b1x + b1y * b1y);
+    const double inv[4] = {b2y / det, -b2x / det, -b1y / det, b1x / det};
+    // every cell on a node?
+    std::vector<int> ia(n), ib(n);
+    int amin = INT32_MAX, amax = INT32_MIN, bmin = INT32_MAX, bmax = INT32_MIN;
+    double eps_max = 0;
+    const double tol = 1e-6 * pitch;
+    for (int c = 0; c < n; ++c) {
+        const double dx = sx[c] - sx[o], dy = sy[c] - sy[o];
+        const double u = std::rint(inv[0] * dx + inv[1] * dy), v = std::rint(inv[2] * dx + inv[3] * dy);
+        if (std::fabs(u) > 1e8 || std::fabs(v) > 1e8) return L;
+        const double rx = dx - (u * b1x + v * b2x), ry = dy - (u * b1y + v * b2y);
+        const double e = std::hypot(rx, ry);
+        if (!(e <= tol)) return L;
+        eps_max = std::max(eps_max, e);
+        ia[c] = (int)u;
+        ib[c] = (int)v;
+        amin = std::min(amin, ia[c]);
+        amax = std::max(amax, ia[c]);
+        bmin = std::min(bmin, ib[c]);
+        bmax = std::max(bmax, ib[c]);
+    }
+    // the map also answers the corner at (a + 1, b + 1): no padding needed, lookups are range-checked
+    const long na = (long)amax - amin + 1, nb = (long)bmax - bmin + 1;
+    if (na * nb > 16L * n + 1024) return L;            // too sparse to be worth a dense map
+    L.map.assign((size_t)(na * nb), -1);
+    for (int c = 0; c < n; ++c) {
+        int32_t &slot = L.map[(size_t)(ia[c] - amin) * nb + (ib[c] - bmin)];
+        if (slot != -1) return LatticeFit();           // two cells on one node
+        slot = c;
+    }
+    // smallest distance from the unit parallelogram to a lattice node that is not one of its corners
+    double h_min = INFINITY;
+    const double cx[4] = {0, b1x, b1x + b2x, b2x}, cy[4] = {0, b1y, b1y + b2y, b2y};
+    for (int i = -2; i <= 3; ++i)
+        for (int j = -2; j <= 3; ++j) {
+            if ((i == 0 || i == 1) && (j == 0 || j == 1)) continue;
+            const double px = i * b1x + j * b2x, py = i * b1y + j * b2y;
+            for (int e = 0; e < 4; ++e)
+                h_min = std::min(h_min, seg_dist(px, py, cx[e], cy[e], cx[(e + 1) & 3], cy[(e + 1) & 3]));
+        }
+    // cells sit within eps_max of their nodes; the sample is within ~1e-12 pitch of the
+    // parallelogram picked by floor(); keep a margin for both
+    const double r = h_min - 2 * eps_max - 1e-9 * pitch;
+    if (!(r > 0.5 * pitch)) return L;                  // degenerate lattice: not worth it
+    L.ok = true;
+    L.c0x = sx[o];
+    L.c0y = sy[o];
+    for (int k = 0; k < 4; ++k) L.inv[k] = inv[k];
+    L.amin = amin;
+    L.bmin = bmin;
+    L.na = (int)na;
+    L.nb = (int)nb;
+    L.accept_r2 = r * r;
+    return L;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ml_abi_version(void) { return ML_ABI_VERSION; }
@@ -252,7 +397,8 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
-                      &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start, &ctx->fields,
+                      &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
+                      &ctx->cell_lattice_map, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->row_first, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
@@ -380,6 +526,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     // centre cells -> uniform grid of bins (about one cell per bin), cells stored in bin
     // order; within a bin the original order is kept (ties resolve to the lowest index)
     ctx->n_cells = n_cells;
+    ctx->lat_ok = false;
     if (n_cells > 0) {
         double x0 = cells[0], x1 = cells[0], y0 = cells[1], y1 = cells[1];
         for (int c = 0; c < n_cells; ++c) {
@@ -427,6 +574,24 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
         ML_TRY(h2d(ctx, ctx->cell_which, sw.data(), n_cells * sizeof(int32_t)));
         ML_TRY(h2d(ctx, ctx->cell_index, si.data(), n_cells * sizeof(int32_t)));
         ML_TRY(h2d(ctx, ctx->bin_start, start.data(), start.size() * sizeof(int32_t)));
+        // lattice shortcut for the nearest-cell search (sorted slots index the arrays above)
+        static const bool no_lattice = [] {
+            const char *e = getenv("ML_NO_CELL_LATTICE");
+            return e && atoi(e) != 0;
+        }();
+        LatticeFit L = no_lattice ? LatticeFit() : fit_lattice(sx, sy);
+        ctx->lat_ok = L.ok;
+        if (L.ok) {
+            ML_TRY(h2d(ctx, ctx->cell_lattice_map, L.map.data(), L.map.size() * sizeof(int32_t)));
+            ctx->lat_c0x = L.c0x;
+            ctx->lat_c0y = L.c0y;
+            for (int k = 0; k < 4; ++k) ctx->lat_inv[k] = L.inv[k];
+            ctx->lat_amin = L.amin;
+            ctx->lat_bmin = L.bmin;
+            ctx->lat_na = L.na;
+            ctx->lat_nb = L.nb;
+            ctx->lat_accept_r2 = L.accept_r2;
+        }
         ML_HIP(hipStreamSynchronize(ctx->stream));
         ctx->bins_x = bxn;
         ctx->bins_y = byn;

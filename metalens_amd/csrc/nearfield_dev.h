@@ -33,6 +33,11 @@ struct NfArgs {
     const double2 *center_tab;   // centre table re-laid out [order][n0][n1][4][K] (fast kernel)   // (x, y) of the bin-sorted cells, one 16-byte load per candidate
     int bins_x, bins_y;
     double bx0, by0, bh, inv_bh;   // inv_bh = 1 / bh, rounded (fast kernel's bin lookup)
+    // lattice shortcut (ctx.hip fit_lattice), fast kernel: lat_map == nullptr if the cells are not
+    // the nodes of one lattice
+    const int *lat_map;            // [lat_na][lat_nb] -> sorted slot or -1
+    double lat_c0x, lat_c0y, lat_inv[4], lat_accept_r2;
+    int lat_amin, lat_bmin, lat_na, lat_nb;
     // tables
     const TableDesc *tables;
     // per-ring tables for the fast kernel: period axis already interpolated, complex
@@ -124,6 +129,42 @@ __device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y)
 // same rule as nearest_cell), otherwise the ring-growing search runs; ties resolve to the
 // lowest original index.
 __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, double y) {
+    // Lattice shortcut: the sample lies in (or within rounding of) the lattice parallelogram
+    // (a0, b0); its four corner nodes are the candidates.  Every cell that is NOT one of them
+    // sits on another node, i.e. at least lat_accept_r away from anywhere in that parallelogram
+    // (margins for the cells' offsets from their nodes and for the rounding of floor() are in
+    // lat_accept_r), so a candidate closer than that is the nearest cell - also when corners are
+    // empty.  Ties between equidistant candidates go to the lowest original index, as below.
+    if (a.lat_map) {
+        const double dx = x - a.lat_c0x, dy = y - a.lat_c0y;
+        const double u = a.lat_inv[0] * dx + a.lat_inv[1] * dy, v = a.lat_inv[2] * dx + a.lat_inv[3] * dy;
+        const int ia = (int)floor(u) - a.lat_amin, ib = (int)floor(v) - a.lat_bmin;
+        int cand[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ca = ia + (k >> 1), cb = ib + (k & 1);
+            const bool in = ca >= 0 && ca < a.lat_na && cb >= 0 && cb < a.lat_nb;
+            cand[k] = in ? a.lat_map[(size_t)ca * a.lat_nb + cb] : -1;
+        }
+        double2 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = a.cxy[max(cand[k], 0)];
+        double best = INFINITY;
+        int best_slot = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (cand[k] < 0) continue;
+            const double ex = x - p[k].x, ey = y - p[k].y;
+            const double d2 = ex * ex + ey * ey;
+            if (d2 < best) {
+                best = d2;
+                best_slot = cand[k];
+            } else if (d2 == best && a.cindex[cand[k]] < a.cindex[best_slot]) {
+                best_slot = cand[k];
+            }
+        }
+        if (best_slot >= 0 && best <= a.lat_accept_r2) return best_slot;
+    }
     // bin of the sample by multiplication with 1/bh (two fp64 divisions saved).  A sample within
     // an ulp of a bin edge may land in the neighbouring bin; the acceptance test below allows
     // for that by requiring the winner to be closer than bh (1 - 1e-9).
