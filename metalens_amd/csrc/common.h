@@ -189,6 +189,7 @@ struct ml_ctx {
     // nearest-cell lattice shortcut (ctx.hip fit_lattice): cells = nodes c0 + a b1 + b b2
     bool lat_ok = false;
     double lat_c0x = 0, lat_c0y = 0, lat_inv[4] = {0, 0, 0, 0}, lat_accept_r2 = 0;
+    double lat_g[3] = {0, 0, 0}, lat_guard = 0;
     int lat_amin = 0, lat_bmin = 0, lat_na = 0, lat_nb = 0;
     ml::DevBuf cell_lattice_map;
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores

@@ -205,6 +205,7 @@ struct LatticeFit {
     double c0x = 0, c0y = 0, inv[4] = {0, 0, 0, 0};   // (u, v) = inv * (p - c0)
     int amin = 0, bmin = 0, na = 0, nb = 0;
     double accept_r2 = 0;
+    double g[3] = {0, 0, 0}, guard = 0;   // metric of the basis; ambiguity guard for the analytic pick
     std::vector<int32_t> map;                          // [na][nb] -> sorted slot, -1 empty
 };
 
@@ -331,6 +332,13 @@ LatticeFit fit_lattice(const std::vector<double> &sx, const std::vector<double> 
     L.na = (int)na;
     L.nb = (int)nb;
     L.accept_r2 = r * r;
+    L.g[0] = b1x * b1x + b1y * b1y;
+    L.g[1] = b1x * b2x + b1y * b2y;
+    L.g[2] = b2x * b2x + b2y * b2y;
+    // |d^2(cell) - d^2(node)| <= 2 d eps + eps^2 with d <= ~2 pitch, for each of two candidates,
+    // plus the rounding of the lattice-coordinate expressions (coordinates up to ~1e4 pitches
+    // at 1e-16): a few 1e-12 pitch^2; generous factor on top
+    L.guard = 8.0 * pitch * (eps_max + 1e-11 * pitch) + 1e-9 * pitch * pitch;
     return L;
 }
 
@@ -591,6 +599,8 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
             ctx->lat_na = L.na;
             ctx->lat_nb = L.nb;
             ctx->lat_accept_r2 = L.accept_r2;
+            for (int k = 0; k < 3; ++k) ctx->lat_g[k] = L.g[k];
+            ctx->lat_guard = L.guard;
         }
         ML_HIP(hipStreamSynchronize(ctx->stream));
         ctx->bins_x = bxn;

@@ -314,6 +314,8 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.lat_c0y = ctx->lat_c0y;
     for (int k = 0; k < 4; ++k) a.lat_inv[k] = ctx->lat_inv[k];
     a.lat_accept_r2 = ctx->lat_accept_r2;
+    for (int k = 0; k < 3; ++k) a.lat_g[k] = ctx->lat_g[k];
+    a.lat_guard = ctx->lat_guard;
     a.lat_amin = ctx->lat_amin;
     a.lat_bmin = ctx->lat_bmin;
     a.lat_na = ctx->lat_na;

@@ -37,6 +37,7 @@ struct NfArgs {
     // the nodes of one lattice
     const int *lat_map;            // [lat_na][lat_nb] -> sorted slot or -1
     double lat_c0x, lat_c0y, lat_inv[4], lat_accept_r2;
+    double lat_g[3], lat_guard;    // metric b1.b1, b1.b2, b2.b2 and the ambiguity guard (in d^2)
     int lat_amin, lat_bmin, lat_na, lat_nb;
     // tables
     const TableDesc *tables;
@@ -138,7 +139,36 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
     if (a.lat_map) {
         const double dx = x - a.lat_c0x, dy = y - a.lat_c0y;
         const double u = a.lat_inv[0] * dx + a.lat_inv[1] * dy, v = a.lat_inv[2] * dx + a.lat_inv[3] * dy;
-        const int ia = (int)floor(u) - a.lat_amin, ib = (int)floor(v) - a.lat_bmin;
+        const double fu = floor(u), fv = floor(v);
+        const int ia = (int)fu - a.lat_amin, ib = (int)fv - a.lat_bmin;
+        // First try: pick the nearest NODE analytically (squared distances to the four corners in
+        // lattice coordinates); if it beats the runner-up by more than the guard - which covers
+        // the cells' offsets from their nodes and the rounding of these expressions - only that
+        // one cell has to be fetched.
+        {
+            const double ru = u - fu, rv = v - fv;           // in [0, 1)
+            double d2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double pu = ru - (k >> 1), pv = rv - (k & 1);
+                d2[k] = a.lat_g[0] * pu * pu + 2.0 * a.lat_g[1] * pu * pv + a.lat_g[2] * pv * pv;
+            }
+            int kb = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) kb = d2[k] < d2[kb] ? k : kb;
+            double second = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) second = (k != kb && d2[k] < second) ? d2[k] : second;
+            const int ca = ia + (kb >> 1), cb = ib + (kb & 1);
+            if (second - d2[kb] > a.lat_guard && ca >= 0 && ca < a.lat_na && cb >= 0 && cb < a.lat_nb) {
+                const int s = a.lat_map[(size_t)ca * a.lat_nb + cb];
+                if (s >= 0) {
+                    const double2 q = a.cxy[s];
+                    const double ex = x - q.x, ey = y - q.y;
+                    if (ex * ex + ey * ey <= a.lat_accept_r2) return s;
+                }
+            }
+        }
         int cand[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
