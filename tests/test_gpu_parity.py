@@ -649,3 +649,32 @@ def test_fused_input_modulation(ma):
     assert lib.ml_farfield_transform_async(ctx.handle, 0, 0) != 0
     _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 0))
     ctx.sync()
+
+
+@pytest.mark.parametrize('kind', ['holes', 'jitter', 'shuffled'])
+def test_nearest_cell_on_irregular_cell_sets(ma, kind):
+    """the lattice shortcut of the nearest-cell search must not change results: a lattice with
+    10 % of its cells removed (empty nodes, shortcut still on), cells jittered off the lattice
+    (fit refused -> bins search) and a shuffled cell order (ties go to the lowest ORIGINAL
+    index) against the CPU oracle's exact nearest-neighbour search"""
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    cells = np.array(lens['lens_center_summary'], dtype=float)
+    rng = np.random.default_rng({'holes': 1, 'jitter': 2, 'shuffled': 3}[kind])
+    if kind == 'holes':
+        cells = cells[rng.random(len(cells)) > 0.1]
+    elif kind == 'jitter':
+        cells[:, :2] += rng.uniform(-0.05, 0.05, (len(cells), 2)) * 320e-9
+    else:
+        cells = cells[rng.permutation(len(cells))]
+    r_c = float(lens['lens_periphery_summary']['r_min_list'][0])
+    x = np.linspace(-1.05 * r_c, 1.05 * r_c, 200)     # the centre disc and a rim of periphery
+    args = (0.2e-6, -0.1e-6, -lens['source_distance'], 'x', wl, lens['lens_periphery_summary'],
+            cells, lens['hexgridset'])
+    got = ma.build_nearfield(*args, x_pts=x, y_pts=x)
+    decisions = {}
+    want = nearfield_oracle.build_nearfield(*args, x_pts=x, y_pts=x, decisions=decisions)
+    for g, w in zip(got[:4], want[:4]):
+        err, flips = field_errors(g, w)
+        assert flips == 0 and err < TOL
