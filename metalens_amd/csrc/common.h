@@ -89,6 +89,10 @@ struct TableDesc {
     // 1 / (node[a+1] - node[a]); one round of independent loads instead of a pointer chase
     // followed by a dependent search loop
     int packed;   // 0 no, 1 both axes <= 5 nodes, 2 both <= PACKED_AXIS
+    // both axes uniformly spaced to a few ulp (np.linspace, what characterize() produces): the
+    // cell is floor((x - first) / step); uni_ax = {first0, step0, 1/step0, first1, step1, 1/step1}
+    int uniform;
+    double uni_ax[6];
     double ax0[PACKED_AXIS], inv0[PACKED_AXIS], ax1[PACKED_AXIS], inv1[PACKED_AXIS];
 };
 

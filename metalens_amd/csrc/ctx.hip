@@ -94,6 +94,23 @@ static int refresh_table_desc(ml_ctx *ctx) {
             pack(t.h_axis0, d.ax0, d.inv0);
             pack(t.h_axis1, d.ax1, d.inv1);
         }
+        {
+            auto uniform_axis = [](const std::vector<double> &axis, double *out) {
+                const int n = (int)axis.size();
+                if (n < 2) return false;
+                const double step = (axis[n - 1] - axis[0]) / (n - 1);
+                if (!(step > 0)) return false;
+                double scale = 0;
+                for (double v : axis) scale = std::max(scale, std::fabs(v));
+                for (int a = 0; a < n; ++a)
+                    if (std::fabs(axis[a] - (axis[0] + a * step)) > 4e-15 * std::max(scale, step)) return false;
+                out[0] = axis[0];
+                out[1] = step;
+                out[2] = 1.0 / step;
+                return true;
+            };
+            d.uniform = uniform_axis(t.h_axis0, d.uni_ax) && uniform_axis(t.h_axis1, d.uni_ax + 3) ? 1 : 0;
+        }
         if (s == MAX_SLOTS) {
             // nearfield.py:395-396: ox * 2*pi/x_period - a scalar in the reference
             for (int o = 0; o < t.n_orders; ++o) {

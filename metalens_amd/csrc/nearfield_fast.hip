@@ -107,7 +107,18 @@ __device__ __forceinline__ void locate_packed(const double *node, const double *
 
 __device__ __forceinline__ void locate_uv(const TableDesc &T, double u, double v, int &i0,
                                           double &t0, int &i1, double &t1) {
-    if (T.packed == 1) {          // both axes have <= 5 nodes (the reference's default tables)
+    if (T.uniform) {
+        // uniformly spaced axes: the cell by arithmetic.  A sample within an ulp of a node may
+        // land in the neighbouring cell; the bilinear interpolant is continuous across cells,
+        // so the value is the same to rounding.
+        const double a0 = (u - T.uni_ax[0]) * T.uni_ax[2], a1 = (v - T.uni_ax[3]) * T.uni_ax[5];
+        const double f0 = fmin(fmax(floor(a0), 0.0), (double)(T.n0 - 2));
+        const double f1 = fmin(fmax(floor(a1), 0.0), (double)(T.n1 - 2));
+        i0 = (int)f0;
+        i1 = (int)f1;
+        t0 = (u - fma(f0, T.uni_ax[1], T.uni_ax[0])) * T.uni_ax[2];
+        t1 = (v - fma(f1, T.uni_ax[4], T.uni_ax[3])) * T.uni_ax[5];
+    } else if (T.packed == 1) {          // both axes have <= 5 nodes (the reference's default tables)
         locate_packed<5>(T.ax0, T.inv0, u, i0, t0);
         locate_packed<5>(T.ax1, T.inv1, v, i1, t1);
     } else if (T.packed == 2) {   // <= PACKED_AXIS nodes
