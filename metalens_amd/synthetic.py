@@ -56,10 +56,19 @@ def _records(ux_axis, uy_axis, s, orders, wavelength_in_nm, seed, phase0=0.0):
     return recs
 
 
+def _warp_axis(axis, warp):
+    """``warp`` != 0: move the interior nodes off the uniform spacing (ends fixed, order kept)"""
+    if not warp:
+        return axis
+    lo, hi = axis[0], axis[-1]
+    t = (axis - lo) / (hi - lo)
+    return lo + (hi - lo) * (t + warp * t * (1 - t))
+
+
 def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavelength,
                     cyl_height=550 * nm, n_glass=0, n_tio2=0, num_gratings=24, u_steps=5,
                     local_lateral_period=330 * nm, orders=PERIPHERY_ORDERS, seed=0,
-                    drop_every=0):
+                    drop_every=0, axis_warp=0.0):
     """A 'round'-lens GratingCollection covering incidence angles
     ``[angle_lo, angle_hi]`` (radians) with ``num_gratings`` periods.
 
@@ -73,8 +82,8 @@ def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavel
     L0 = local_lateral_period / math.tan(mid)
     ux_lo = max(-0.99, math.sin(angle_lo) - 0.25)
     ux_hi = min(0.99, math.sin(angle_hi) + 0.25)
-    ux_axis = np.linspace(ux_lo, ux_hi, u_steps)
-    uy_axis = np.linspace(-0.2, 0.2, u_steps)
+    ux_axis = _warp_axis(np.linspace(ux_lo, ux_hi, u_steps), axis_warp)
+    uy_axis = _warp_axis(np.linspace(-0.2, 0.2, u_steps), axis_warp)
     gratings = []
     for i, period in enumerate(np.linspace(p_min, p_max, num_gratings)):
         period = float(period)
@@ -91,12 +100,12 @@ def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavel
 
 def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=550 * nm,
                     n_glass=0, n_tio2=0, num_entries=12, u_steps=5, orders=CENTER_ORDERS,
-                    seed=100):
+                    seed=100, axis_warp=0.0):
     """A HexGridSet of ``num_entries`` cells whose normal-incidence phase
     sweeps 0..2pi, characterised over ux,uy in [-0.499, 0.501]
     (reference lens_center.py:88-90)."""
     wl_nm = int(round(wavelength / nm))
-    axis = np.linspace(-0.499, 0.501, u_steps)
+    axis = _warp_axis(np.linspace(-0.499, 0.501, u_steps), axis_warp)
     gratings = []
     x_amp = []
     for k in range(num_entries):
@@ -113,7 +122,7 @@ def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=55
 
 def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 * nm,
               switch_angle=12 * degree, n_glass=0, num_gratings=24, num_entries=12,
-              max_collection_span=9 * degree, design_kwargs=None):
+              max_collection_span=9 * degree, design_kwargs=None, axis_warp=0.0, u_steps=5):
     """A complete synthetic round lens of ``radius`` and ``numerical_aperture``
     for an on-axis source at the focal distance ``radius / tan(asin(NA))``.
 
@@ -131,10 +140,11 @@ def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 *
     for i in range(n_col):
         lo, hi = float(bounds[i]), float(bounds[i + 1])
         gc = make_collection(Grating, GratingCollection, lo, hi, wavelength, n_glass=n_glass,
-                             num_gratings=num_gratings, seed=i)
+                             num_gratings=num_gratings, seed=i, axis_warp=axis_warp,
+                             u_steps=u_steps)
         collections.append([(lo, hi), gc])
     hgs = make_hexgridset(Grating, HexGridSet, wavelength, n_glass=n_glass,
-                          num_entries=num_entries)
+                          num_entries=num_entries, axis_warp=axis_warp, u_steps=u_steps)
     for _, gc in collections:
         gc.build_interpolators()
     hgs.build_interpolators()

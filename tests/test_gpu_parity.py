@@ -678,3 +678,30 @@ def test_nearest_cell_on_irregular_cell_sets(ma, kind):
     for g, w in zip(got[:4], want[:4]):
         err, flips = field_errors(g, w)
         assert flips == 0 and err < TOL
+
+
+@pytest.mark.parametrize('u_steps', [5, 7, 11])
+def test_nonuniform_table_axes(ma, u_steps):
+    """characterisation tables whose (ux, uy) axes are NOT uniformly spaced take the select-chain
+    (<= 5 nodes, <= 8 nodes) or the search-loop (> 8 nodes) cell location instead of the
+    arithmetic one: near field of a whole small lens against the oracle"""
+    import math
+    import metalens_amd as ma_
+    from metalens_amd import layout, synthetic
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens = synthetic.make_lens((ma_.Grating, ma_.GratingCollection, ma_.HexGridSet),
+                               layout.make_design, radius=30e-6, numerical_aperture=0.4,
+                               wavelength=wl, switch_angle=9 * math.pi / 180, num_gratings=16,
+                               num_entries=10, design_kwargs={'wavelength': wl},
+                               axis_warp=0.35, u_steps=u_steps)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    x = np.linspace(-R, R, 230)
+    args = (0.4e-6, 0.3e-6, -lens['source_distance'], 'y', wl, lens['lens_periphery_summary'],
+            lens['lens_center_summary'], lens['hexgridset'])
+    got = ma.build_nearfield(*args, x_pts=x, y_pts=x)
+    decisions = {}
+    want = nearfield_oracle.build_nearfield(*args, x_pts=x, y_pts=x, decisions=decisions)
+    for g, w in zip(got[:4], want[:4]):
+        err, flips = field_errors(g, w)
+        assert flips == 0 and err < TOL
