@@ -705,3 +705,26 @@ def test_nonuniform_table_axes(ma, u_steps):
     for g, w in zip(got[:4], want[:4]):
         err, flips = field_errors(g, w)
         assert flips == 0 and err < TOL
+
+
+@pytest.mark.parametrize('N,M', [(383, 95), (385, 96), (384, 97)])
+def test_fused_input_modulation_odd_sizes(ma, N, M):
+    """odd aperture / direction counts (unpaired centre sample, self-paired centre direction)
+    through the GPU-resident pipeline with and without the fused input modulation"""
+    from metalens_amd import _lib
+    from metalens_amd.pipeline import HotPath
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    x = np.linspace(-R, R, N)
+    u = (np.arange(M) - M // 2) * 0.004
+    args = ((0.3e-6, -0.2e-6, -lens['source_distance'], 'y'), wl, lens['lens_periphery_summary'],
+            lens['lens_center_summary'], lens['hexgridset'], x, x, u, u)
+    out = {}
+    for fuse in (False, True):
+        hp = HotPath(*args, ctx=_lib.default_context(), fuse_modulation=fuse)
+        hp.step()
+        hp.sync()
+        out[fuse] = hp.results()
+    for key in ('a_theta', 'a_phi', 'Nx', 'Ly'):
+        assert np.abs(out[True][key] - out[False][key]).max() <= 1e-13 * np.abs(out[False][key]).max()
