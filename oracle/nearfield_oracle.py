@@ -244,7 +244,16 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
     nearest = None
     if xc.size:
         cells = np.asarray(lens_center_summary, dtype=float)
-        nearest = cKDTree(cells[:, 0:2]).query(np.column_stack((xc, yc)))[1]
+        tree = cKDTree(cells[:, 0:2])
+        nearest = tree.query(np.column_stack((xc, yc)))[1]
+        if decisions is not None and len(cells) > 1:
+            # samples whose two closest cells are (to rounding) equally far: the reference
+            # takes whichever cKDTree's traversal meets first, which is not a property of the
+            # geometry - callers comparing another implementation skip these samples
+            d2 = tree.query(np.column_stack((xc, yc)), k=2)[0]
+            tie = np.zeros(X.shape, dtype=bool)
+            tie[in_center] = (d2[:, 1] - d2[:, 0]) <= 1e-9 * d2[:, 1]
+            decisions['nearest_tie'] = tie
         cx, cy = cells[nearest, 0], cells[nearest, 1]
         which = cells[nearest, 2].astype(int)
         if not plane_wave:
@@ -309,6 +318,7 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
         decisions['in_center'] = in_center
         decisions['sector'] = sector
         decisions['nearest'] = nearest
+        decisions.setdefault('nearest_tie', np.zeros(X.shape, dtype=bool))
     return Ex, Ey, Hx, Hy, x_pts, y_pts, power, n_glass
 
 
