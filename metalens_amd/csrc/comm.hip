@@ -216,6 +216,7 @@ int ml_farfield_allreduce(ml_ctx *ctx) {
         return ML_ESTATE;
     }
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(flush_unfold(ctx));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     pl.amplitudes_reduced = false;
     return allreduce_dev(ctx, pl.vectors.as<double>(), 4 * n * 2, 0);

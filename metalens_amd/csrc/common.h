@@ -150,6 +150,16 @@ struct FarfieldPlan {
     bool fold2 = false, fold2_has_E = false;
     int fold2_S = 0;
     DevBuf fold2_v, fold2_cm, fold2_sm, fold2_r4, fold2_E, fold2_D, fold2_gt, fold2_ot;
+    // the stage-2 tables depend on the plan and on which rows are resident: rebuilt only when
+    // that changes (serial, row0, resident rows, mirrored)
+    long fold2_key[4] = {-1, -1, -1, -1};
+    int fold2_want_split = 1;
+    // the folded stage 2 leaves its split-K slabs in fold2_ot; they are summed, transposed and
+    // signed into `vectors` by whoever needs the vectors next - the projection does it in the
+    // same kernel (farfield.hip flush_unfold / unfold_project_kernel)
+    bool unfold_pending = false;
+    int unfold_splits = 1, unfold_accumulate = 0;
+    double unfold_alpha[4] = {0, 0, 0, 0};
 };
 
 }  // namespace ml
@@ -204,8 +214,18 @@ struct ml_ctx {
     long fields_premod_serial = -1;
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
-    ml::DevBuf row_first;          // see note_row_extent(); valid only for synthesised fields
+    ml::DevBuf row_first;          // see row_extent_kernel; valid only for synthesised fields
     bool row_first_valid = false;
+    // row_first depends on the grid and the lens radius only: recomputed when either changes
+    long grid_serial = 0, layout_serial = 0, row_first_key[2] = {-1, -1};
+    // bound-violation keys are double-buffered: the synthesis kernel that fills one half clears
+    // the other for the next launch (no separate memset per call)
+    int viol_half = 0;
+    bool viol_zeroed = false;
+    // the per-block power partials of the last synthesis have not been summed into `power` yet:
+    // the projection kernel does it in a spare block, ml_nearfield_result otherwise
+    bool power_pending = false;
+    int n_partials = 0;
     int nf_blocks = 0;
 
     ml::FarfieldPlan plan;
@@ -265,10 +285,36 @@ int zfold_splits(int T, int ksplit);
 void comm_release(ml_ctx *ctx);
 // farfield.hip: undo ml_nearfield_premodulate on the resident fields (no-op if plain)
 int fields_unmodulate(ml_ctx *ctx);
+// farfield.hip: write the radiation vectors a folded stage 2 left in split-K slabs (no-op if none)
+int flush_unfold(ml_ctx *ctx);
 // in-place sum of `count` doubles over the communicator, on the context's stream (no-op without one)
 int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count);
 
 // nearfield.hip
 int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny);
+// sum the pending power partials now (no-op if none are pending)
+int power_flush(ml_ctx *ctx);
+// ML_NO_PLAN_CACHE=1: rebuild every geometry-only table on every call (for timing them)
+bool plan_cache_disabled();
+// Incident-power reduction, second level: the per-block partials of the synthesis kernel are
+// summed in POWER_GROUPS contiguous groups (group g = partial[g*n/G .. (g+1)*n/G), one
+// 256-thread block per group at a time, fixed order inside the group); the host adds the
+// POWER_GROUPS group sums in order.  Deterministic, and no single block walks all partials.
+constexpr int POWER_GROUPS = 32;
+__device__ __forceinline__ void sum_partials_group(const double *partial, int n, double *groups,
+                                                   int g, int tid) {
+    __shared__ double s_part[256];
+    const int lo = (int)((long long)n * g / POWER_GROUPS), hi = (int)((long long)n * (g + 1) / POWER_GROUPS);
+    double acc = 0.0;
+    for (int k = lo + tid; k < hi; k += 256) acc += partial[k];
+    __syncthreads();   // s_part may still be read by the previous group's tree
+    s_part[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) s_part[tid] += s_part[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) groups[g] = s_part[0];
+}
 
 }  // namespace ml

@@ -628,6 +628,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     }
     ML_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_layout = true;
+    ++ctx->layout_serial;
     ctx->tables_dirty = true;   // per-ring table locations depend on the ring periods
     return ML_OK;
 }
@@ -655,6 +656,7 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
             return ML_OK;
         ML_HIP(hipStreamSynchronize(ctx->stream));   // an earlier async copy may still read `host`
         host.assign(src, src + n);
+        ++ctx->grid_serial;
         return h2d(ctx, dev, host.data(), n * sizeof(double));
     };
     ML_TRY(grid_axis(ctx->x_pts, ctx->h_x_pts, x_pts, nx));
@@ -665,9 +667,14 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     ctx->ny = ny;
     const int blocks = std::max(((ny + 255) / 256) * nx, ((ny + 31) / 32) * ((nx + 7) / 8));
     ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
-    ML_TRY(ctx->power.reserve(sizeof(double)));
-    const size_t viol_bytes = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
-    ML_TRY(ctx->violations.reserve(viol_bytes));   // cleared by row_extent_kernel
+    ML_TRY(ctx->power.reserve(POWER_GROUPS * sizeof(double)));
+    // two halves: each synthesis launch clears the one the next launch reports into
+    const size_t viol_bytes = (size_t)2 * (MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
+    ML_TRY(ctx->violations.reserve(viol_bytes));
+    if (!ctx->viol_zeroed) {
+        ML_HIP(hipMemsetAsync(ctx->violations.p, 0, viol_bytes, ctx->stream));
+        ctx->viol_zeroed = true;
+    }
     ML_TRY(ctx->row_first.reserve((size_t)nx * sizeof(int)));
     ctx->row_first_valid = true;
     return nearfield_launch(ctx, p, nx, ny);
@@ -692,12 +699,17 @@ int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violatio
     ML_HIP(hipSetDevice(ctx->device));
     const size_t n_keys = (size_t)(MAX_SLOTS + 1) * MAX_ORDERS * 6;
     std::vector<unsigned long long> keys(n_keys);
-    double pw = 0;
-    ML_HIP(hipMemcpyAsync(&pw, ctx->power.p, sizeof pw, hipMemcpyDeviceToHost, ctx->stream));
-    ML_HIP(hipMemcpyAsync(keys.data(), ctx->violations.p, n_keys * sizeof(unsigned long long),
-                          hipMemcpyDeviceToHost, ctx->stream));
+    double pw = 0, group_sums[POWER_GROUPS];
+    ML_REQUIRE(ctx->power.p && ctx->violations.p, "no near field has been synthesised");
+    ML_TRY(power_flush(ctx));
+    ML_HIP(hipMemcpyAsync(group_sums, ctx->power.p, sizeof group_sums, hipMemcpyDeviceToHost,
+                          ctx->stream));
+    ML_HIP(hipMemcpyAsync(keys.data(),
+                          ctx->violations.as<unsigned long long>() + (size_t)ctx->viol_half * n_keys,
+                          n_keys * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     ML_TRY(prof_harvest(ctx));
+    for (int g = 0; g < POWER_GROUPS; ++g) pw += group_sums[g];   // last level of the reduction
     if (power) *power = pw;
     int count = 0;
     // reference check order: collections in list order, then the centre; per order; ux<, ux>,

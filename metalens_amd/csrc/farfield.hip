@@ -247,11 +247,11 @@ __device__ __forceinline__ double2 cadd(double2 a, double2 b) {
 }
 __device__ __forceinline__ double2 cneg(double2 a) { return make_double2(-a.x, -a.y); }
 
-__global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i = blockIdx.y;
-    if (j >= a.my) return;
-    const size_t at = (size_t)i * a.my + j;
+// One direction: radiation vectors -> spherical components -> the two far-field amplitudes ->
+// power (nearfield_farfield.py:153-189).  Shared by the stand-alone kernel and the fused
+// unfold + projection kernel so that both produce the same bits.
+__device__ __forceinline__ void project_point(const ProjArgs &a, size_t at, int i, int j,
+                                              double2 Nx, double2 Ny, double2 Lx, double2 Ly) {
     const double ux = a.ux[i];
     const double uy = a.pair_list ? a.uy[i] : a.uy[j];
     double uz = 1 - ux * ux - uy * uy;
@@ -264,7 +264,6 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
         a.P[at] = P;
         return;
     }
-    double2 Nx = a.Nx[at], Ny = a.Ny[at], Lx = a.Lx[at], Ly = a.Ly[at];
     if (a.from_fft) {
         // Nx = -fftHy*dxp*dyp, Ny = fftHx*dxp*dyp, Lx = fftEy*dxp*dyp, Ly = -fftEx*dxp*dyp
         Nx = cscale(cscale(cneg(Nx), a.dxp), a.dyp);
@@ -299,6 +298,82 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
     a.P[at] = P;
     if (a.a_theta) a.a_theta[at] = at_;
     if (a.a_phi) a.a_phi[at] = ap_;
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= a.my) return;
+    const size_t at = (size_t)i * a.my + j;
+    const double2 zero = make_double2(0.0, 0.0);
+    if (a.stage == 2)
+        project_point(a, at, i, j, zero, zero, zero, zero);
+    else
+        project_point(a, at, i, j, a.Nx[at], a.Ny[at], a.Lx[at], a.Ly[at]);
+}
+
+// The folded stage 2 leaves `splits` split-K slabs in[sp][f][j][a]; this kernel sums them,
+// transposes to the radiation-vector layout V[3 - f][a][j] (+)= alpha_f * in (exactly what
+// zunfold_out_kernel does, same order of additions) AND projects the four vectors of each
+// direction while they are in registers.  One block = 16 x 16 directions; block index
+// row gridDim.y - 1 is a spare row of blocks, launched when power partials are pending, which sums
+// the synthesis kernel's incident-power partials into their POWER_GROUPS group sums instead.
+struct UnfoldArgs {
+    const double2 *in;
+    double2 *out;
+    Alpha4f alpha;
+    int accumulate, splits;
+    const double *partial;   // null: no power sum
+    int n_partials;
+    double *power_out;
+};
+
+__global__ __launch_bounds__(256) void unfold_project_kernel(const ProjArgs a, const UnfoldArgs u) {
+    if (u.partial && blockIdx.y == gridDim.y - 1) {   // the spare row of blocks
+        for (int g = blockIdx.x; g < POWER_GROUPS; g += gridDim.x)
+            sum_partials_group(u.partial, u.n_partials, u.power_out, g, threadIdx.x);
+        return;
+    }
+    __shared__ double2 tile[4][16][17];
+    const int mx = a.mx, my = a.my;
+    const size_t plane = (size_t)mx * my;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int a0 = blockIdx.x * 16, j0 = blockIdx.y * 16;   // in is [j][a]
+    if (j0 + ty < my && a0 + tx < mx) {
+        const size_t src = (size_t)(j0 + ty) * mx + a0 + tx;
+        double2 v[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) v[f] = u.in[(size_t)f * plane + src];
+        for (int sp = 1; sp < u.splits; ++sp) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const double2 w = u.in[(size_t)sp * 4 * plane + (size_t)f * plane + src];
+                v[f].x += w.x;
+                v[f].y += w.y;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) tile[f][ty][tx] = v[f];
+    }
+    __syncthreads();
+    const int i = a0 + ty, j = j0 + tx;   // now ty walks the directions' first axis
+    if (i >= mx || j >= my) return;
+    const size_t at = (size_t)i * my + j;
+    double2 V[4];                         // V[p] = plane p of Nx, Ny, Lx, Ly
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        double2 v = tile[f][tx][ty];
+        v.x *= u.alpha.v[f];
+        v.y *= u.alpha.v[f];
+        double2 *dst = u.out + (size_t)(3 - f) * plane + at;
+        if (u.accumulate) {
+            v.x += dst->x;
+            v.y += dst->y;
+        }
+        *dst = v;
+        V[3 - f] = v;
+    }
+    project_point(a, at, i, j, V[0], V[1], V[2], V[3]);
 }
 
 static int launch_twiddle(ml_ctx *ctx, double *out, int rows, int cols, int sample_major, int n,
@@ -450,6 +525,8 @@ static int stage2_tables(ml_ctx *ctx, int row0, int mirrored, int *want_split_ou
                                ? forced_split2
                                : (int)std::min<long>(8, std::max<long>(1, 1024 / std::max<long>(tiles, 1)));
     *want_split_out = want_split;
+    const long key[4] = {pl.serial, row0, nxl, mirrored};
+    if (!plan_cache_disabled() && memcmp(key, pl.fold2_key, sizeof key) == 0) return ML_OK;
     const int splits = zfold_splits(T, want_split);
     ML_TRY(pl.fold2_ot.reserve((size_t)splits * 4 * my * mx * 2 * sizeof(double)));
     ML_TRY(pl.fold2_cm.reserve((size_t)T * S * sizeof(double)));
@@ -479,7 +556,23 @@ static int stage2_tables(ml_ctx *ctx, int row0, int mirrored, int *want_split_ou
     const double delta = half - (double)(pl.nx_total - pl.nx_total / 2);
     batch_add(pb, pl.fold2_D.as<double2>(), nullptr, nullptr, 1, mx, 1, delta, 0.0, s_hi, s_lo,
               pl.ux.as<double>(), nullptr);
-    return batch_launch(ctx, pb);
+    ML_TRY(batch_launch(ctx, pb));
+    memcpy(pl.fold2_key, key, sizeof key);
+    return ML_OK;
+}
+
+// Materialise the radiation vectors of a folded stage 2 whose unfold was deferred.
+int flush_unfold(ml_ctx *ctx) {
+    FarfieldPlan &pl = ctx->plan;
+    if (!pl.unfold_pending) return ML_OK;
+    Alpha4f al;
+    for (int k = 0; k < 4; ++k) al.v[k] = pl.unfold_alpha[k];
+    hipLaunchKernelGGL(zunfold_out_kernel, dim3((pl.mx + 31) / 32, (pl.my + 31) / 32, 4), dim3(256),
+                       0, ctx->stream, pl.fold2_ot.as<double2>(), pl.vectors.as<double2>(), pl.my,
+                       pl.mx, al, pl.unfold_accumulate, pl.unfold_splits);
+    ML_HIP(hipGetLastError());
+    pl.unfold_pending = false;
+    return ML_OK;
 }
 
 // `gt_direct`: stage 1 already wrote its result transposed (GT layout, pl.stage1_splits slabs)
@@ -512,12 +605,18 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
                         T, S, pl.fold2_has_E && !gt_direct ? pl.fold2_E.as<double>() : nullptr,
                         pl.fold2_D.as<double>(), pl.fold2_ot.as<double>(), mx, mx, nullptr, 1,
                         want_split, (int64_t)4 * my * mx, ctx->gemm_f32 != 0, io));
-    Alpha4f al;
-    for (int k = 0; k < 4; ++k) al.v[k] = alpha[k];
-    hipLaunchKernelGGL(zunfold_out_kernel, dim3((mx + 31) / 32, (my + 31) / 32, 4), dim3(256), 0,
-                       ctx->stream, pl.fold2_ot.as<double2>(), pl.vectors.as<double2>(), my, mx, al,
-                       accumulate, splits);
-    ML_HIP(hipGetLastError());
+    // the slabs are summed / transposed / signed into `vectors` by the next consumer: the
+    // projection kernel if it comes first (one launch for both), flush_unfold otherwise
+    for (int k = 0; k < 4; ++k) pl.unfold_alpha[k] = alpha[k];
+    pl.unfold_splits = splits;
+    pl.unfold_accumulate = accumulate;
+    pl.unfold_pending = true;
+    (void)mx;
+    static const bool eager = [] {
+        const char *e = getenv("ML_EAGER_UNFOLD");
+        return e && atoi(e) != 0;
+    }();
+    if (eager) ML_TRY(flush_unfold(ctx));
     return ML_OK;
 }
 
@@ -576,6 +675,19 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     ML_REQUIRE(wavelength > 0 && n_glass > 0 && dxp != 0 && dyp != 0, "bad geometry");
     ML_HIP(hipSetDevice(ctx->device));
     FarfieldPlan &pl = ctx->plan;
+    pl.unfold_pending = false;   // vectors of the previous plan that nobody asked for
+    // Same geometry as the active plan (a sweep over sources re-plans every pass): its phase
+    // tables depend on nothing else, keep them.  ML_NO_PLAN_CACHE=1 rebuilds them every call.
+    if (pl.ready && !plan_cache_disabled() && pl.nx_total == nx_total && pl.ny == ny &&
+        pl.mx == mx && pl.my == my && pl.pair_list == pair_list && pl.dxp == dxp &&
+        pl.dyp == dyp && pl.wavelength == wavelength && pl.n_glass == n_glass &&
+        pl.h_ux.size() == (size_t)mx && pl.h_uy.size() == (size_t)my &&
+        memcmp(pl.h_ux.data(), ux, mx * sizeof(double)) == 0 &&
+        memcmp(pl.h_uy.data(), uy, my * sizeof(double)) == 0) {
+        pl.have_vectors = false;
+        pl.amplitudes_reduced = false;
+        return ML_OK;
+    }
     pl.ready = false;
     ++pl.serial;
     pl.have_vectors = false;
@@ -637,6 +749,11 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     }
     ML_REQUIRE(!accumulate || pl.have_vectors, "accumulate requested but nothing to add to");
     ML_HIP(hipSetDevice(ctx->device));
+    // a deferred unfold of the previous transform: needed if this one adds to it, moot otherwise
+    if (accumulate)
+        ML_TRY(flush_unfold(ctx));
+    else
+        pl.unfold_pending = false;
     const int nxl = ctx->nx, ny = pl.ny, mx = pl.mx, my = pl.my;
     // few resident rows (multi-GPU shards) and a long reduction: split the pairs of stage 1 over
     // several workgroups per tile; the slabs are summed by the next kernel
@@ -816,6 +933,28 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage) {
     a.a_theta = pl.amplitudes.as<double2>();
     a.a_phi = pl.amplitudes.as<double2>() + n;
     a.stage = stage;
+    if (pl.unfold_pending && stage != 2) {
+        // vectors still in split-K slabs: unfold and project in one kernel, and let a spare
+        // block sum the synthesis kernel's power partials if they are waiting too
+        UnfoldArgs u;
+        u.in = pl.fold2_ot.as<double2>();
+        u.out = pl.vectors.as<double2>();
+        for (int k = 0; k < 4; ++k) u.alpha.v[k] = pl.unfold_alpha[k];
+        u.accumulate = pl.unfold_accumulate;
+        u.splits = pl.unfold_splits;
+        u.partial = ctx->power_pending ? ctx->partial_power.as<double>() : nullptr;
+        u.n_partials = ctx->n_partials;
+        u.power_out = ctx->power.as<double>();
+        ProfScope scope(ctx, ML_K_PROJECT);
+        hipLaunchKernelGGL(unfold_project_kernel,
+                           dim3((mx + 15) / 16, (my + 15) / 16 + (u.partial ? 1 : 0)), dim3(256), 0,
+                           ctx->stream, a, u);
+        ML_HIP(hipGetLastError());
+        pl.unfold_pending = false;
+        ctx->power_pending = false;
+        return ML_OK;
+    }
+    ML_TRY(flush_unfold(ctx));
     return project_launch(ctx, a, ML_K_PROJECT);
 }
 
@@ -877,6 +1016,8 @@ int ml_farfield_add_vectors(ml_ctx *dst, ml_ctx *src) {
     ML_REQUIRE(pd.mx == ps.mx && pd.my == ps.my && pd.pair_list == ps.pair_list,
                "the two plans have different direction grids");
     ML_HIP(hipSetDevice(dst->device));
+    ML_TRY(flush_unfold(dst));
+    ML_TRY(flush_unfold(src));
     if (!dst->peer_event) ML_HIP(hipEventCreateWithFlags(&dst->peer_event, hipEventDisableTiming));
     if (!src->peer_event) ML_HIP(hipEventCreateWithFlags(&src->peer_event, hipEventDisableTiming));
     const size_t n = 4 * (size_t)pd.mx * (pd.pair_list ? 1 : pd.my);
@@ -915,6 +1056,7 @@ int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double
         return ML_ESTATE;
     }
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(flush_unfold(ctx));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     double *dst[4] = {Nx, Ny, Lx, Ly};
     for (int k = 0; k < 4; ++k)

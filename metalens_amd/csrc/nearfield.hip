@@ -223,11 +223,9 @@ __global__ __launch_bounds__(256) void nearfield_exact_kernel(const NfArgs a) {
 // min(j, ny-1-j).  Samples outside the lens are exactly zero, so the far-field GEMM skips that
 // outer part of each row (zfold.hip).  Inside-the-lens is the kernels' own test
 // sqrt(x^2 + y^2) <= outer boundary, which is monotone in |y|.
-// Runs BEFORE the synthesis kernel and also clears the bound-violation keys (one launch less
-// than a separate memset).
-__global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a, int n_viol_keys) {
+// Depends on the grid and the lens radius only, so it runs when one of them has changed.
+__global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_viol_keys) a.viol[i] = 0ull;
     if (i >= a.nx) return;
     const double x = a.x_pts[i], rmax = a.B[a.n_rings];
     auto inside = [&](int j) { return !(sqrt(x * x + a.y_pts[j] * a.y_pts[j]) > rmax); };
@@ -255,19 +253,28 @@ __global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a, int n_v
     a.row_first[i] = first;
 }
 
-// deterministic tree sum of the per-block partials
-__global__ __launch_bounds__(1024) void sum_partials_kernel(const double *partial, int n,
-                                                            double *out) {
-    __shared__ double s[1024];
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < n; k += 1024) acc += partial[k];
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
-        if (threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *out = s[0];
+// deterministic tree sum of the per-block partials (the same routine runs as a spare block of
+// the projection kernel when a transform follows, farfield.hip)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double *partial, int n,
+                                                           double *groups) {
+    sum_partials_group(partial, n, groups, blockIdx.x, threadIdx.x);
+}
+
+bool plan_cache_disabled() {
+    static const bool v = [] {
+        const char *e = getenv("ML_NO_PLAN_CACHE");
+        return e && atoi(e) != 0;
+    }();
+    return v;
+}
+
+int power_flush(ml_ctx *ctx) {
+    if (!ctx->power_pending) return ML_OK;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(POWER_GROUPS), dim3(256), 0, ctx->stream,
+                       ctx->partial_power.as<double>(), ctx->n_partials, ctx->power.as<double>());
+    ML_HIP(hipGetLastError());
+    ctx->power_pending = false;
+    return ML_OK;
 }
 
 static bool use_exact_kernel();
@@ -328,7 +335,9 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
     a.row_first = ctx->row_first.as<int>();
-    a.viol = ctx->violations.as<unsigned long long>();
+    a.n_viol_keys = (MAX_SLOTS + 1) * MAX_ORDERS * 6;
+    a.viol = ctx->violations.as<unsigned long long>() + (size_t)ctx->viol_half * a.n_viol_keys;
+    a.viol_next = ctx->violations.as<unsigned long long>() + (size_t)(1 - ctx->viol_half) * a.n_viol_keys;
     // opt-in fusion: write the fields already multiplied by the plan's column phasors
     const FarfieldPlan &pl = ctx->plan;
     const bool premod = ctx->premod_enabled && !use_exact_kernel() && pl.ready && pl.fold &&
@@ -349,13 +358,18 @@ static bool use_exact_kernel() {
 
 int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) {
     NfArgs a;
+    // this launch reports into the half the previous launch cleared
+    ctx->viol_half = 1 - ctx->viol_half;
     fill_nf_args(ctx, p, nx, ny, a);
     const dim3 grid((ny + 255) / 256, nx);
     int n_partials = (int)(grid.x * grid.y);
-    // row extents for the far-field GEMM + reset of the violation keys, ahead of the synthesis
-    const int n_keys = (MAX_SLOTS + 1) * MAX_ORDERS * 6;
-    hipLaunchKernelGGL(row_extent_kernel, dim3((std::max(nx, n_keys) + 255) / 256), dim3(256), 0,
-                       ctx->stream, a, n_keys);
+    // row extents for the far-field GEMM: a function of the grid and the lens radius
+    if (plan_cache_disabled() || ctx->row_first_key[0] != ctx->grid_serial ||
+        ctx->row_first_key[1] != ctx->layout_serial) {
+        hipLaunchKernelGGL(row_extent_kernel, dim3((nx + 255) / 256), dim3(256), 0, ctx->stream, a);
+        ctx->row_first_key[0] = ctx->grid_serial;
+        ctx->row_first_key[1] = ctx->layout_serial;
+    }
     if (use_exact_kernel()) {
         ProfScope scope(ctx, ML_K_NEARFIELD);
         hipLaunchKernelGGL(nearfield_exact_kernel, grid, dim3(256), 0, ctx->stream, a);
@@ -363,9 +377,10 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
         ProfScope scope(ctx, ML_K_NEARFIELD);
         ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
     }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(1024), 0, ctx->stream,
-                       ctx->partial_power.as<double>(), n_partials, ctx->power.as<double>());
     ML_HIP(hipGetLastError());
+    // the partials are summed by the projection kernel if one follows, else on demand
+    ctx->n_partials = n_partials;
+    ctx->power_pending = true;
     return ML_OK;
 }
 

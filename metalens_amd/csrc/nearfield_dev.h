@@ -52,7 +52,9 @@ struct NfArgs {
     double *fields;
     double *partial_power;
     int *row_first;   // per aperture row: smallest min(j, ny-1-j) over samples inside the lens
-    unsigned long long *viol;
+    unsigned long long *viol;        // keys of this launch
+    unsigned long long *viol_next;   // keys of the next launch: cleared by block (0, 0)
+    int n_viol_keys;
     // fast kernel, opt-in (ml_nearfield_premodulate): column phasors E[ny] of the active far-field
     // plan; the stored fields are F[i][j] * premod[j], which is what the plan's stage 1 needs
     const double2 *premod;
@@ -312,6 +314,8 @@ __device__ __forceinline__ void block_power(const NfArgs &a, double power_here) 
     if (threadIdx.x == 0)
         a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
             (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int k = threadIdx.x; k < a.n_viol_keys; k += 256) a.viol_next[k] = 0ull;
 }
 
 __device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 Ex, c2 Ey, c2 Hx,

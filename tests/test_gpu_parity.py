@@ -636,16 +636,28 @@ def test_fused_input_modulation(ma):
         scale = max(np.abs(w).max() for w in want[:4])
         for g, w in zip(F, want[:4]):
             assert np.abs(g - w).max() <= TOL * scale
-    # stale plan: synthesise for one plan, re-plan, transform -> refused
+    # stale plan: synthesise for one plan, re-plan for OTHER directions, transform -> refused;
+    # re-planning the same geometry keeps the plan (and its modulation) and is accepted
     hp = HotPath(*args, ctx=_lib.default_context(), fuse_modulation=True)
     ctx, lib = hp.ctx, hp.ctx.lib
     _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 1))
-    plan = lambda: lib.ml_farfield_plan(ctx.handle, x.size, x.size, hp.dxp, hp.dyp, wl, hp.n_glass,
-                                        _lib.dptr(hp.ux), hp.ux.size, _lib.dptr(hp.uy), hp.uy.size, 0)
-    _lib.check(plan())
-    _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(hp.params), _lib.dptr(hp.x_local),
-                                      hp.x_local.size, _lib.dptr(hp.y), hp.y.size))
-    _lib.check(plan())
+    u_other = _lib.f64(hp.uy + 0.001)
+
+    def plan(uy):
+        return lib.ml_farfield_plan(ctx.handle, x.size, x.size, hp.dxp, hp.dyp, wl, hp.n_glass,
+                                    _lib.dptr(hp.ux), hp.ux.size, _lib.dptr(uy), uy.size, 0)
+
+    def synthesise():
+        _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(hp.params),
+                                          _lib.dptr(hp.x_local), hp.x_local.size,
+                                          _lib.dptr(hp.y), hp.y.size))
+
+    _lib.check(plan(hp.uy))
+    synthesise()
+    _lib.check(plan(hp.uy))
+    _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
+    synthesise()
+    _lib.check(plan(u_other))
     assert lib.ml_farfield_transform_async(ctx.handle, 0, 0) != 0
     _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 0))
     ctx.sync()
@@ -728,3 +740,83 @@ def test_fused_input_modulation_odd_sizes(ma, N, M):
         out[fuse] = hp.results()
     for key in ('a_theta', 'a_phi', 'Nx', 'Ly'):
         assert np.abs(out[True][key] - out[False][key]).max() <= 1e-13 * np.abs(out[False][key]).max()
+
+
+def test_merged_launches_keep_per_call_semantics(ma):
+    """The step's small launches are merged: the bound-violation keys are
+    double-buffered and cleared by the synthesis kernel itself, the incident-power partials are
+    summed by a spare block of the projection kernel (or on demand), the stage-2 unfold rides in
+    the projection kernel, plan tables and row extents are kept while the geometry stands.  What
+    a caller sees per call must not change."""
+    from metalens_amd import _lib
+    from metalens_amd.pipeline import HotPath
+    from oracle import nearfield_oracle, farfield_oracle
+    base = np.load(golden_io.golden_path('nearfield_B_periphery_onaxis_x.npz'))
+    um = 1e-6
+    # (1) violations belong to the call that produced them: bad, good, bad, bad, good
+    good = ma.build_nearfield(**case_args(base))
+    for bad in (True, False, True, True, False):
+        if bad:
+            with pytest.raises(ValueError):
+                ma.build_nearfield(**case_args(base, source_x=-180 * um))
+        else:
+            out = ma.build_nearfield(**case_args(base))
+            for g, w in zip(out[:4], good[:4]):
+                assert np.array_equal(g, w)
+            assert out[6] == good[6]
+    # (2) the power summed inside the projection kernel == the power summed on demand, and the
+    # fused unfold + projection == vectors downloaded first (plain unfold) then projected
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    x = np.linspace(-R, R, 384)
+    u = (np.arange(96) - 48) * 0.004
+    source = (0.3e-6, -0.2e-6, -lens['source_distance'], 'x')
+    args = (source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+            lens['hexgridset'], x, x, u, u)
+    hp = HotPath(*args, ctx=_lib.default_context())
+    for _ in range(3):                      # repeated steps re-use plan tables and row extents
+        hp.step()
+    hp.sync()
+    fused = hp.results()
+    ctx, lib = hp.ctx, hp.ctx.lib
+    hp.step_local()                         # near field + transform, nothing consumed yet
+    power = _lib.c_double(0)
+    n_viol = _lib.c_int(0)
+    viol = (_lib.BoundViolation * 8)()
+    _lib.check(lib.ml_nearfield_result(ctx.handle, _lib.byref(power), viol, 8, _lib.byref(n_viol)))
+    assert n_viol.value == 0
+    assert power.value * hp.dxp * hp.dyp == fused['power_local_rows']
+    vec = [np.empty(hp.shape, dtype=np.complex128) for _ in range(4)]
+    _lib.check(lib.ml_farfield_download(ctx.handle, *[_lib.dptr(v) for v in vec]))   # plain unfold
+    P = np.empty(hp.shape)
+    _lib.check(lib.ml_farfield_project(ctx.handle, hp.Z0, _lib.dptr(P), None, None))
+    for v, key in zip(vec, ('Nx', 'Ny', 'Lx', 'Ly')):
+        assert np.array_equal(v, fused[key]), key
+    assert np.array_equal(P, fused['P'], equal_nan=True)
+    # (3) and all of it against the oracle
+    want = nearfield_oracle.build_nearfield(source[0], source[1], source[2], source[3], wl,
+                                            lens['lens_periphery_summary'],
+                                            lens['lens_center_summary'], lens['hexgridset'],
+                                            x_pts=x, y_pts=x)
+    assert abs(fused['power_local_rows'] - want[6]) <= 1e-12 * abs(want[6])
+    N = farfield_oracle.radiation_vectors(want[0], want[1], want[2], want[3], x, x, wl,
+                                                 want[7], u, u)
+    for got, w in zip((fused['Nx'], fused['Ny'], fused['Lx'], fused['Ly']), N):
+        assert np.abs(got - w).max() <= TOL * np.abs(w).max()
+    # (4) a different grid on the same context: extents and tables must follow
+    x2 = np.linspace(-0.8 * R, 0.9 * R, 300)
+    hp2 = HotPath(source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                  lens['hexgridset'], x2, x2, u, u, ctx=_lib.default_context())
+    hp2.step()
+    hp2.sync()
+    got2 = hp2.results()
+    want2 = nearfield_oracle.build_nearfield(source[0], source[1], source[2], source[3], wl,
+                                             lens['lens_periphery_summary'],
+                                             lens['lens_center_summary'], lens['hexgridset'],
+                                             x_pts=x2, y_pts=x2)
+    N2 = farfield_oracle.radiation_vectors(want2[0], want2[1], want2[2], want2[3], x2, x2,
+                                                  wl, want2[7], u, u)
+    for got, w in zip((got2['Nx'], got2['Ny'], got2['Lx'], got2['Ly']), N2):
+        assert np.abs(got - w).max() <= TOL * np.abs(w).max()
+    assert abs(got2['power_local_rows'] - want2[6]) <= 1e-12 * abs(want2[6])
