@@ -19,10 +19,11 @@
 // form) - the radix-2 step of a DFT applied on both sides, exact for any uniform grids.
 // Grids that are not centre-symmetric take the generic zgemm path.
 //
-// Tiling: 64 rows x 128 half-directions (= 256 directions) per workgroup of 8 waves (2 x 4,
-// 32 x 32 per wave, 16 MFMAs per 4 t), K step 16 pairs (= 32 aperture samples).  LDS: four A
-// planes [64][18] + two B planes [16][144] = 74 KB -> 2 workgroups per CU.  With my <= 256 the
-// aperture is read from HBM exactly once.
+// Production tiling: 32 rows x 128 half-directions (= 256 directions) per workgroup of 8 waves
+// (1 x 8: 32 rows x 16 half-directions per wave, 8 MFMAs per 4 pairs), K step 32 pairs (= 64
+// aperture samples), 4 waves per SIMD.  LDS: the folded planes Ge, Go as (re, im) pairs
+// [32][34] = 35 KB; the cos/sin operand is generated in registers.  With my <= 256 the aperture
+// is read from HBM exactly once.
 #include <cstdlib>
 
 #include "common.h"
@@ -41,6 +42,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 template <typename CT> struct Mma;
 template <> struct Mma<double> {
     typedef v4d acc_t;
+    typedef double2 pair_t;
     static __device__ __forceinline__ acc_t mma(double x, double y, acc_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0);
     }
@@ -48,6 +50,7 @@ template <> struct Mma<double> {
 };
 template <> struct Mma<float> {
     typedef v4f acc_t;
+    typedef float2 pair_t;
     static __device__ __forceinline__ acc_t mma(float x, float y, acc_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0);
     }
@@ -91,6 +94,7 @@ template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, 
           bool IN_SUM, bool OUT_T>
 __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs a) {
     typedef typename Mma<CT>::acc_t acc_t;
+    typedef typename Mma<CT>::pair_t pair_t;
     static_assert(FLY || sizeof(CT) == 8, "the table-operand variants are fp64 only");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -99,7 +103,10 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
     constexpr int B_PER = BKT * BN / 2 / NT;      // double2 per thread per plane
     static_assert(BM * BKT % NT == 0 && (BKT * BN / 2) % NT == 0, "tile/threads mismatch");
 
-    __shared__ CT sGer[BM * LDAS], sGei[BM * LDAS], sGor[BM * LDAS], sGoi[BM * LDAS];
+    // folded planes, (re, im) packed: one ds_read_b128 (fp64) / ds_read_b64 (fp32) per plane
+    // and fragment; a row pitch of BKT + 2 pairs makes both conflict-free (lane groups of
+    // MI355X_MICROARCH.md, LDS)
+    __shared__ pair_t sGe[BM * LDAS], sGo[BM * LDAS];
     __shared__ __align__(16) double sC[FLY ? 2 : BKT * LDBS], sS[FLY ? 2 : BKT * LDBS];
 
     const int b = blockIdx.x;
@@ -191,10 +198,13 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
         for (int p = 0; p < A_PER; ++p) {
             const int e = tid + p * NT;
             const int at = (e / BKT) * LDAS + e % BKT;
-            sGer[at] = (CT)(gp[p].x + gm[p].x);
-            sGei[at] = (CT)(gp[p].y + gm[p].y);
-            sGor[at] = (CT)(gp[p].x - gm[p].x);
-            sGoi[at] = (CT)(gp[p].y - gm[p].y);
+            pair_t ev, od;
+            ev.x = (CT)(gp[p].x + gm[p].x);
+            ev.y = (CT)(gp[p].y + gm[p].y);
+            od.x = (CT)(gp[p].x - gm[p].x);
+            od.y = (CT)(gp[p].y - gm[p].y);
+            sGe[at] = ev;
+            sGo[at] = od;
         }
 #pragma unroll
         for (int p = 0; p < (FLY ? 0 : B_PER); ++p) {
@@ -264,10 +274,11 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int at = ((wm * TM + i) * 16 + frow) * LDAS + s * 4 + fk;
-                ger[i] = sGer[at];
-                gei[i] = sGei[at];
-                gor[i] = sGor[at];
-                goi[i] = sGoi[at];
+                const pair_t e = sGe[at], o = sGo[at];
+                ger[i] = e.x;
+                gei[i] = e.y;
+                gor[i] = o.x;
+                goi[i] = o.y;
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -414,25 +425,30 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     }();
     // Measured (tools/zfold_shape_sweep.py, bench.py): 128 half-directions per tile read the
     // aperture fewer times (once when S <= 128); 8 waves per workgroup at 4 waves per SIMD beat 4
-    // waves at 2 by 6-9 %; take them whenever tiles x split-K slabs give ~2 workgroups per CU,
-    // else 64-wide tiles of 4 waves (the folded stage 2: few rows, long reduction).  The
-    // on-the-fly-rotation variants are 2-5 % faster than the table variants (8, 9).
+    // waves at 2 by 6-9 %; with the (re, im)-packed LDS planes a wave tile of 32 rows x 16
+    // half-directions (1 x 8 waves: 4 wide LDS reads + 4 rotation instructions per 8 MFMAs) beats
+    // 16 x 32 (2 x 4 waves: 2 + 8) by 7 % (fp64) / 9 % (fp32).  Take it whenever tiles x split-K
+    // slabs give ~2 workgroups per CU, else 64-wide tiles of 4 waves (the folded stage 2: few
+    // rows, long reduction).  The on-the-fly-rotation variants are 2-5 % faster than the table
+    // variants (8, 9).  Tried and slower: 256-wide tiles of 16 waves, 64-row tiles at 2 waves per
+    // SIMD, deeper unrolling.
     const long wide = (long)((M + 31) / 32) * ((S + 127) / 128) * ksplit;
-    static const int pick_wide = getenv("ML_ZFOLD_PICK_WIDE") ? atoi(getenv("ML_ZFOLD_PICK_WIDE")) : 40;
+    static const int pick_wide = getenv("ML_ZFOLD_PICK_WIDE") ? atoi(getenv("ML_ZFOLD_PICK_WIDE")) : 50;
     static const int pick_small = getenv("ML_ZFOLD_PICK_SMALL") ? atoi(getenv("ML_ZFOLD_PICK_SMALL")) : 31;
     int pick = wide >= 480 ? pick_wide : pick_small;
     if (forced >= 0) pick = forced;
     if (f32) {
-        static const int f32_wide = getenv("ML_ZFOLD_F32_WIDE") ? atoi(getenv("ML_ZFOLD_F32_WIDE")) : 140;
+        static const int f32_wide = getenv("ML_ZFOLD_F32_WIDE") ? atoi(getenv("ML_ZFOLD_F32_WIDE")) : 141;
         static const int f32_small = getenv("ML_ZFOLD_F32_SMALL") ? atoi(getenv("ML_ZFOLD_F32_SMALL")) : 132;
         switch (wide >= 480 ? f32_wide : f32_small) {
             case 131: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, float>(stream, a, ksplit);
             case 132: return launch_fold_io<32, 64, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
+            case 141: return launch_fold_io<32, 128, 1, 8, 1, true, 32, 4, float>(stream, a, ksplit);
             default: return launch_fold_io<32, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
         }
     }
     const bool special_io = a.out_t_rows > 0 || a.in_slabs > 1;
-    if (special_io && pick != 31) pick = 40;   // only the production tiles have the I/O flavours
+    if (special_io && pick != 31 && pick != 40 && pick != 51) pick = 50;   // only these have the I/O flavours
     switch (pick) {
         case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a, ksplit);
         case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a, ksplit);
@@ -440,6 +456,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
         case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a, ksplit);
         case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a, ksplit);
         case 31: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, double>(stream, a, ksplit);
+        case 50: return launch_fold_io<32, 128, 1, 8, 1, true, 32, 4, double>(stream, a, ksplit);
+        case 51: return launch_fold_io<32, 64, 1, 4, 2, true, 32, 2, double>(stream, a, ksplit);
         case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a, ksplit);
         case 42: return launch_fold<32, 128, 2, 4, 1, true, 16, 4>(stream, a, ksplit);
         case 44: return launch_fold<32, 64, 2, 2, 1, true, 16, 4>(stream, a, ksplit);
