@@ -665,7 +665,8 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     ML_TRY(ctx->fields.reserve(4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
-    const int blocks = std::max(((ny + 255) / 256) * nx, ((ny + 31) / 32) * ((nx + 7) / 8));
+    // one power partial per workgroup: exact kernel 256 x 1 samples, fast kernel 8 x 32 or 8 x 8
+    const int blocks = std::max(((ny + 255) / 256) * nx, ((ny + 7) / 8) * ((nx + 7) / 8));
     ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
     ML_TRY(ctx->power.reserve(POWER_GROUPS * sizeof(double)));
     // two halves: each synthesis launch clears the one the next launch reports into

@@ -318,6 +318,14 @@ __device__ __forceinline__ void block_power(const NfArgs &a, double power_here) 
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 256) a.viol_next[k] = 0ull;
 }
 
+// the same for one-wave workgroups: one partial per wave, no barrier
+__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here) {
+    for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
+    if (threadIdx.x == 0) a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = power_here;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
+}
+
 __device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 Ex, c2 Ey, c2 Hx,
                                              c2 Hy) {
     // 16 B per lane per plane, coalesced along y

@@ -175,16 +175,19 @@ __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int 
     acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs a) {
+// BW = waves per workgroup.  BW = 1: every wave is its own workgroup - no barrier at the end
+// (one power partial per wave), so a wave's slot is free the moment it finishes and the waves
+// of a SIMD drift out of phase instead of starting, stalling and finishing together.
+template <int WAVES, int BW>
+__global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const NfArgs a) {
     // Thread -> sample map: each wave covers an 8 x 8 patch of the aperture (not a 64 x 1
     // line), so its lanes fall into 2-3 rings instead of ~10 and the table gathers of one
-    // wave instruction touch few distinct cache lines (measured: -20 % at 4096^2).  The four
-    // waves of a workgroup sit side by side along y: 8 rows x 32 columns per workgroup;
+    // wave instruction touch few distinct cache lines (measured: -20 % at 4096^2).  The
+    // waves of a workgroup sit side by side along y: 8 rows x 8 BW columns per workgroup;
     // stores are 128-byte row segments per plane.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.y * 8 + (lane >> 3);               // x index
-    const int j = blockIdx.x * 32 + wave * 8 + (lane & 7);    // y index (fastest in memory)
+    const int j = blockIdx.x * (8 * BW) + wave * 8 + (lane & 7);    // y index (fastest in memory)
     const ml_nearfield_params &p = a.p;
     double power_here = 0.0;
     Acc acc = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -345,22 +348,32 @@ __global__ __launch_bounds__(256, WAVES) void nearfield_fast_kernel(const NfArgs
         }
         store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
     }
-    block_power(a, power_here);
+    if (BW == 1)
+        wave_power(a, power_here);
+    else
+        block_power(a, power_here);
 }
 
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
-    const dim3 grid((a.ny + 31) / 32, (a.nx + 7) / 8);
-    *n_partials = (int)(grid.x * grid.y);
     static const int waves = [] {
         const char *e = getenv("ML_NF_WAVES");
         return e ? atoi(e) : 4;   // measured: 4 waves/SIMD (124 VGPRs) beats 3 by 10 %, 5 spills
     }();
-    if (waves == 4)
-        hipLaunchKernelGGL(nearfield_fast_kernel<4>, grid, dim3(256), 0, ctx->stream, a);
+    static const int block_waves = [] {
+        const char *e = getenv("ML_NF_BLOCK_WAVES");
+        return e ? atoi(e) : 1;   // measured: one-wave workgroups -6 % (2048^2) / -9 % (4096^2)
+    }();
+    const int bw = block_waves == 1 ? 1 : 4;
+    const dim3 grid((a.ny + 8 * bw - 1) / (8 * bw), (a.nx + 7) / 8);
+    *n_partials = (int)(grid.x * grid.y);
+    if (bw == 1)
+        hipLaunchKernelGGL((nearfield_fast_kernel<4, 1>), grid, dim3(64), 0, ctx->stream, a);
+    else if (waves == 4)
+        hipLaunchKernelGGL((nearfield_fast_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, a);
     else if (waves == 5)
-        hipLaunchKernelGGL(nearfield_fast_kernel<5>, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_fast_kernel<5, 4>), grid, dim3(256), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(nearfield_fast_kernel<3>, grid, dim3(256), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_fast_kernel<3, 4>), grid, dim3(256), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
