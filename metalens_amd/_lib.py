@@ -16,7 +16,9 @@ import numpy as np
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 LIB_NAME = 'libmetalens_hip.so'
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# METALENS_HIP_LIB: another build of the same library (diagnostic builds, A/B timing)
+LIB_PATH = os.environ.get('METALENS_HIP_LIB') or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 K_NEARFIELD, K_TWIDDLE, K_ZGEMM_STAGE1, K_ZGEMM_STAGE2, K_PROJECT, K_LATTICE_POWER, K_COLDOT = range(7)
 KERNEL_NAMES = ('nearfield', 'twiddle', 'zgemm_stage1', 'zgemm_stage2', 'project',

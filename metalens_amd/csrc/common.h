@@ -125,6 +125,14 @@ struct Profile {
     std::vector<hipEvent_t> pool;
 };
 
+// One bucket of the fast kernel's ring search: the number of boundaries strictly below the
+// bucket's lower edge and the boundaries just around it, so that searchsorted needs ONE load
+// (boundaries_below: LUT entry, then two to three dependent boundary loads).
+struct RingBucket {
+    double bm1, b0, b1;   // B[first - 1] (-inf if none), B[first], B[first + 1] (+inf past the end)
+    int first, pad;
+};
+
 struct FarfieldPlan {
     bool ready = false;
     long serial = 0;   // incremented by every ml_farfield_plan call
@@ -188,6 +196,9 @@ struct ml_ctx {
     ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables
     ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
+    ml::DevBuf ring_lutrec;          // fast kernel: coarser buckets that carry the boundaries
+    int lutrec_buckets = 0;
+    double lutrec_inv_h = 0, r_outer = 0;
     int lut_buckets = 0;
     double lut_inv_h = 0;
     ml::DevBuf cell_x, cell_y, cell_xy, cell_which, cell_index, bin_start;

@@ -421,7 +421,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
                       &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
-                      &ctx->ring_rot_half, &ctx->ring_lut, &ctx->cell_x, &ctx->cell_y,
+                      &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
                       &ctx->cell_lattice_map, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
@@ -547,6 +547,30 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     ML_TRY(h2d(ctx, ctx->ring_lut, lut.data(), lut.size() * sizeof(int32_t)));
     ctx->lut_buckets = buckets;
     ctx->lut_inv_h = 1.0 / h;
+    {
+        // fast kernel: buckets about half the narrowest ring wide (so that a bucket rarely holds
+        // more than one boundary), each carrying the boundaries around its lower edge
+        double narrowest = r_max;
+        for (int k = 1; k <= n_rings; ++k)
+            if (B[k] > B[k - 1]) narrowest = std::min(narrowest, B[k] - B[k - 1]);
+        const int nb = (int)std::min(65536.0, std::max(1024.0, std::ceil(2.0 * r_max / narrowest)));
+        const double hb = r_max / nb;
+        std::vector<RingBucket> rec(nb);
+        int at = 0;
+        for (int b = 0; b < nb; ++b) {
+            const double edge = b * hb;
+            while (at <= n_rings && B[at] < edge) ++at;
+            rec[b].first = at;
+            rec[b].pad = 0;
+            rec[b].bm1 = at > 0 ? B[at - 1] : -INFINITY;
+            rec[b].b0 = at <= n_rings ? B[at] : INFINITY;
+            rec[b].b1 = at + 1 <= n_rings ? B[at + 1] : INFINITY;
+        }
+        ML_TRY(h2d(ctx, ctx->ring_lutrec, rec.data(), rec.size() * sizeof(RingBucket)));
+        ctx->lutrec_buckets = nb;
+        ctx->lutrec_inv_h = 1.0 / hb;
+        ctx->r_outer = r_max;
+    }
 
     // centre cells -> uniform grid of bins (about one cell per bin), cells stored in bin
     // order; within a bin the original order is kept (ties resolve to the lowest index)

@@ -295,6 +295,10 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.gc = ctx->ring_gc.as<int>();
     a.ring_i2 = ctx->ring_i2.as<int>();
     a.lut = ctx->ring_lut.as<int>();
+    a.lutrec = ctx->ring_lutrec.as<RingBucket>();
+    a.lutrec_buckets = ctx->lutrec_buckets;
+    a.lutrec_inv_h = ctx->lutrec_inv_h;
+    a.r_outer = ctx->r_outer;
     a.rot_center = ctx->ring_rot_center.as<int>();
     a.rot_half = ctx->ring_rot_half.as<int>();
     a.rot_table = ctx->rot_table.as<double2>();

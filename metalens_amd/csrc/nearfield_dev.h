@@ -25,6 +25,9 @@ struct NfArgs {
     const double *tie_table;   // [rot_len][6]: boundary angle, cos, sin as (hi, lo) pairs
     int lut_buckets;
     double lut_inv_h;
+    const RingBucket *lutrec;
+    int lutrec_buckets;
+    double lutrec_inv_h, r_outer;
     // centre cells
     int n_cells;
     const double *cx, *cy;
@@ -303,6 +306,22 @@ __device__ __forceinline__ int boundaries_below(const NfArgs &a, double r) {
     while (idx <= a.n_rings && a.B[idx] < r) ++idx;
     while (idx > 0 && a.B[idx - 1] >= r) --idx;
     return idx;
+}
+
+// the same answer from one 32-byte bucket record whenever the record settles it (at most one
+// boundary inside the bucket below r), else by the search above
+__device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) {
+    if (r > a.r_outer) return a.n_rings + 1;
+    int bucket = (int)(r * a.lutrec_inv_h);
+    bucket = min(max(bucket, 0), a.lutrec_buckets - 1);
+    // the record as ONE 32-byte vector load: read field by field the compiler fetches two
+    // fields, waits, branches, and only then fetches the other two
+    typedef double rec_t __attribute__((ext_vector_type(4)));
+    const rec_t q = *reinterpret_cast<const rec_t *>(a.lutrec + bucket);   // bm1, b0, b1, (first, pad)
+    const int first = (int)(__double_as_longlong(q.w) & 0xffffffffll);
+    const bool below0 = q.y < r, below1 = q.z < r;
+    if (q.x < r && !below1) return first + (below0 ? 1 : 0);
+    return boundaries_below(a, r);
 }
 
 // incident power: wave reduction, then one partial per block (fixed order)

@@ -79,6 +79,63 @@ __device__ __forceinline__ double recip(double x) {
     return y;
 }
 
+// arctan2(y, x) to ~2 ulp for finite (x, y) != (0, 0): atan(a) = a Q(a^2) on [0, 1] (degree-20
+// least-squares-at-Chebyshev-nodes fit, 2.6e-17 from atan with these rounded coefficients),
+// reciprocal by Newton steps, octant fix-ups by selects.  The device libm's atan2 costs ~160
+// vector instructions here (44 of them v_mov pairs for its coefficients, two divisions, class
+// tests); this is ~45.  Used for the sector decision only, whose near-ties are re-decided
+// exactly (sector_of_fast), so 2 ulp is 1e6 times finer than needed.
+__device__ __forceinline__ double atan2_fast(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double t = mn * recip(mx);
+    const double z = t * t;
+    double q = horner(z, 1.26311784304774261e-05, -1.46170881636250135e-04);
+    q = horner(z, q, 8.03360418162602668e-04);
+    q = horner(z, q, -2.80476555317013152e-03);
+    q = horner(z, q, 7.03864620298981329e-03);
+    q = horner(z, q, -1.36741392883994780e-02);
+    q = horner(z, q, 2.17402138307581337e-02);
+    q = horner(z, q, -2.97007177362342313e-02);
+    q = horner(z, q, 3.65108135272103479e-02);
+    q = horner(z, q, -4.21257239638553257e-02);
+    q = horner(z, q, 4.71972399232111206e-02);
+    q = horner(z, q, -5.25272555732257465e-02);
+    q = horner(z, q, 5.88034200240154306e-02);
+    q = horner(z, q, -6.66637118772109849e-02);
+    q = horner(z, q, 7.69227555520562989e-02);
+    q = horner(z, q, -9.09090660565689823e-02);
+    q = horner(z, q, 1.11111109820871259e-01);
+    q = horner(z, q, -1.42857142815926930e-01);
+    q = horner(z, q, 1.99999999999299460e-01);
+    q = horner(z, q, -3.33333333333328596e-01);
+    // atan(t) = t + t z q'  keeps the leading term exact
+    double r = fma(t * z, q, t);
+    r = ay > ax ? 1.57079632679489655800e+00 - r : r;
+    r = x < 0.0 ? 3.14159265358979311600e+00 - r : r;
+    return y < 0.0 ? -r : r;
+}
+
+// sector_of (nearfield_dev.h) with the ring's constants already in registers and the fast
+// arctangent; the near-tie branch is the same exact recomputation
+__device__ __forceinline__ int sector_of_fast(const NfArgs &a, int half, int rot_center, double x,
+                                              double y, double dphi, double inv_dphi) {
+    double q = atan2_fast(y, x) * inv_dphi;
+    const double fl = floor(q);
+    if (fabs((q - fl) - 0.5) < 1e-9) {
+        const int k = min(max((int)fl, -half - 1), half);
+        const double *e = a.tie_table + (size_t)(rot_center + k) * 6;
+        const double th_hi = e[0], th_lo = e[1], c_hi = e[2], c_lo = e[3], s_hi = e[4], s_lo = e[5];
+        const double p1 = y * c_hi, e1 = fma(y, c_hi, -p1);
+        const double p2 = x * s_hi, e2 = fma(x, s_hi, -p2);
+        const double num = (p1 - p2) + ((e1 - e2) + (y * c_lo - x * s_lo));
+        const double den = x * c_hi + y * s_hi;
+        const double phi = th_hi + (th_lo + num / den);
+        q = phi / dphi;
+    }
+    return min(max((int)rint(q), -half), half);
+}
+
 // cell of a short ascending axis: largest i with axis[i] <= x, clamped to [0, n-2]
 __device__ __forceinline__ void locate_fast(const double *axis, int n, double x, int &i,
                                             double &t) {
@@ -175,6 +232,22 @@ __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int 
     acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
 }
 
+// Diagnostic build (-DML_PHASE_TIMERS, see the Makefile and tools/nearfield_phase_timers.py):
+// every wave stamps s_memtime at fixed points; `dep` is a value that must have arrived by then.
+#ifdef ML_PHASE_TIMERS
+constexpr int PHASE_SLOTS = 16, PHASE_WAVES = 1 << 18;
+__device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
+#define ML_MARK(k, dep)                                   \
+    do {                                                  \
+        asm volatile("" ::"v"(dep));                      \
+        __builtin_amdgcn_sched_barrier(0);                \
+        stamp[k] = __builtin_amdgcn_s_memtime();          \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#else
+#define ML_MARK(k, dep)
+#endif
+
 // BW = waves per workgroup.  BW = 1: every wave is its own workgroup - no barrier at the end
 // (one power partial per wave), so a wave's slot is free the moment it finishes and the waves
 // of a SIMD drift out of phase instead of starting, stalling and finishing together.
@@ -191,10 +264,15 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
     const ml_nearfield_params &p = a.p;
     double power_here = 0.0;
     Acc acc = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+#ifdef ML_PHASE_TIMERS
+    unsigned long long stamp[PHASE_SLOTS] = {0};
+    stamp[0] = __builtin_amdgcn_s_memtime();
+#endif
     if (j < a.ny && i < a.nx) {
         const double x = a.x_pts[i], y = a.y_pts[j];
         const double r = sqrt(x * x + y * y);
-        const int idx = boundaries_below(a, r);
+        const int idx = boundaries_below_fast(a, r);
+        ML_MARK(1, idx);
         if (idx <= a.n_rings) {
             // ---- incidence direction and incident field (amplitude-type arithmetic)
             double ux = 0.0, uy = 0.0, uz = 1.0;
@@ -219,17 +297,28 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
             }
             power_here = Ex_i * Hy_i - Ey_i * Hx_i;
             const double inv_n = recip(p.n_glass);
+            ML_MARK(2, power_here);
 
             if (idx >= 1) {
                 // ================= periphery =================
                 const int ring = idx - 1;
+                // everything that depends on the ring alone is fetched here, in one batch (the
+                // compiler otherwise leaves each load next to its use, a chain of round trips)
                 const int slot = a.gc[ring];
+                const double dphi = a.dphi[ring], rcen = a.rc[ring], period = a.period[ring];
+                const int rot_half = a.rot_half[ring], rot_center = a.rot_center[ring];
+                const double *ok = a.ring_ok + a.ring_ok_off[ring];
+                const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
                 const TableDesc &T = a.tables[slot];
-                const double dphi = a.dphi[ring], rcen = a.rc[ring];
+                // ... and the table bounds in one batch as well: as a || chain they become six
+                // dependent loads with a wait after each
+                const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3],
+                             b4 = T.bounds[4], b5 = T.bounds[5];
                 // sector decision: exact (nearfield.py:169)
-                const int sector = sector_of(a, ring, x, y, dphi, recip(dphi));
-                const double2 cs = a.rot_table[a.rot_center[ring] + sector];
+                const int sector = sector_of_fast(a, rot_half, rot_center, x, y, dphi, recip(dphi));
+                const double2 cs = a.rot_table[rot_center + sector];
                 const double cosr = cs.x, sinr = cs.y;
+                ML_MARK(3, cosr);
                 // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
                 const double xp = x * cosr + y * sinr - rcen;
                 const double yp = -x * sinr + y * cosr;
@@ -239,15 +328,13 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                 int i0, i1;
                 double t0, t1;
                 locate_uv(T, uxp, uyp, i0, t0, i1, t1);
-                const double *ok = a.ring_ok + a.ring_ok_off[ring];
-                const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
                 const int stride1 = 4, stride0 = T.n1 * 4, stride_o = T.n0 * T.n1 * 4;
-                const double period = a.period[ring];
                 // the table-bound tests do not depend on the order: evaluate them once, and only
                 // take the reporting path (per order, in the reference's check order) on failure
-                const bool outside = uxp < T.bounds[0] || uxp > T.bounds[1] || uyp < T.bounds[2] ||
-                                     uyp > T.bounds[3] || period < T.bounds[4] || period > T.bounds[5];
+                const bool outside = (int)(uxp < b0) | (int)(uxp > b1) | (int)(uyp < b2) |
+                                     (int)(uyp > b3) | (int)(period < b4) | (int)(period > b5);
                 Acc pr = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+                ML_MARK(4, t0 + t1 + period);
                 for (int o = 0; o < T.n_orders; ++o) {
                     const double kxp = fma(p.kvac, uxp, ok[2 * o]);
                     const double kyp = fma(p.kvac, uyp, ok[2 * o + 1]);
@@ -259,6 +346,7 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                                    p.k_glass, inv_n, p.Z0, kxp * xp + kyp * yp);
                     }
                 }
+                ML_MARK(5, pr.Ex.r + pr.Hy.i);
                 // input modulation of the far-field plan's stage 1, applied here for free (see
                 // NfArgs); loaded late so that it does not occupy registers through the order loop
                 c2 tilt = {1.0, 0.0};
@@ -289,24 +377,30 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                 acc.Ey = {fma(pr.Ex.r, sinr, pr.Ey.r * cosr), fma(pr.Ex.i, sinr, pr.Ey.i * cosr)};
                 acc.Hx = {fma(pr.Hx.r, cosr, -pr.Hy.r * sinr), fma(pr.Hx.i, cosr, -pr.Hy.i * sinr)};
                 acc.Hy = {fma(pr.Hx.r, sinr, pr.Hy.r * cosr), fma(pr.Hx.i, sinr, pr.Hy.i * cosr)};
+                ML_MARK(6, acc.Ex.r + acc.Hy.i);
             } else if (a.n_cells > 0) {
                 // ================= centre: nearest hexagonal cell =================
                 const TableDesc &T = a.tables[MAX_SLOTS];
-                const int s = nearest_cell_fast(a, x, y);
-                const double2 cc = a.cxy[s];
-                const double ccx = cc.x, ccy = cc.y;
-                const int which = min(max(a.cwhich[s], 0), T.n2 - 1);
+                // what does not depend on the cell first: the (ux, uy) table cell and the
+                // bound tests (bitwise |: one batch of descriptor loads, no chain of branches)
                 int i0, i1;
                 double t0, t1;
                 locate_uv(T, ux, uy, i0, t0, i1, t1);
+                const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3];
+                const bool outside = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
+                const int n2 = T.n2;
+                const int stride1 = n2 * 4, stride0 = T.n1 * n2 * 4;
+                const size_t stride_o = (size_t)T.n0 * T.n1 * n2 * 4;
+                const int s = nearest_cell_fast(a, x, y);
+                ML_MARK(7, s);
+                const double2 cc = a.cxy[s];
+                const double ccx = cc.x, ccy = cc.y;
+                const int which = min(max(a.cwhich[s], 0), n2 - 1);
                 // centre table, amplitude-major: [order][i0][i1][4][K]
                 const double2 *tab = a.center_tab;
-                const int stride1 = T.n2 * 4, stride0 = T.n1 * T.n2 * 4;
-                const size_t stride_o = (size_t)T.n0 * T.n1 * T.n2 * 4;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
                 const double ox_ = x - ccx, oy_ = y - ccy;
-                const bool outside = ux < T.bounds[0] || ux > T.bounds[1] || uy < T.bounds[2] ||
-                                     uy > T.bounds[3];
+                ML_MARK(8, t0 + t1 + ccx + (double)which);
                 for (int o = 0; o < T.n_orders; ++o) {
                     const double kx = fma(p.kvac, ux, T.center_kx[o]);
                     const double ky = fma(p.kvac, uy, T.center_ky[o]);
@@ -316,11 +410,12 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                         // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
                         order_term(acc, tab + o * stride_o + (size_t)i0 * stride0 + i1 * stride1 +
                                             which,
-                                   stride0, stride1, T.n2, t0, t1, Hy_i, Hx_i, kx, ky,
+                                   stride0, stride1, n2, t0, t1, Hy_i, Hx_i, kx, ky,
                                    p.k_glass2 - kt2,
                                    p.k_glass, inv_n, p.Z0, kx * ox_ + ky * oy_);
                     }
                 }
+                ML_MARK(9, acc.Ex.r + acc.Hy.i);
                 // input modulation of the far-field plan's stage 1, (see the periphery branch)
                 c2 tilt = {1.0, 0.0};
                 if (a.premod) {
@@ -344,15 +439,32 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                     acc.Hx = cmul(acc.Hx, tilt);
                     acc.Hy = cmul(acc.Hy, tilt);
                 }
+                ML_MARK(10, acc.Ex.r + acc.Hy.i);
             }
         }
         store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
+        ML_MARK(11, power_here);
     }
     if (BW == 1)
         wave_power(a, power_here);
     else
         block_power(a, power_here);
+#ifdef ML_PHASE_TIMERS
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) etc.: the stores have left the wave
+    stamp[12] = __builtin_amdgcn_s_memtime();
+    const size_t wid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BW + wave;
+    if (lane == 0 && wid < PHASE_WAVES)
+        for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = stamp[k];
+#endif
 }
+
+#ifdef ML_PHASE_TIMERS
+extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase),
+                                    n_waves * PHASE_SLOTS * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
 
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     static const int waves = [] {
