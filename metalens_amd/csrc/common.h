@@ -133,6 +133,13 @@ struct RingBucket {
     int first, pad;
 };
 
+// a centre cell as the fast kernel's lattice shortcut reads it (nearfield_dev.h lattice_pick)
+struct CellRec {
+    double x, y;          // cell centre (NaN for an empty lattice node)
+    int which, index;     // grating type, original index in lens_center_summary
+    double pad;
+};
+
 struct FarfieldPlan {
     bool ready = false;
     long serial = 0;   // incremented by every ml_farfield_plan call
@@ -183,6 +190,7 @@ struct ml_ctx {
     ml::TableSlot slots[ml::MAX_SLOTS];
     ml::TableSlot center;
     ml::DevBuf table_desc;   // TableDesc[MAX_SLOTS + 1], last = centre
+    ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
 
     // layout
@@ -216,7 +224,7 @@ struct ml_ctx {
     double lat_c0x = 0, lat_c0y = 0, lat_inv[4] = {0, 0, 0, 0}, lat_accept_r2 = 0;
     double lat_g[3] = {0, 0, 0}, lat_guard = 0;
     int lat_amin = 0, lat_bmin = 0, lat_na = 0, lat_nb = 0;
-    ml::DevBuf cell_lattice_map;
+    ml::DevBuf cell_lattice_map, cell_lattice_rec;
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
     hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
     // ml_nearfield_premodulate: the synthesis applies the active plan's stage-1 input modulation;

@@ -120,6 +120,7 @@ static int refresh_table_desc(ml_ctx *ctx) {
         }
     }
     ML_TRY(h2d(ctx, ctx->table_desc, h.data(), h.size() * sizeof(TableDesc)));
+    ctx->h_center_desc = h[MAX_SLOTS];
     ML_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
     ctx->tables_dirty = false;
     return ML_OK;
@@ -423,7 +424,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
-                      &ctx->cell_lattice_map, &ctx->fields,
+                      &ctx->cell_lattice_map, &ctx->cell_lattice_rec, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->row_first, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
@@ -632,6 +633,16 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
         ctx->lat_ok = L.ok;
         if (L.ok) {
             ML_TRY(h2d(ctx, ctx->cell_lattice_map, L.map.data(), L.map.size() * sizeof(int32_t)));
+            std::vector<CellRec> rec(L.map.size());
+            for (size_t n = 0; n < L.map.size(); ++n) {
+                const int32_t slot = L.map[n];
+                rec[n].x = slot >= 0 ? sx[slot] : NAN;
+                rec[n].y = slot >= 0 ? sy[slot] : NAN;
+                rec[n].which = slot >= 0 ? sw[slot] : -1;
+                rec[n].index = slot >= 0 ? si[slot] : -1;
+                rec[n].pad = 0.0;
+            }
+            ML_TRY(h2d(ctx, ctx->cell_lattice_rec, rec.data(), rec.size() * sizeof(CellRec)));
             ctx->lat_c0x = L.c0x;
             ctx->lat_c0y = L.c0y;
             for (int k = 0; k < 4; ++k) ctx->lat_inv[k] = L.inv[k];

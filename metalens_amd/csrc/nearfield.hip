@@ -321,6 +321,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.bh = ctx->bin_h;
     a.inv_bh = 1.0 / ctx->bin_h;
     a.lat_map = ctx->lat_ok ? ctx->cell_lattice_map.as<int>() : nullptr;
+    a.lat_rec = ctx->lat_ok ? ctx->cell_lattice_rec.as<CellRec>() : nullptr;
     a.lat_c0x = ctx->lat_c0x;
     a.lat_c0y = ctx->lat_c0y;
     for (int k = 0; k < 4; ++k) a.lat_inv[k] = ctx->lat_inv[k];
@@ -332,6 +333,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.lat_na = ctx->lat_na;
     a.lat_nb = ctx->lat_nb;
     a.tables = ctx->table_desc.as<TableDesc>();
+    a.center_desc = ctx->h_center_desc;
     a.ring_tab = ctx->ring_tab.as<double2>();
     a.ring_tab_off = ctx->ring_tab_off.as<long long>();
     a.ring_ok = ctx->ring_ok.as<double>();

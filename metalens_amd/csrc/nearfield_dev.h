@@ -39,10 +39,16 @@ struct NfArgs {
     // lattice shortcut (ctx.hip fit_lattice), fast kernel: lat_map == nullptr if the cells are not
     // the nodes of one lattice
     const int *lat_map;            // [lat_na][lat_nb] -> sorted slot or -1
+    // the same node map carrying the cell itself: x, y, (which, original index) - one load
+    // instead of map -> position -> type; a NaN position marks an empty node
+    const CellRec *lat_rec;
     double lat_c0x, lat_c0y, lat_inv[4], lat_accept_r2;
     double lat_g[3], lat_guard;    // metric b1.b1, b1.b2, b2.b2 and the ambiguity guard (in d^2)
     int lat_amin, lat_bmin, lat_na, lat_nb;
     // tables
+    // the centre table's descriptor by value: its fields are then kernel arguments (scalar loads
+    // at known offsets) instead of a pointer chase through `tables`
+    TableDesc center_desc;
     const TableDesc *tables;
     // per-ring tables for the fast kernel: period axis already interpolated, complex
     // [order][n0][n1][4] per ring at ring_tab + ring_tab_off[ring]; per-ring order
@@ -128,6 +134,36 @@ __device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y)
 }
 
 
+// Lattice shortcut, first try: the sample lies in (or within rounding of) the lattice
+// parallelogram (ia, ib); pick the nearest of its four corner NODES analytically (squared
+// distances in lattice coordinates).  Returns that node's index in the dense node map if it
+// beats the runner-up by more than the guard - which covers the cells' offsets from their nodes
+// and the rounding of these expressions - and lies inside the map, else -1.
+__device__ __forceinline__ int lattice_pick(const NfArgs &a, double x, double y, int &ia, int &ib) {
+    const double dx = x - a.lat_c0x, dy = y - a.lat_c0y;
+    const double u = a.lat_inv[0] * dx + a.lat_inv[1] * dy, v = a.lat_inv[2] * dx + a.lat_inv[3] * dy;
+    const double fu = floor(u), fv = floor(v);
+    ia = (int)fu - a.lat_amin;
+    ib = (int)fv - a.lat_bmin;
+    const double ru = u - fu, rv = v - fv;           // in [0, 1)
+    double d2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double pu = ru - (k >> 1), pv = rv - (k & 1);
+        d2[k] = a.lat_g[0] * pu * pu + 2.0 * a.lat_g[1] * pu * pv + a.lat_g[2] * pv * pv;
+    }
+    int kb = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) kb = d2[k] < d2[kb] ? k : kb;
+    double second = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) second = (k != kb && d2[k] < second) ? d2[k] : second;
+    const int ca = ia + (kb >> 1), cb = ib + (kb & 1);
+    if (second - d2[kb] > a.lat_guard && ca >= 0 && ca < a.lat_na && cb >= 0 && cb < a.lat_nb)
+        return ca * a.lat_nb + cb;
+    return -1;
+}
+
 // Nearest centre cell, fast path: the 3 x 3 bin neighbourhood of the sample is three
 // contiguous runs of the bin-sorted cell array (one per bin column), so the search is 6 loads of
 // run bounds + one 16-byte load per candidate (~10) instead of ~50 scattered loads.  Exactness
@@ -142,36 +178,14 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
     // lat_accept_r), so a candidate closer than that is the nearest cell - also when corners are
     // empty.  Ties between equidistant candidates go to the lowest original index, as below.
     if (a.lat_map) {
-        const double dx = x - a.lat_c0x, dy = y - a.lat_c0y;
-        const double u = a.lat_inv[0] * dx + a.lat_inv[1] * dy, v = a.lat_inv[2] * dx + a.lat_inv[3] * dy;
-        const double fu = floor(u), fv = floor(v);
-        const int ia = (int)fu - a.lat_amin, ib = (int)fv - a.lat_bmin;
-        // First try: pick the nearest NODE analytically (squared distances to the four corners in
-        // lattice coordinates); if it beats the runner-up by more than the guard - which covers
-        // the cells' offsets from their nodes and the rounding of these expressions - only that
-        // one cell has to be fetched.
-        {
-            const double ru = u - fu, rv = v - fv;           // in [0, 1)
-            double d2[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double pu = ru - (k >> 1), pv = rv - (k & 1);
-                d2[k] = a.lat_g[0] * pu * pu + 2.0 * a.lat_g[1] * pu * pv + a.lat_g[2] * pv * pv;
-            }
-            int kb = 0;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) kb = d2[k] < d2[kb] ? k : kb;
-            double second = INFINITY;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) second = (k != kb && d2[k] < second) ? d2[k] : second;
-            const int ca = ia + (kb >> 1), cb = ib + (kb & 1);
-            if (second - d2[kb] > a.lat_guard && ca >= 0 && ca < a.lat_na && cb >= 0 && cb < a.lat_nb) {
-                const int s = a.lat_map[(size_t)ca * a.lat_nb + cb];
-                if (s >= 0) {
-                    const double2 q = a.cxy[s];
-                    const double ex = x - q.x, ey = y - q.y;
-                    if (ex * ex + ey * ey <= a.lat_accept_r2) return s;
-                }
+        int ia, ib;
+        const int node = lattice_pick(a, x, y, ia, ib);
+        if (node >= 0) {
+            const int s = a.lat_map[node];
+            if (s >= 0) {
+                const double2 q = a.cxy[s];
+                const double ex = x - q.x, ey = y - q.y;
+                if (ex * ex + ey * ey <= a.lat_accept_r2) return s;
             }
         }
         int cand[4];

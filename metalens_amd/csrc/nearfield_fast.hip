@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                 ML_MARK(6, acc.Ex.r + acc.Hy.i);
             } else if (a.n_cells > 0) {
                 // ================= centre: nearest hexagonal cell =================
-                const TableDesc &T = a.tables[MAX_SLOTS];
+                const TableDesc &T = a.center_desc;
                 // what does not depend on the cell first: the (ux, uy) table cell and the
                 // bound tests (bitwise |: one batch of descriptor loads, no chain of branches)
                 int i0, i1;
@@ -391,11 +391,35 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                 const int n2 = T.n2;
                 const int stride1 = n2 * 4, stride0 = T.n1 * n2 * 4;
                 const size_t stride_o = (size_t)T.n0 * T.n1 * n2 * 4;
-                const int s = nearest_cell_fast(a, x, y);
-                ML_MARK(7, s);
-                const double2 cc = a.cxy[s];
-                const double ccx = cc.x, ccy = cc.y;
-                const int which = min(max(a.cwhich[s], 0), n2 - 1);
+                // nearest cell: the lattice shortcut returns the cell itself from the node map
+                // (one load); anything it cannot settle goes through nearest_cell_fast
+                double ccx, ccy;
+                int which_raw;
+                bool have_cell = false;
+                if (a.lat_rec) {
+                    int ia, ib;
+                    const int node = lattice_pick(a, x, y, ia, ib);
+                    if (node >= 0) {
+                        typedef double rec_t __attribute__((ext_vector_type(4)));
+                        const rec_t q = *reinterpret_cast<const rec_t *>(a.lat_rec + node);
+                        const double ex = x - q.x, ey = y - q.y;
+                        if (ex * ex + ey * ey <= a.lat_accept_r2) {   // false for a NaN (empty) node
+                            ccx = q.x;
+                            ccy = q.y;
+                            which_raw = (int)(__double_as_longlong(q.z) & 0xffffffffll);
+                            have_cell = true;
+                        }
+                    }
+                }
+                if (!have_cell) {
+                    const int s = nearest_cell_fast(a, x, y);
+                    const double2 cc = a.cxy[s];
+                    ccx = cc.x;
+                    ccy = cc.y;
+                    which_raw = a.cwhich[s];
+                }
+                ML_MARK(7, ccx);
+                const int which = min(max(which_raw, 0), n2 - 1);
                 // centre table, amplitude-major: [order][i0][i1][4][K]
                 const double2 *tab = a.center_tab;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Extra (manual) GPU parity sweep, not collected by pytest: many random windows, sources and
+"""GPU parity sweep (tests/test_gpu_parity.py runs a short one): random windows, sources and
 polarisations on the 2 mm NA 0.94 lens and on a 1 mm NA 0.5 lens against the CPU oracle,
 counting discrete-decision flips (ring / sector / nearest cell).
 
@@ -29,12 +29,12 @@ def lens_of(radius, na, wl):
                                design_kwargs={'wavelength': wl})
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+def run(n_cases, seed):
+    """returns (worst relative field error, decision flips, exact-tie samples skipped)"""
+    rng = np.random.default_rng(seed)
     wl = 580e-9
     lenses = [lens_of(1e-3, 0.94, wl), lens_of(0.5e-3, 0.5, wl)]
-    worst, flips_total, ties_total, t0 = 0.0, 0, 0, time.time()
+    worst, flips_total, ties_total = 0.0, 0, 0
     for case in range(n_cases):
         lens = lenses[case % 2]
         R = float(lens['lens_periphery_summary']['r_max_list'][-1])
@@ -78,6 +78,14 @@ def main():
             flips_total += flips
             assert flips == 0 and err < 1e-12, (case, err, flips, cx, cy, pol)
         assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6]) or want[6] == 0
+    return worst, flips_total, ties_total
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
+    t0 = time.time()
+    worst, flips_total, ties_total = run(n_cases, seed)
     print('%d cases, worst relative field error %.2e, decision flips %d, exact-tie samples skipped %d, '
           '%.1f s' % (n_cases, worst, flips_total, ties_total, time.time() - t0))
 

@@ -820,3 +820,14 @@ def test_merged_launches_keep_per_call_semantics(ma):
     for got, w in zip((got2['Nx'], got2['Ny'], got2['Lx'], got2['Ly']), N2):
         assert np.abs(got - w).max() <= TOL * np.abs(w).max()
     assert abs(got2['power_local_rows'] - want2[6]) <= 1e-12 * abs(want2[6])
+
+
+@pytest.mark.parametrize('seed', [5, 6])
+def test_random_windows_sweep(ma, seed):
+    """random windows, sources and polarisations on two lenses against the oracle
+    (tests/extra_random_sweep.py; run that script for hundreds of cases): every discrete decision
+    (ring, sector, nearest cell) must agree, fields to 1e-12"""
+    import extra_random_sweep
+    worst, flips, _ties = extra_random_sweep.run(16, seed)
+    assert flips == 0
+    assert worst < TOL
