@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
 // The folded stage 2 leaves `splits` split-K slabs in[sp][f][j][a]; this kernel sums them,
 // transposes to the radiation-vector layout V[3 - f][a][j] (+)= alpha_f * in (exactly what
 // zunfold_out_kernel does, same order of additions) AND projects the four vectors of each
-// direction while they are in registers.  One block = 16 x 16 directions; block index
+// direction while they are on chip.  One block = 8 x 8 directions x 4 fields; block index
 // row gridDim.y - 1 is a spare row of blocks, launched when power partials are pending, which sums
 // the synthesis kernel's incident-power partials into their POWER_GROUPS group sums instead.
 struct UnfoldArgs {
@@ -334,34 +334,30 @@ __global__ __launch_bounds__(256) void unfold_project_kernel(const ProjArgs a, c
             sum_partials_group(u.partial, u.n_partials, u.power_out, g, threadIdx.x);
         return;
     }
-    __shared__ double2 tile[4][16][17];
+    // one block = 8 x 8 directions x 4 fields: thread (f, ty, tx) sums the slabs of one element
+    // (four times as many blocks as one thread per direction with all four fields: 12 vs 15 us at
+    // 256 x 256 directions, the same at 512 x 512)
+    __shared__ double2 tile[4][8][9];
     const int mx = a.mx, my = a.my;
     const size_t plane = (size_t)mx * my;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int a0 = blockIdx.x * 16, j0 = blockIdx.y * 16;   // in is [j][a]
+    const int f = threadIdx.x >> 6, ty = (threadIdx.x >> 3) & 7, tx = threadIdx.x & 7;
+    const int a0 = blockIdx.x * 8, j0 = blockIdx.y * 8;   // in is [j][a]
     if (j0 + ty < my && a0 + tx < mx) {
-        const size_t src = (size_t)(j0 + ty) * mx + a0 + tx;
-        double2 v[4];
-#pragma unroll
-        for (int f = 0; f < 4; ++f) v[f] = u.in[(size_t)f * plane + src];
+        const double2 *src = u.in + (size_t)f * plane + (size_t)(j0 + ty) * mx + a0 + tx;
+        double2 v = src[0];
         for (int sp = 1; sp < u.splits; ++sp) {
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const double2 w = u.in[(size_t)sp * 4 * plane + (size_t)f * plane + src];
-                v[f].x += w.x;
-                v[f].y += w.y;
-            }
+            const double2 w = src[(size_t)sp * 4 * plane];
+            v.x += w.x;
+            v.y += w.y;
         }
-#pragma unroll
-        for (int f = 0; f < 4; ++f) tile[f][ty][tx] = v[f];
+        tile[f][ty][tx] = v;
     }
     __syncthreads();
-    const int i = a0 + ty, j = j0 + tx;   // now ty walks the directions' first axis
-    if (i >= mx || j >= my) return;
+    // transposed: now ty walks the directions' first axis; every thread writes its field's plane
+    const int i = a0 + ty, j = j0 + tx;
+    const bool in_range = i < mx && j < my;
     const size_t at = (size_t)i * my + j;
-    double2 V[4];                         // V[p] = plane p of Nx, Ny, Lx, Ly
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    if (in_range) {
         double2 v = tile[f][tx][ty];
         v.x *= u.alpha.v[f];
         v.y *= u.alpha.v[f];
@@ -371,9 +367,11 @@ __global__ __launch_bounds__(256) void unfold_project_kernel(const ProjArgs a, c
             v.y += dst->y;
         }
         *dst = v;
-        V[3 - f] = v;
+        tile[f][tx][ty] = v;   // own element: no other thread reads it before the barrier
     }
-    project_point(a, at, i, j, V[0], V[1], V[2], V[3]);
+    __syncthreads();
+    if (f == 0 && in_range)   // one wave projects the 64 directions; plane p = field 3 - p
+        project_point(a, at, i, j, tile[3][tx][ty], tile[2][tx][ty], tile[1][tx][ty], tile[0][tx][ty]);
 }
 
 static int launch_twiddle(ml_ctx *ctx, double *out, int rows, int cols, int sample_major, int n,
@@ -947,7 +945,7 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage) {
         u.power_out = ctx->power.as<double>();
         ProfScope scope(ctx, ML_K_PROJECT);
         hipLaunchKernelGGL(unfold_project_kernel,
-                           dim3((mx + 15) / 16, (my + 15) / 16 + (u.partial ? 1 : 0)), dim3(256), 0,
+                           dim3((mx + 7) / 8, (my + 7) / 8 + (u.partial ? 1 : 0)), dim3(256), 0,
                            ctx->stream, a, u);
         ML_HIP(hipGetLastError());
         pl.unfold_pending = false;

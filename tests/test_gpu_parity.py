@@ -770,40 +770,41 @@ def test_merged_launches_keep_per_call_semantics(ma):
     lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
     R = lens['lens_periphery_summary']['r_max_list'][-1]
     x = np.linspace(-R, R, 384)
-    u = (np.arange(96) - 48) * 0.004
     source = (0.3e-6, -0.2e-6, -lens['source_distance'], 'x')
-    args = (source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
-            lens['hexgridset'], x, x, u, u)
-    hp = HotPath(*args, ctx=_lib.default_context())
-    for _ in range(3):                      # repeated steps re-use plan tables and row extents
-        hp.step()
-    hp.sync()
-    fused = hp.results()
-    ctx, lib = hp.ctx, hp.ctx.lib
-    hp.step_local()                         # near field + transform, nothing consumed yet
-    power = _lib.c_double(0)
-    n_viol = _lib.c_int(0)
-    viol = (_lib.BoundViolation * 8)()
-    _lib.check(lib.ml_nearfield_result(ctx.handle, _lib.byref(power), viol, 8, _lib.byref(n_viol)))
-    assert n_viol.value == 0
-    assert power.value * hp.dxp * hp.dyp == fused['power_local_rows']
-    vec = [np.empty(hp.shape, dtype=np.complex128) for _ in range(4)]
-    _lib.check(lib.ml_farfield_download(ctx.handle, *[_lib.dptr(v) for v in vec]))   # plain unfold
-    P = np.empty(hp.shape)
-    _lib.check(lib.ml_farfield_project(ctx.handle, hp.Z0, _lib.dptr(P), None, None))
-    for v, key in zip(vec, ('Nx', 'Ny', 'Lx', 'Ly')):
-        assert np.array_equal(v, fused[key]), key
-    assert np.array_equal(P, fused['P'], equal_nan=True)
-    # (3) and all of it against the oracle
-    want = nearfield_oracle.build_nearfield(source[0], source[1], source[2], source[3], wl,
-                                            lens['lens_periphery_summary'],
-                                            lens['lens_center_summary'], lens['hexgridset'],
-                                            x_pts=x, y_pts=x)
-    assert abs(fused['power_local_rows'] - want[6]) <= 1e-12 * abs(want[6])
-    N = farfield_oracle.radiation_vectors(want[0], want[1], want[2], want[3], x, x, wl,
-                                                 want[7], u, u)
-    for got, w in zip((fused['Nx'], fused['Ny'], fused['Lx'], fused['Ly']), N):
-        assert np.abs(got - w).max() <= TOL * np.abs(w).max()
+    for n_dir in (96, 464):
+        u = (np.arange(n_dir) - n_dir // 2) * (0.384 / n_dir)
+        args = (source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                lens['hexgridset'], x, x, u, u)
+        hp = HotPath(*args, ctx=_lib.default_context())
+        for _ in range(3):                      # repeated steps re-use plan tables and row extents
+            hp.step()
+        hp.sync()
+        fused = hp.results()
+        ctx, lib = hp.ctx, hp.ctx.lib
+        hp.step_local()                         # near field + transform, nothing consumed yet
+        power = _lib.c_double(0)
+        n_viol = _lib.c_int(0)
+        viol = (_lib.BoundViolation * 8)()
+        _lib.check(lib.ml_nearfield_result(ctx.handle, _lib.byref(power), viol, 8, _lib.byref(n_viol)))
+        assert n_viol.value == 0
+        assert power.value * hp.dxp * hp.dyp == fused['power_local_rows']
+        vec = [np.empty(hp.shape, dtype=np.complex128) for _ in range(4)]
+        _lib.check(lib.ml_farfield_download(ctx.handle, *[_lib.dptr(v) for v in vec]))   # plain unfold
+        P = np.empty(hp.shape)
+        _lib.check(lib.ml_farfield_project(ctx.handle, hp.Z0, _lib.dptr(P), None, None))
+        for v, key in zip(vec, ('Nx', 'Ny', 'Lx', 'Ly')):
+            assert np.array_equal(v, fused[key]), key
+        assert np.array_equal(P, fused['P'], equal_nan=True)
+        # (3) and all of it against the oracle
+        want = nearfield_oracle.build_nearfield(source[0], source[1], source[2], source[3], wl,
+                                                lens['lens_periphery_summary'],
+                                                lens['lens_center_summary'], lens['hexgridset'],
+                                                x_pts=x, y_pts=x)
+        assert abs(fused['power_local_rows'] - want[6]) <= 1e-12 * abs(want[6])
+        N = farfield_oracle.radiation_vectors(want[0], want[1], want[2], want[3], x, x, wl,
+                                                     want[7], u, u)
+        for got, w in zip((fused['Nx'], fused['Ny'], fused['Lx'], fused['Ly']), N):
+            assert np.abs(got - w).max() <= TOL * np.abs(w).max()
     # (4) a different grid on the same context: extents and tables must follow
     x2 = np.linspace(-0.8 * R, 0.9 * R, 300)
     hp2 = HotPath(source, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
