@@ -163,7 +163,10 @@ int ml_farfield_lattice_power(ml_ctx *ctx, int nx, int ny,
  * (row0 = 0, nx_total = nx_local for a single GPU); sample j of an axis of n samples
  * sits at (j - ceil(n/2)) * step, which is what fftshift + FFT imply on the lattice.
  *
- *   ml_farfield_plan      : set the geometry and directions, build the twiddle matrices
+ *   ml_farfield_plan      : set the geometry and directions, build the phase tables.  Called
+ *                           again with the arguments of the active plan it keeps that plan
+ *                           (tables depend on the geometry only; a sweep over sources
+ *                           re-plans every pass); any other argument starts a new plan
  *   ml_farfield_transform : radiation vectors Nx,Ny,Lx,Ly [mx][my] of the resident rows
  *                           (a partial sum when the aperture is sharded); accumulate != 0
  *                           adds to the previous result instead of overwriting
@@ -257,6 +260,8 @@ int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p,
 int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_project_async(ml_ctx *ctx, double Z0);
+/* power and bound violations of the LAST synthesis queued on this context (each launch has its
+ * own violation record; the incident power is reduced here unless a projection already did) */
 int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,
                         int max_violations, int *n_violations);
 
