@@ -250,9 +250,9 @@ def main():
             'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
             'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
             'frac': achieved / mfma_peak,
-            # PMC, profiles/r01k_summary.txt: FETCH_SIZE x2 (274.2 MB) + WRITE_SIZE (71.9 MB: two
+            # PMC, profiles/r01m_summary.txt: FETCH_SIZE x2 (272.1 MB) + WRITE_SIZE (69.8 MB: two
             # split-K slabs) per launch [bytes]
-            'traffic': 346.1e6 if default_cfg and args.precision == 'f64' else None,
+            'traffic': 341.9e6 if default_cfg and args.precision == 'f64' else None,
             'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
             'executed_flops_per_launch': executed,
             'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / mfma_peak,
@@ -269,8 +269,8 @@ def main():
         roofs['nearfield'] = {
             'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            # PMC, profiles/r01k_summary.txt: FETCH_SIZE x2 (49.2 MB) + WRITE_SIZE (269.0 MB) per launch
-            'traffic': 318.2e6 if default_cfg else None,
+            # PMC, profiles/r01m_summary.txt: FETCH_SIZE x2 (56.7 MB) + WRITE_SIZE (270.6 MB) per launch
+            'traffic': 327.2e6 if default_cfg else None,
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
             'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by '
                     'instruction issue (fp64 VALU) and dependent L1 gathers, not by HBM '
