@@ -4,7 +4,7 @@ transform for the sbyrnes321/metalens design flow.
 Host code in Python (mirroring the reference's function and class names), compute
 in hand-written HIP for gfx950 behind the C ABI of include/metalens_hip.h.
 """
-from . import constants, grating, interp, layout, lens_center, synthetic  # noqa: F401
+from . import constants, grating, interp, layout, lens_center, postprocess, synthetic  # noqa: F401
 from .grating import Grating, GratingCollection  # noqa: F401
 from .lens_center import HexGridSet  # noqa: F401
 from .nearfield import build_nearfield, build_nearfield_big, good_fft_number  # noqa: F401
