@@ -536,6 +536,7 @@ static int stage2_tables(ml_ctx *ctx, int row0, int mirrored, int *want_split_ou
     const double s_hi = (double)sl, s_lo = (double)(sl - (long double)s_hi);
     const double half = 0.5 * (pl.nx_total - 1);
     const double *v_hi = pl.fold2_v.as<double>(), *v_lo = v_hi + S, *uc = v_hi + 2 * (size_t)S;
+    ProfScope scope(ctx, ML_K_TWIDDLE);
     PhaseBatch pb;
     pb.n = pb.blocks = 0;
     batch_add(pb, nullptr, pl.fold2_cm.as<double>(), pl.fold2_sm.as<double>(), T, S, 1, half - row0,
@@ -609,7 +610,6 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     pl.unfold_splits = splits;
     pl.unfold_accumulate = accumulate;
     pl.unfold_pending = true;
-    (void)mx;
     static const bool eager = [] {
         const char *e = getenv("ML_EAGER_UNFOLD");
         return e && atoi(e) != 0;
@@ -796,7 +796,6 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     int want_split2 = 1;
     if (gt_direct) {
         // stage 2's tables first: stage 1's epilogue applies stage 2's input modulation
-        ProfScope scope(ctx, ML_K_TWIDDLE);
         ML_TRY(stage2_tables(ctx, row0, mirrored, &want_split2));
         io1.out_t_rows = nxl;
         io1.out_E = pl.fold2_has_E ? pl.fold2_E.as<double>() : nullptr;
