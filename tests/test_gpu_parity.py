@@ -832,3 +832,71 @@ def test_random_windows_sweep(ma, seed):
     worst, flips, _ties = extra_random_sweep.run(16, seed)
     assert flips == 0
     assert worst < TOL
+
+
+@pytest.mark.parametrize('side,M,diameter,na', [(4096, 512, 1e-3, 0.5), (8192, 512, 2e-3, 0.94)])
+def test_north_star_size_properties(ma, side, M, diameter, na):
+    """The north-star size (4096^2 aperture window -> 512^2 directions, fp64) and BASELINE
+    configs[2]'s problem (8192^2 on the 2 mm NA 0.94 lens) through the
+    GPU-resident pipeline, checked by properties that do not need the oracle at that size -
+    determinism, exact homogeneity in the dipole moment, additivity over mirrored row shards
+    on two streams - plus the oracle on a sample: 16 near-field rows and a 16 x 16 sample of
+    the far-field amplitudes evaluated by the oracle from the GPU's own near field."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from metalens_amd import _lib
+    from metalens_amd.pipeline import HotPath, HotPath2Stream
+    from oracle import farfield_oracle, nearfield_oracle
+    wl = 580e-9
+    lens, x, u = bench.build_workload(side, M, diameter, na, wl, 1.0)
+    src = (0.0, 0.0, -lens['source_distance'], 'x')
+    args = (src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+            lens['hexgridset'], x, x, u, u)
+    ctx = _lib.default_context()
+    one = HotPath(*args, ctx=ctx)
+    one.step()
+    one.sync()
+    r1 = one.results()
+    # (a) sample against the oracle
+    rows = slice(side // 2 - 8, side // 2 + 8)
+    F = [np.empty((side, side), dtype=np.complex128) for _ in range(4)]
+    _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(a) for a in F]))
+    want = nearfield_oracle.build_nearfield(src[0], src[1], src[2], src[3], wl,
+                                            lens['lens_periphery_summary'],
+                                            lens['lens_center_summary'], lens['hexgridset'],
+                                            x_pts=x[rows], y_pts=x)
+    scale = max(np.abs(w).max() for w in want[:4])
+    assert max(np.abs(g[rows] - w).max() for g, w in zip(F, want[:4])) <= TOL * scale
+    sel = np.arange(0, M, M // 16)
+    ref = farfield_oracle.farfield_direct(*F, x, x, wl, one.n_glass, u[sel], u[sel])
+    for key in ('a_theta', 'a_phi'):
+        assert np.abs(r1[key][np.ix_(sel, sel)] - ref[key]).max() <= TOL * np.abs(ref[key]).max()
+    del F
+    # (b) determinism: the same step again, bit for bit
+    one.step()
+    one.sync()
+    r1b = one.results()
+    for key in ('a_theta', 'a_phi', 'Nx', 'Ly'):
+        assert np.array_equal(r1[key], r1b[key]), key
+    assert r1['power_local_rows'] == r1b['power_local_rows']
+    # (c) homogeneity: twice the dipole moment is an exact power-of-two scaling of every field
+    two_p = HotPath(*args, ctx=ctx, dipole_moment=2e-30)
+    two_p.step()
+    two_p.sync()
+    r2 = two_p.results()
+    for key in ('a_theta', 'a_phi', 'Nx', 'Ny', 'Lx', 'Ly'):
+        assert np.array_equal(r2[key], 2.0 * r1[key]), key
+    assert np.array_equal(r2['P'], 4.0 * r1['P'], equal_nan=True)
+    assert r2['power_local_rows'] == 4.0 * r1['power_local_rows']
+    # (d) additivity: the aperture as two mirrored row shards on two streams
+    pair = HotPath2Stream(*args, ctx=ctx)
+    pair.step()
+    pair.sync()
+    r3 = pair.results()
+    pair.close()
+    for key in ('a_theta', 'a_phi', 'Nx', 'Ny', 'Lx', 'Ly'):
+        assert np.abs(r3[key] - r1[key]).max() <= 1e-13 * np.abs(r1[key]).max(), key
+    assert abs(r3['power_local_rows'] - r1['power_local_rows']) <= 1e-12 * r1['power_local_rows']
