@@ -248,6 +248,9 @@ int ml_profile_enable(ml_ctx *ctx, int on);
  * timed launch costs two event records on the stream (~4 us of serialisation per pair on
  * MI355X), so a benchmark that only needs its dominant kernels selects those.               */
 int ml_profile_select(ml_ctx *ctx, unsigned mask);
+/* time only every `period`-th launch of each selected kernel (default 1 = every launch): the
+ * averages are then over a sample of the launches and the instrumentation costs 1/period     */
+int ml_profile_sample(ml_ctx *ctx, int period);
 int ml_profile_reset(ml_ctx *ctx);
 int ml_profile_get(ml_ctx *ctx, int kernel, int64_t *launches, double *total_ms);
 /* wait for everything queued on the context's stream */

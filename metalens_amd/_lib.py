@@ -32,6 +32,7 @@ SYMBOLS = (
     'ml_fields_download', 'ml_fields_upload', 'ml_fields_shape', 'ml_farfield_lattice_power',
     'ml_farfield_plan', 'ml_farfield_transform', 'ml_farfield_allreduce', 'ml_farfield_project',
     'ml_farfield_download', 'ml_farfield_plan_info', 'ml_farfield_set_precision', 'ml_farfield_project_reduce', 'ml_farfield_add_vectors', 'ml_profile_select',
+    'ml_profile_sample',
     'ml_nearfield_premodulate', 'ml_comm_unique_id', 'ml_comm_init', 'ml_comm_allreduce_host',
     'ml_comm_barrier', 'ml_profile_enable', 'ml_profile_reset', 'ml_profile_get', 'ml_sync',
     'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_transform_mirrored',
@@ -112,6 +113,7 @@ def load():
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
     lib.ml_farfield_add_vectors.argtypes = [c_void_p, c_void_p]
     lib.ml_profile_select.argtypes = [c_void_p, ctypes.c_uint]
+    lib.ml_profile_sample.argtypes = [c_void_p, c_int]
     lib.ml_nearfield_premodulate.argtypes = [c_void_p, c_int]
     lib.ml_comm_unique_id.argtypes = [POINTER(c_uint8)]
     lib.ml_comm_init.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_int]
@@ -204,10 +206,12 @@ class Context:
         (include/metalens_hip.h, ml_farfield_set_precision); everything else stays fp64"""
         check(self.lib.ml_farfield_set_precision(self.handle, {'f64': 0, 'f32': 1}[precision]))
 
-    def profile(self, on=True, kernels=None):
-        """time kernel launches with HIP events; ``kernels`` = names to time (default all)"""
+    def profile(self, on=True, kernels=None, every=1):
+        """time kernel launches with HIP events; ``kernels`` = names to time (default all),
+        ``every`` = time only every n-th launch of each (a sample, at 1/n of the cost)"""
         mask = 0xffffffff if kernels is None else sum(1 << KERNEL_NAMES.index(k) for k in kernels)
         check(self.lib.ml_profile_select(self.handle, mask))
+        check(self.lib.ml_profile_sample(self.handle, int(every)))
         check(self.lib.ml_profile_enable(self.handle, int(on)))
 
     def profile_reset(self):

@@ -114,6 +114,8 @@ struct KernelTimer {
 struct Profile {
     bool on = false;
     unsigned mask = 0xffffffffu;   // bit k: kernel id k is timed while `on`
+    int period = 1;                // every period-th launch of a selected kernel is timed
+    int64_t seen[ML_K_COUNT] = {0};
     int64_t launches[ML_K_COUNT] = {0};
     double total_ms[ML_K_COUNT] = {0};
     // events are recorded around each launch and harvested lazily

@@ -38,6 +38,7 @@ static hipEvent_t take_event(ml_ctx *ctx) {
 
 void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b) {
     if (!ctx->prof.on || !((ctx->prof.mask >> kernel) & 1u)) return;
+    if (ctx->prof.seen[kernel]++ % ctx->prof.period != 0) return;
     *a = take_event(ctx);
     *b = take_event(ctx);
     (void)hipEventRecord(*a, ctx->stream);
@@ -836,6 +837,14 @@ int ml_profile_select(ml_ctx *ctx, unsigned mask) {
     return ML_OK;
 }
 
+int ml_profile_sample(ml_ctx *ctx, int period) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(period >= 1, "period must be >= 1");
+    ctx->prof.period = period;
+    for (int k = 0; k < ML_K_COUNT; ++k) ctx->prof.seen[k] = 0;
+    return ML_OK;
+}
+
 int ml_profile_reset(ml_ctx *ctx) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_HIP(hipSetDevice(ctx->device));
@@ -844,6 +853,7 @@ int ml_profile_reset(ml_ctx *ctx) {
     for (int k = 0; k < ML_K_COUNT; ++k) {
         ctx->prof.launches[k] = 0;
         ctx->prof.total_ms[k] = 0;
+        ctx->prof.seen[k] = 0;
     }
     return ML_OK;
 }
