@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <cfloat>
+
 #include "common.h"
 
 namespace ml {
@@ -406,6 +408,20 @@ static int upload_if_changed(ml_ctx *ctx, DevBuf &dev, std::vector<double> &host
     return ML_OK;
 }
 
+// How far (in radians of phase at the aperture edge) a direction grid may deviate from exact
+// centre symmetry and still take the folded path: 1e-13 rad, or - for large apertures, where
+// that is less than the grid's own representation error - four times the phase uncertainty that
+// half an ulp of the largest direction cosine already carries (2 pi kappa p_max eps/2 max|u|).
+// A grid computed as centre +/- k*step in floating point is symmetric to about one ulp; without
+// the second term a 16384-sample aperture (4.3 mm at lambda/2.2) falls back to the generic
+// complex GEMM, 5x slower, for an asymmetry of 3e-13 rad that the inputs cannot resolve anyway.
+static long double symmetry_tolerance(long double kappa, long double p_max, const double *u, int n) {
+    long double umax = 0;
+    for (int k = 0; k < n; ++k) umax = fmaxl(umax, fabsl((long double)u[k]));
+    const long double inherent = 2 * M_PIl * kappa * p_max * umax * (long double)DBL_EPSILON * 0.5L;
+    return fmaxl(1e-13L, 4 * inherent);
+}
+
 // Decide whether stage 1 can run folded (zfold.hip) and build its tables.  Needs a tensor
 // grid whose uy are centre-symmetric to within 1e-13 rad of phase at the aperture edge.
 static int plan_fold(ml_ctx *ctx, const double *uy) {
@@ -430,7 +446,7 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
         v[s] = (double)vs;
         v[S + s] = (double)(vs - (long double)v[s]);
     }
-    if (2 * M_PIl * kappa * p_max * worst > 1e-13L) return ML_OK;   // not symmetric enough
+    if (2 * M_PIl * kappa * p_max * worst > symmetry_tolerance(kappa, p_max, uy, my)) return ML_OK;
     v[2 * (size_t)S] = (double)uc;
     v[2 * (size_t)S + 1] = (double)(uc - (long double)v[2 * (size_t)S]);
     ML_TRY(upload_if_changed(ctx, pl.fold_v, pl.h_fold_v, v.data(), v.size()));
@@ -494,7 +510,7 @@ static int plan_fold2(ml_ctx *ctx, const double *ux) {
         v[s] = (double)vs;
         v[S + s] = (double)(vs - (long double)v[s]);
     }
-    if (2 * M_PIl * kappa * p_max * worst > 1e-13L) return ML_OK;
+    if (2 * M_PIl * kappa * p_max * worst > symmetry_tolerance(kappa, p_max, ux, mx)) return ML_OK;
     v[2 * (size_t)S] = (double)uc;
     v[2 * (size_t)S + 1] = (double)(uc - (long double)v[2 * (size_t)S]);
     ML_TRY(upload_if_changed(ctx, pl.fold2_v, pl.h_fold2_v, v.data(), v.size()));

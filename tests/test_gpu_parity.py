@@ -900,3 +900,32 @@ def test_north_star_size_properties(ma, side, M, diameter, na):
     for key in ('a_theta', 'a_phi', 'Nx', 'Ny', 'Lx', 'Ly'):
         assert np.abs(r3[key] - r1[key]).max() <= 1e-13 * np.abs(r1[key]).max(), key
     assert abs(r3['power_local_rows'] - r1['power_local_rows']) <= 1e-12 * r1['power_local_rows']
+
+
+@pytest.mark.parametrize('N,M', [(2048, 256), (16384, 1024), (65536, 1024)])
+def test_large_aperture_plans_take_the_folded_path(ma, N, M):
+    """A direction grid computed as (k - M/2) * du in floating point is centre-symmetric only to
+    about one ulp; for large apertures that is more than 1e-13 rad of phase at the aperture edge.
+    The symmetry test scales with the grid's own rounding (farfield.hip symmetry_tolerance), so
+    such grids must still plan the folded kernel (the generic complex GEMM is ~5x slower), while
+    a grid perturbed well above its rounding must not."""
+    from metalens_amd import _lib
+    ctx = _lib.default_context()
+    lib = ctx.lib
+    wl, n_glass = 580e-9, 1.459
+    pitch = wl / 2.2
+    du = (wl / n_glass) / (pitch * N)
+    u = _lib.f64((np.arange(M) - M // 2) * du)
+
+    def planned_kernel(uy):
+        _lib.check(lib.ml_farfield_plan(ctx.handle, N, N, pitch, pitch, wl, n_glass, _lib.dptr(u),
+                                        u.size, _lib.dptr(uy), uy.size, 0))
+        k = _lib.c_int(-1)
+        _lib.check(lib.ml_farfield_plan_info(ctx.handle, _lib.byref(k)))
+        return k.value
+
+    assert planned_kernel(u) == 1
+    bent = u.copy()
+    bent[3] += 1e-9 * du * M          # far above rounding, far below anything a user would notice
+    assert planned_kernel(bent) == 0
+    ctx.sync()
