@@ -263,6 +263,23 @@ int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p,
 int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_project_async(ml_ctx *ctx, double Z0);
+/* Exact ties of the nearest-cell search.  A centre-region sample that is exactly equidistant
+ * from two cells (it sits on a mirror line of the cell lattice: the x = 0 row of a symmetric
+ * grid with an odd number of samples) has no defined nearest cell; the reference takes the one
+ * scipy's cKDTree.query (nearfield.py:363-364) meets first, which depends on how that tree was
+ * built and cannot be restated.  The kernels therefore REPORT such samples (provisionally
+ * taking the lowest cell index) and look the answer up in a list the host supplies:
+ *   ml_nearfield_ties        : *n_ties = samples the last synthesis could not settle; up to
+ *                              max_ids of them (sample id = local row * ny + column) are
+ *                              written to sample_ids (at most ML_TIE_CAPACITY are kept)
+ *   ml_nearfield_tie_answers : for these sample ids take these cells (row index into
+ *                              lens_center_summary, what cKDTree.query returned); replaces the
+ *                              previous list, belongs to the current grid and layout and is
+ *                              dropped when either changes.  A synthesis run afterwards is exact.
+ * metalens_amd/nearfield.py does this round trip (scipy on the host) whenever ties are reported. */
+#define ML_TIE_CAPACITY 1048576
+int ml_nearfield_ties(ml_ctx *ctx, int64_t *sample_ids, int max_ids, int *n_ties);
+int ml_nearfield_tie_answers(ml_ctx *ctx, const int64_t *sample_ids, const int32_t *cell_index, int n);
 /* power and bound violations of the LAST synthesis queued on this context (each launch has its
  * own violation record; the incident power is reduced here unless a projection already did) */
 int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,

@@ -20,6 +20,8 @@ LIB_NAME = 'libmetalens_hip.so'
 LIB_PATH = os.environ.get('METALENS_HIP_LIB') or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
+TIE_CAPACITY = 1048576   # ML_TIE_CAPACITY
+
 K_NEARFIELD, K_TWIDDLE, K_ZGEMM_STAGE1, K_ZGEMM_STAGE2, K_PROJECT, K_LATTICE_POWER, K_COLDOT = range(7)
 KERNEL_NAMES = ('nearfield', 'twiddle', 'zgemm_stage1', 'zgemm_stage2', 'project',
                 'lattice_power', 'coldot')
@@ -37,7 +39,7 @@ SYMBOLS = (
     'ml_comm_barrier', 'ml_profile_enable', 'ml_profile_reset', 'ml_profile_get', 'ml_sync',
     'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_transform_mirrored',
     'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
-    'ml_nearfield_result',
+    'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
 )
 
 
@@ -93,6 +95,8 @@ def load():
     lib.ml_nearfield_async.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int]
     lib.ml_nearfield_result.argtypes = [c_void_p, _dp, POINTER(BoundViolation), c_int,
                                         POINTER(c_int)]
+    lib.ml_nearfield_ties.argtypes = [c_void_p, POINTER(c_int64), c_int, POINTER(c_int)]
+    lib.ml_nearfield_tie_answers.argtypes = [c_void_p, POINTER(c_int64), POINTER(c_int32), c_int]
     lib.ml_fields_download.argtypes = [c_void_p, _dp, _dp, _dp, _dp]
     lib.ml_fields_upload.argtypes = [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]
     lib.ml_fields_shape.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]

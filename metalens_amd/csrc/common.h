@@ -227,6 +227,12 @@ struct ml_ctx {
     double lat_g[3] = {0, 0, 0}, lat_guard = 0;
     int lat_amin = 0, lat_bmin = 0, lat_na = 0, lat_nb = 0;
     ml::DevBuf cell_lattice_map, cell_lattice_rec;
+    // exact nearest-cell ties (nearfield_dev.h settle_tie): samples the last synthesis could not
+    // settle, and the host's answers for the current (grid, layout)
+    ml::DevBuf tie_count, tie_list, ovr_key, ovr_slot;
+    int n_ovr = 0;
+    long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
+    std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
     hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
     // ml_nearfield_premodulate: the synthesis applies the active plan's stage-1 input modulation;

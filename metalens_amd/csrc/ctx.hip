@@ -425,7 +425,8 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
-                      &ctx->cell_lattice_map, &ctx->cell_lattice_rec, &ctx->fields,
+                      &ctx->cell_lattice_map, &ctx->cell_lattice_rec, &ctx->tie_count, &ctx->tie_list,
+                      &ctx->ovr_key, &ctx->ovr_slot, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->row_first, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
@@ -624,6 +625,8 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
         ML_TRY(h2d(ctx, ctx->cell_xy, sxy.data(), sxy.size() * sizeof(double)));
         ML_TRY(h2d(ctx, ctx->cell_which, sw.data(), n_cells * sizeof(int32_t)));
         ML_TRY(h2d(ctx, ctx->cell_index, si.data(), n_cells * sizeof(int32_t)));
+        ctx->h_slot_of_cell.assign(n_cells, 0);
+        for (int c = 0; c < n_cells; ++c) ctx->h_slot_of_cell[si[c]] = c;
         ML_TRY(h2d(ctx, ctx->bin_start, start.data(), start.size() * sizeof(int32_t)));
         // lattice shortcut for the nearest-cell search (sorted slots index the arrays above)
         static const bool no_lattice = [] {
@@ -714,6 +717,15 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     }
     ML_TRY(ctx->row_first.reserve((size_t)nx * sizeof(int)));
     ctx->row_first_valid = true;
+    // nearest-cell ties: the record of this launch starts empty; answers for another geometry
+    // are dropped
+    // (two counters, used alternately like the violation halves: a launch clears the other one)
+    if (!ctx->tie_count.p) {
+        ML_TRY(ctx->tie_count.reserve(2 * sizeof(int)));
+        ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, 2 * sizeof(int), ctx->stream));
+    }
+    ML_TRY(ctx->tie_list.reserve((size_t)ML_TIE_CAPACITY * sizeof(long long)));
+    if (ctx->ovr_for[0] != ctx->grid_serial || ctx->ovr_for[1] != ctx->layout_serial) ctx->n_ovr = 0;
     return nearfield_launch(ctx, p, nx, ny);
 }
 
@@ -728,6 +740,52 @@ static double decode_key(unsigned long long k, int check) {
     double v;
     memcpy(&v, &b, sizeof v);
     return v;
+}
+
+int ml_nearfield_ties(ml_ctx *ctx, int64_t *sample_ids, int max_ids, int *n_ties) {
+    ML_REQUIRE(ctx && n_ties, "NULL argument");
+    ML_REQUIRE(ctx->tie_count.p, "no near field has been synthesised");
+    ML_HIP(hipSetDevice(ctx->device));
+    int count = 0;
+    ML_HIP(hipMemcpyAsync(&count, ctx->tie_count.as<int>() + ctx->viol_half, sizeof count,
+                          hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    *n_ties = count;
+    const int n = std::min(std::min(count, ML_TIE_CAPACITY), max_ids);
+    if (sample_ids && n > 0) {
+        static_assert(sizeof(long long) == sizeof(int64_t), "sample ids are 64-bit");
+        ML_HIP(hipMemcpy(sample_ids, ctx->tie_list.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    return ML_OK;
+}
+
+int ml_nearfield_tie_answers(ml_ctx *ctx, const int64_t *sample_ids, const int32_t *cell_index, int n) {
+    ML_REQUIRE(ctx && (n == 0 || (sample_ids && cell_index)), "NULL argument");
+    ML_REQUIRE(n >= 0, "negative count");
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_HIP(hipStreamSynchronize(ctx->stream));   // a running synthesis may be reading the old list
+    std::vector<std::pair<long long, int>> kv((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        ML_REQUIRE(cell_index[k] >= 0 && (size_t)cell_index[k] < ctx->h_slot_of_cell.size(),
+                   "cell index %d out of range", cell_index[k]);
+        kv[k] = {(long long)sample_ids[k], ctx->h_slot_of_cell[cell_index[k]]};
+    }
+    std::sort(kv.begin(), kv.end());
+    std::vector<long long> keys((size_t)n);
+    std::vector<int32_t> slots((size_t)n);
+    for (int k = 0; k < n; ++k) {
+        keys[k] = kv[k].first;
+        slots[k] = kv[k].second;
+    }
+    if (n > 0) {
+        ML_TRY(h2d(ctx, ctx->ovr_key, keys.data(), keys.size() * sizeof(long long)));
+        ML_TRY(h2d(ctx, ctx->ovr_slot, slots.data(), slots.size() * sizeof(int32_t)));
+        ML_HIP(hipStreamSynchronize(ctx->stream));   // the staging vectors go out of scope
+    }
+    ctx->n_ovr = n;
+    ctx->ovr_for[0] = ctx->grid_serial;
+    ctx->ovr_for[1] = ctx->layout_serial;
+    return ML_OK;
 }
 
 int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void nearfield_exact_kernel(const NfArgs a) {
             } else if (a.n_cells > 0) {
                 // ---- lens centre: nearest hexagonal cell (nearfield.py:359-466)
                 const TableDesc &T = a.tables[MAX_SLOTS];
-                const int s = nearest_cell(a, x, y);
+                const int s = nearest_cell(a, x, y, (long long)i * a.ny + j);
                 const double ccx = a.cx[s], ccy = a.cy[s];
                 const int which = a.cwhich[s];
                 const int i2 = min(max(which, 0), T.n2 - 2);
@@ -322,6 +322,13 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.inv_bh = 1.0 / ctx->bin_h;
     a.lat_map = ctx->lat_ok ? ctx->cell_lattice_map.as<int>() : nullptr;
     a.lat_rec = ctx->lat_ok ? ctx->cell_lattice_rec.as<CellRec>() : nullptr;
+    a.tie_count = ctx->tie_count.as<int>() + ctx->viol_half;
+    a.tie_count_next = ctx->tie_count.as<int>() + (1 - ctx->viol_half);
+    a.tie_list = ctx->tie_list.as<long long>();
+    a.tie_cap = ML_TIE_CAPACITY;
+    a.ovr_key = ctx->ovr_key.as<long long>();
+    a.ovr_slot = ctx->ovr_slot.as<int>();
+    a.n_ovr = ctx->n_ovr;
     a.lat_c0x = ctx->lat_c0x;
     a.lat_c0y = ctx->lat_c0y;
     for (int k = 0; k < 4; ++k) a.lat_inv[k] = ctx->lat_inv[k];

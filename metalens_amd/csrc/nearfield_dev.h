@@ -35,6 +35,17 @@ struct NfArgs {
     const double2 *cxy;
     const double2 *center_tab;   // centre table re-laid out [order][n0][n1][4][K] (fast kernel)   // (x, y) of the bin-sorted cells, one 16-byte load per candidate
     int bins_x, bins_y;
+    // Exact ties of the nearest-cell search (a sample equidistant from two cells: it sits on a
+    // mirror line of the lattice, e.g. the x = 0 row of a symmetric grid with an odd sample
+    // count).  The reference takes whichever cell scipy's cKDTree meets first, which only scipy
+    // can tell: the kernel records such samples (tie_list, up to tie_cap) and, once the host has
+    // asked cKDTree about them, finds the answer in the sorted override list.
+    int *tie_count, *tie_count_next;   // this launch's counter; the next one's (cleared here)
+    long long *tie_list;
+    int tie_cap;
+    const long long *ovr_key;   // sorted sample ids (row * ny + column)
+    const int *ovr_slot;        // the cell (bin-sorted slot) to take there
+    int n_ovr;
     double bx0, by0, bh, inv_bh;   // inv_bh = 1 / bh, rounded (fast kernel's bin lookup)
     // lattice shortcut (ctx.hip fit_lattice), fast kernel: lat_map == nullptr if the cells are not
     // the nodes of one lattice
@@ -97,14 +108,47 @@ __device__ __forceinline__ void check_bounds(const NfArgs &a, const TableDesc &T
     }
 }
 
+// one candidate of the nearest-cell search: ties go to the lowest original index (provisional,
+// see settle_tie) and are remembered
+__device__ __forceinline__ void consider_cell(const NfArgs &a, double d2, int s, double &best,
+                                              int &best_slot, bool &tied) {
+    if (d2 < best) {
+        best = d2;
+        best_slot = s;
+        tied = false;
+    } else if (d2 == best) {
+        tied = true;
+        if (a.cindex[s] < a.cindex[best_slot]) best_slot = s;
+    }
+}
+
+// the winner shared its distance with another cell: take the host's answer if there is one,
+// else keep the provisional winner and report the sample
+__device__ __forceinline__ int settle_tie(const NfArgs &a, long long sample_id, int best_slot) {
+    int lo = 0, hi = a.n_ovr;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a.ovr_key[mid] < sample_id)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < a.n_ovr && a.ovr_key[lo] == sample_id) return a.ovr_slot[lo];
+    const int at = atomicAdd(a.tie_count, 1);
+    if (at < a.tie_cap) a.tie_list[at] = sample_id;
+    return best_slot;
+}
+
 // exact nearest centre cell (nearfield.py:363-364) through a uniform grid of bins
-__device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y) {
+__device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y,
+                                            long long sample_id) {
     int bx = (int)floor((x - a.bx0) / a.bh);
     int by = (int)floor((y - a.by0) / a.bh);
     bx = min(max(bx, 0), a.bins_x - 1);
     by = min(max(by, 0), a.bins_y - 1);
     double best = INFINITY;
-    int best_slot = -1, best_idx = 0x7fffffff;
+    int best_slot = -1;
+    bool tied = false;
     const int kmax = max(a.bins_x, a.bins_y);
     for (int k = 0; k <= kmax; ++k) {
         const int x_lo = bx - k, x_hi = bx + k, y_lo = by - k, y_hi = by + k;
@@ -116,13 +160,7 @@ __device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y)
                 const int b = gx * a.bins_y + gy;
                 for (int s = a.bin_start[b]; s < a.bin_start[b + 1]; ++s) {
                     const double ex = x - a.cx[s], ey = y - a.cy[s];
-                    const double d2 = ex * ex + ey * ey;
-                    const int idx = a.cindex[s];
-                    if (d2 < best || (d2 == best && idx < best_idx)) {
-                        best = d2;
-                        best_slot = s;
-                        best_idx = idx;
-                    }
+                    consider_cell(a, ex * ex + ey * ey, s, best, best_slot, tied);
                 }
             }
         }
@@ -130,7 +168,7 @@ __device__ __forceinline__ int nearest_cell(const NfArgs &a, double x, double y)
         const double reach = k * a.bh;
         if (best_slot >= 0 && best <= reach * reach) break;
     }
-    return best_slot;
+    return tied ? settle_tie(a, sample_id, best_slot) : best_slot;
 }
 
 
@@ -170,7 +208,8 @@ __device__ __forceinline__ int lattice_pick(const NfArgs &a, double x, double y,
 // is kept: the result is accepted only if it is provably nearest (distance <= one bin width,
 // same rule as nearest_cell), otherwise the ring-growing search runs; ties resolve to the
 // lowest original index.
-__device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, double y) {
+__device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, double y,
+                                                 long long sample_id) {
     // Lattice shortcut: the sample lies in (or within rounding of) the lattice parallelogram
     // (a0, b0); its four corner nodes are the candidates.  Every cell that is NOT one of them
     // sits on another node, i.e. at least lat_accept_r away from anywhere in that parallelogram
@@ -200,19 +239,15 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
         for (int k = 0; k < 4; ++k) p[k] = a.cxy[max(cand[k], 0)];
         double best = INFINITY;
         int best_slot = -1;
+        bool tied = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (cand[k] < 0) continue;
             const double ex = x - p[k].x, ey = y - p[k].y;
-            const double d2 = ex * ex + ey * ey;
-            if (d2 < best) {
-                best = d2;
-                best_slot = cand[k];
-            } else if (d2 == best && a.cindex[cand[k]] < a.cindex[best_slot]) {
-                best_slot = cand[k];
-            }
+            consider_cell(a, ex * ex + ey * ey, cand[k], best, best_slot, tied);
         }
-        if (best_slot >= 0 && best <= a.lat_accept_r2) return best_slot;
+        if (best_slot >= 0 && best <= a.lat_accept_r2)
+            return tied ? settle_tie(a, sample_id, best_slot) : best_slot;
     }
     // bin of the sample by multiplication with 1/bh (two fp64 divisions saved).  A sample within
     // an ulp of a bin edge may land in the neighbouring bin; the acceptance test below allows
@@ -233,6 +268,7 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
     }
     double best = INFINITY;
     int best_slot = -1;
+    bool tied = false;
     // candidates are fetched four per run at a time, all twelve loads in flight together
     // (a one-candidate-per-iteration loop would serialise ~10 L1 latencies per sample)
     constexpr int BATCH = 4;
@@ -251,13 +287,7 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
                 const int s = lo[c] + k;
                 if (s < hi[c]) {
                     const double ex = x - p[c][k].x, ey = y - p[c][k].y;
-                    const double d2 = ex * ex + ey * ey;
-                    if (d2 < best) {
-                        best = d2;
-                        best_slot = s;
-                    } else if (d2 == best && a.cindex[s] < a.cindex[best_slot]) {
-                        best_slot = s;
-                    }
+                    consider_cell(a, ex * ex + ey * ey, s, best, best_slot, tied);
                 }
             }
             more |= (hi[c] - lo[c] > BATCH);
@@ -268,18 +298,12 @@ __device__ __forceinline__ int nearest_cell_fast(const NfArgs &a, double x, doub
             for (int s = lo[c] + BATCH; s < hi[c]; ++s) {
                 const double2 q = a.cxy[s];
                 const double ex = x - q.x, ey = y - q.y;
-                const double d2 = ex * ex + ey * ey;
-                if (d2 < best) {
-                    best = d2;
-                    best_slot = s;
-                } else if (d2 == best && a.cindex[s] < a.cindex[best_slot]) {
-                    best_slot = s;
-                }
+                consider_cell(a, ex * ex + ey * ey, s, best, best_slot, tied);
             }
     }
     const double reach = a.bh * (1.0 - 1e-9);
-    if (best_slot < 0 || !(best <= reach * reach)) return nearest_cell(a, x, y);
-    return best_slot;
+    if (best_slot < 0 || !(best <= reach * reach)) return nearest_cell(a, x, y, sample_id);
+    return tied ? settle_tie(a, sample_id, best_slot) : best_slot;
 }
 
 // Sector of a sample: round(arctan2(y, x) / dphi) (nearfield.py:119,169), clamped to the
@@ -347,16 +371,20 @@ __device__ __forceinline__ void block_power(const NfArgs &a, double power_here) 
     if (threadIdx.x == 0)
         a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
             (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 256) a.viol_next[k] = 0ull;
+        if (threadIdx.x == 0) *a.tie_count_next = 0;
+    }
 }
 
 // the same for one-wave workgroups: one partial per wave, no barrier
 __device__ __forceinline__ void wave_power(const NfArgs &a, double power_here) {
     for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
     if (threadIdx.x == 0) a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = power_here;
-    if (blockIdx.x == 0 && blockIdx.y == 0)
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
+        if (threadIdx.x == 0) *a.tie_count_next = 0;
+    }
 }
 
 __device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 Ex, c2 Ey, c2 Hx,

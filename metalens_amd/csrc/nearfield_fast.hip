@@ -412,7 +412,7 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
                     }
                 }
                 if (!have_cell) {
-                    const int s = nearest_cell_fast(a, x, y);
+                    const int s = nearest_cell_fast(a, x, y, (long long)i * a.ny + j);
                     const double2 cc = a.cxy[s];
                     ccx = cc.x;
                     ccy = cc.y;

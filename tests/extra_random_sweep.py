@@ -30,7 +30,7 @@ def lens_of(radius, na, wl):
 
 
 def run(n_cases, seed):
-    """returns (worst relative field error, decision flips, exact-tie samples skipped)"""
+    """returns (worst relative field error, decision flips, exact-tie samples met)"""
     rng = np.random.default_rng(seed)
     wl = 580e-9
     lenses = [lens_of(1e-3, 0.94, wl), lens_of(0.5e-3, 0.5, wl)]
@@ -66,14 +66,12 @@ def run(n_cases, seed):
                 continue                          # both refuse (sample outside the tables): fine
             raise AssertionError('case %d: the oracle refused, the GPU did not' % case)
         got = ma.build_nearfield(*args, x_pts=x, y_pts=y)
-        # a sample exactly equidistant from two cells (it sits on a mirror line of the hex
-        # lattice) has no defined "nearest": the reference takes cKDTree's traversal order, the
-        # GPU the lowest cell index.  Such samples are compared for support only.
-        keep = ~dec['nearest_tie']
-        ties_total += int(np.count_nonzero(~keep))
+        # samples exactly equidistant from two cells (on a mirror line of the hex lattice): the
+        # reference takes cKDTree's pick, and so does the HIP path (metalens_amd/ties.py asks
+        # cKDTree about exactly those samples) - they are compared like every other sample
+        ties_total += int(np.count_nonzero(dec['nearest_tie']))
         for g, w in zip(got[:4], want[:4]):
-            assert np.array_equal(g == 0, w == 0)
-            err, flips = field_errors(g * keep, w * keep)
+            err, flips = field_errors(g, w)
             worst = max(worst, err)
             flips_total += flips
             assert flips == 0 and err < 1e-12, (case, err, flips, cx, cy, pol)
@@ -86,7 +84,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
     t0 = time.time()
     worst, flips_total, ties_total = run(n_cases, seed)
-    print('%d cases, worst relative field error %.2e, decision flips %d, exact-tie samples skipped %d, '
+    print('%d cases, worst relative field error %.2e, decision flips %d, exact-tie samples met %d, '
           '%.1f s' % (n_cases, worst, flips_total, ties_total, time.time() - t0))
 
 

@@ -929,3 +929,48 @@ def test_large_aperture_plans_take_the_folded_path(ma, N, M):
     bent[3] += 1e-9 * du * M          # far above rounding, far below anything a user would notice
     assert planned_kernel(bent) == 0
     ctx.sync()
+
+
+def test_nearest_cell_ties_follow_ckdtree(ma):
+    """A symmetric grid with an ODD number of samples has its middle row and column on mirror
+    lines of the hexagonal cell lattice: those samples are exactly equidistant from two cells and
+    the reference's choice is cKDTree's traversal order.  The kernels report them and the host
+    asks cKDTree (metalens_amd/ties.py); every sample, ties included, must then equal the
+    oracle.  Also through the resident pipeline, whose first results() settles them."""
+    from metalens_amd import _lib, ties
+    from metalens_amd.pipeline import HotPath
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    r_c = float(lens['lens_periphery_summary']['r_min_list'][0])
+    R = float(lens['lens_periphery_summary']['r_max_list'][-1])
+    src = (0.4e-6, -0.3e-6, -lens['source_distance'], 'y')
+    common = (wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'])
+    assert r_c > 4e-6 and R > 30e-6
+    for n in (61, 251):                            # centre disc only; centre + periphery
+        x = (np.arange(n) - n // 2) * (wl / 2.2)   # symmetric, x[n // 2] == 0.0 exactly
+        assert x[n // 2] == 0.0
+        dec = {}
+        want = nearfield_oracle.build_nearfield(*src, *common, x_pts=x, y_pts=x, decisions=dec)
+        n_ties = int(np.count_nonzero(dec['nearest_tie']))
+        assert n_ties > 0                          # the case really exercises ties
+        got = ma.build_nearfield(*src, *common, x_pts=x, y_pts=x)
+        for g, w, key in zip(got[:4], want[:4], ('Ex', 'Ey', 'Hx', 'Hy')):
+            err, flips = field_errors(g, w)
+            assert flips == 0 and err < TOL, (n, key, err, flips, n_ties)
+        assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
+        # nothing is left pending after the drop-in call
+        assert ties.pending(_lib.default_context()).size == 0
+    # the resident pipeline: the first results() settles the ties and repeats the pass
+    u = np.linspace(-0.1, 0.1, 64)
+    hp = HotPath(src, *common, x, x, u, u, ctx=_lib.Context(0))
+    hp.step()
+    hp.sync()
+    assert ties.pending(hp.ctx).size > 0
+    hp.results()
+    assert ties.pending(hp.ctx).size == 0
+    F = [np.empty((x.size, x.size), dtype=np.complex128) for _ in range(4)]
+    _lib.check(hp.ctx.lib.ml_fields_download(hp.ctx.handle, *[_lib.dptr(a) for a in F]))
+    scale = max(np.abs(w).max() for w in want[:4])
+    assert max(np.abs(g - w).max() for g, w in zip(F, want[:4])) <= TOL * scale
+    hp.ctx.close()
