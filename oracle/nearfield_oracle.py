@@ -249,7 +249,7 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
         if decisions is not None and len(cells) > 1:
             # samples whose two closest cells are (to rounding) equally far: the reference
             # takes whichever cKDTree's traversal meets first, which is not a property of the
-            # geometry - callers comparing another implementation skip these samples
+            # geometry; reported so that tests can tell whether a case exercises such samples
             d2 = tree.query(np.column_stack((xc, yc)), k=2)[0]
             tie = np.zeros(X.shape, dtype=bool)
             tie[in_center] = (d2[:, 1] - d2[:, 0]) <= 1e-9 * d2[:, 1]
