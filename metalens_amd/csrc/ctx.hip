@@ -744,7 +744,10 @@ static double decode_key(unsigned long long k, int check) {
 
 int ml_nearfield_ties(ml_ctx *ctx, int64_t *sample_ids, int max_ids, int *n_ties) {
     ML_REQUIRE(ctx && n_ties, "NULL argument");
-    ML_REQUIRE(ctx->tie_count.p, "no near field has been synthesised");
+    if (!ctx->tie_count.p) {   // nothing synthesised yet: nothing pending
+        *n_ties = 0;
+        return ML_OK;
+    }
     ML_HIP(hipSetDevice(ctx->device));
     int count = 0;
     ML_HIP(hipMemcpyAsync(&count, ctx->tie_count.as<int>() + ctx->viol_half, sizeof count,

@@ -9,7 +9,8 @@ O=$R/gpurun_out/$1
 mkdir -p $O
 CMD="python $R/bench.py --steps 7 --warmup 2 --cpu-rows 0"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $CMD > $O/stats.log 2>&1
+# the kernel-trace pass runs EXACTLY the default command (what the driver runs at N = 1)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py > $O/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1
 bash $R/tools/pmc_mfma.sh $O/mfma -- $CMD > $O/mfma.log 2>&1
@@ -24,4 +25,5 @@ python bench.py --precision f32 --cpu-rows 0 2>/dev/null | tail -1 > $O/bench_f3
 python bench.py --precision f32 --aperture 4096 --farfield 512 --cpu-rows 0 2>/dev/null | tail -1 > $O/bench_f32_4096x512.json
 python bench.py --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --cpu-rows 0 2>/dev/null | tail -1 > $O/bench_8192x512_na094.json
 ML_NO_PLAN_CACHE=1 ML_EAGER_UNFOLD=1 python bench.py --profile none --cpu-rows 0 2>/dev/null | tail -1 > $O/bench_no_plan_cache.json
+python bench.py --warmup 0 --steps 2 --cpu-rows 0 2>/dev/null | tail -1 > $O/bench_warmup0.json
 ls -la $O
