@@ -82,6 +82,7 @@ struct FoldArgs {
     // TRANSPOSED per field, C[(field * my + j) * out_t_rows + n1] - the layout the folded
     // stage 2 reads - instead of C[row * ldc + j]
     int out_t_rows;
+    int debug_skip;
     const double2 *out_E;   // with out_t_rows: phasor per n1 multiplied into the output (the next
                             // stage's input modulation), or nullptr
 };
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
         load_seed(t_begin);
     }
 
+    const bool wave_has_columns = s0 + wn * TN * 16 < a.S && !a.debug_skip;   // wave-uniform
     load_tile(t_begin);
     for (int t0 = t_begin; t0 < t_end; t0 += BKT) {
         __syncthreads();
@@ -268,6 +270,10 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             }
             if ((t0 + BKT) % RESEED == 0 && t0 + BKT < t_end) load_seed(t0 + BKT);
         }
+        // a wave whose direction columns all lie beyond S (the ragged last column tile) only
+        // helps with the tile loads and barriers: its matrix-core slots go to the waves with
+        // real columns
+        if (!wave_has_columns) continue;
 #pragma unroll UNR
         for (int s = 0; s < BKT / 4; ++s) {
             CT ger[TM], gei[TM], gor[TM], goi[TM], cc[TN], ss[TN];
@@ -397,6 +403,7 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.in_slab_stride = io.in_slab_stride;
     a.out_t_rows = io.out_t_rows;
     a.out_E = reinterpret_cast<const double2 *>(io.out_E);
+    a.debug_skip = getenv("ML_ZFOLD_SKIP_MFMA") ? atoi(getenv("ML_ZFOLD_SKIP_MFMA")) : 0;
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
     a.M = M;
