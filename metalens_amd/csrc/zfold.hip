@@ -403,7 +403,8 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.in_slab_stride = io.in_slab_stride;
     a.out_t_rows = io.out_t_rows;
     a.out_E = reinterpret_cast<const double2 *>(io.out_E);
-    a.debug_skip = getenv("ML_ZFOLD_SKIP_MFMA") ? atoi(getenv("ML_ZFOLD_SKIP_MFMA")) : 0;
+    static const int skip_mfma = getenv("ML_ZFOLD_SKIP_MFMA") ? atoi(getenv("ML_ZFOLD_SKIP_MFMA")) : 0;
+    a.debug_skip = skip_mfma;   // diagnostic only: time the kernel's memory skeleton
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
     a.M = M;
