@@ -458,17 +458,13 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     const bool special_io = a.out_t_rows > 0 || a.in_slabs > 1;
     if (special_io && pick != 31 && pick != 40 && pick != 51) pick = 50;   // only these have the I/O flavours
     switch (pick) {
+        // 8, 9: the cos/sin operand read from tables through LDS (kept as the comparison for the
+        // on-the-fly operand); 31 / 50: the production shapes; 40 (default case), 51: shapes they replaced
         case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a, ksplit);
         case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a, ksplit);
-        case 21: return launch_fold<32, 128, 2, 2, 1, true>(stream, a, ksplit);
-        case 22: return launch_fold<32, 64, 2, 2, 1, true>(stream, a, ksplit);
-        case 26: return launch_fold<32, 64, 2, 2, 2, true>(stream, a, ksplit);
         case 31: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, double>(stream, a, ksplit);
         case 50: return launch_fold_io<32, 128, 1, 8, 1, true, 32, 4, double>(stream, a, ksplit);
         case 51: return launch_fold_io<32, 64, 1, 4, 2, true, 32, 2, double>(stream, a, ksplit);
-        case 32: return launch_fold<32, 128, 2, 2, 1, true, 32>(stream, a, ksplit);
-        case 42: return launch_fold<32, 128, 2, 4, 1, true, 16, 4>(stream, a, ksplit);
-        case 44: return launch_fold<32, 64, 2, 2, 1, true, 16, 4>(stream, a, ksplit);
         default: return launch_fold_io<32, 128, 2, 4, 1, true, 32, 4, double>(stream, a, ksplit);
     }
 }
