@@ -522,33 +522,38 @@ def test_two_stream_pipeline_equals_single_stream(ma):
     assert abs(got['power_local_rows'] - want['power_local_rows']) <= 1e-12 * abs(want['power_local_rows'])
 
 
-def _run_bench(extra, env, timeout=600):
+def _run_bench(extra, env, timeout=600, aperture=512):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', '512', '--farfield', '64',
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', str(aperture),
+           '--farfield', '64',
            '--diameter', '3e-4', '--steps', '2', '--warmup', '1', '--cpu-rows', '0',
            '--scaling', 'strong'] + extra
     return subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE,
                             stderr=subprocess.PIPE, text=True)
 
 
-@pytest.mark.parametrize('reduce', ['amplitudes', 'vectors'])
-def test_two_ranks_sharing_one_gpu(tmp_path, reduce):
+@pytest.mark.parametrize('reduce,aperture', [('amplitudes', 512), ('vectors', 512),
+                                             ('amplitudes', 511)])
+def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture):
     """bench.py --gpus 2 end to end on ONE GPU: two processes (ranks 0 and 1, both on device 0)
     with the test communicator (ML_COMM_BACKEND=file; RCCL refuses two ranks per GPU): unique-id
     rendezvous, weighted mirrored row shards, per-rank synthesis and transform, the reduction,
-    max-over-ranks timing - and the far field must equal the one-process result."""
+    max-over-ranks timing - and the far field must equal the one-process result.  The odd
+    aperture takes contiguous row blocks, and only the rank that owns the x = 0 row meets
+    nearest-cell ties: results() has to settle them collectively."""
     import json
     one = str(tmp_path / 'one.npz')
-    p = _run_bench(['--dump', one], {})
+    p = _run_bench(['--dump', one], {}, aperture=aperture)
     out, err = p.communicate(timeout=600)
     assert p.returncode == 0, err[-2000:]
     two = str(tmp_path / 'two.npz')
     env = dict(ML_COMM_BACKEND='file', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT='29533' if reduce == 'vectors' else '29534')
+               MASTER_PORT=str(29533 + (reduce == 'vectors') + 2 * (aperture % 2)))
     procs = [_run_bench(['--gpus', '2', '--dump', two, '--reduce', reduce],
-                        dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+                        dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=aperture)
+             for r in range(2)]
     outs = [q.communicate(timeout=600) for q in procs]
     for q, (o, e) in zip(procs, outs):
         assert q.returncode == 0, e[-2000:]
