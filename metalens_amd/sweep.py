@@ -5,7 +5,8 @@ emitter is the INCOHERENT sum of x-, y- and z-polarised dipoles, possibly at sev
 or wavelengths - i.e. many runs of near field -> far field whose POWERS are added.  A sweep
 re-uses the resident tables and layout and keeps two passes in flight on two GPU streams: the
 near-field kernel (L1/latency-bound, matrix cores idle) of one source overlaps the folded GEMMs
-(matrix-core-bound) of the previous one (measured +15 % throughput at 2048^2 -> 256^2).
+(matrix-core-bound) of the previous one (measured +7 % throughput at 2048^2 -> 256^2, +11 % at
+4096^2 -> 512^2 with the end-of-round-1 kernels).
 """
 import numpy as np
 
