@@ -52,8 +52,10 @@ def build_workload(aperture, farfield, diameter, na, wavelength, zoom):
     x = (np.arange(aperture) - (aperture - 1) / 2) * pitch
     # far-field grid: M x M directions centred on the collimated beam, `zoom` FFT-lattice
     # spacings apart (zoom = 1 -> the central M x M bins of the FFT lattice)
+    # (the lattice of nearfield_farfield.py:35-39, built like the reference builds it: from the
+    # sample spacing the aperture axis actually has, x[1] - x[0])
     n_glass = 1.459
-    du = zoom * (wavelength / n_glass) / (pitch * aperture)
+    du = zoom * (wavelength / n_glass) / ((x[1] - x[0]) * aperture)
     u = (np.arange(farfield) - farfield // 2) * du
     return lens, x, u
 
@@ -129,6 +131,9 @@ def main():
     ap.add_argument('--precision', choices=('f64', 'f32'), default='f64',
                     help="arithmetic of the far-field GEMMs: f64 (BASELINE metric, 1e-12) or f32 "
                          "(fp32 matrix cores, 1e-4; near field, storage and projection stay fp64)")
+    ap.add_argument('--method', choices=('auto', 'gemm'), default='auto',
+                    help='auto: output-pruned FFT on axes whose direction grid sits on the FFT '
+                         'lattice (zoom 1), GEMMs elsewhere; gemm: the folded matrix-core GEMMs')
     args = ap.parse_args()
 
     from metalens_amd import _lib, dist
@@ -153,7 +158,7 @@ def main():
     hp = HotPath(source, args.wavelength, lens['lens_periphery_summary'],
                  lens['lens_center_summary'], lens['hexgridset'], x, x, u, u, ctx=ctx,
                  rank=rank, world=world, precision=args.precision, reduce=args.reduce,
-                 fuse_modulation=bool(args.fuse_modulation))
+                 fuse_modulation=bool(args.fuse_modulation), method=args.method)
 
     for _ in range(args.warmup):
         hp.step()

@@ -201,6 +201,18 @@ int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double
 /* which stage-1 kernel the current plan uses: *stage1_kernel = 0 generic complex GEMM (3M),
  * 1 folded even/odd real-kernel GEMM (centre-symmetric uy grid).                          */
 int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel);
+/* The same for both stages: 0 generic complex GEMM, 1 folded GEMM, 2 output-pruned FFT in LDS
+ * (the axis' direction grid is a run of consecutive bins of the aperture's FFT lattice,
+ * kappa * step * du = 1 / N_eff with N_eff a multiple of 256 up to 8192 - the reference's own
+ * far-field grid, nearfield_farfield.py:35-39, and any window of it).                       */
+int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel);
+/* How ml_farfield_plan chooses: ML_METHOD_AUTO (default) takes the FFT on every axis whose grid
+ * sits on the lattice and the GEMMs elsewhere; ML_METHOD_GEMM always takes the GEMMs (arbitrary
+ * grids need them anyway; this makes them testable on lattice grids too).  Takes effect at the
+ * next ml_farfield_plan.                                                                     */
+#define ML_METHOD_AUTO 0
+#define ML_METHOD_GEMM 1
+int ml_farfield_set_method(ml_ctx *ctx, int method);
 /* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",
  * configs[4] "fp32 GEMM-cast MFMA path").  ML_PRECISION_F64 (default): fp64 matrix cores.
  * ML_PRECISION_F32_GEMM: the folded GEMMs of both stages round their operands to fp32 and

@@ -40,6 +40,7 @@ SYMBOLS = (
     'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_transform_mirrored',
     'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
     'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
+    'ml_farfield_plan_kernels', 'ml_farfield_set_method',
 )
 
 
@@ -114,6 +115,8 @@ def load():
     lib.ml_farfield_download.argtypes = [c_void_p, _dp, _dp, _dp, _dp]
     lib.ml_farfield_plan_info.argtypes = [c_void_p, POINTER(c_int)]
     lib.ml_farfield_set_precision.argtypes = [c_void_p, c_int]
+    lib.ml_farfield_plan_kernels.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
+    lib.ml_farfield_set_method.argtypes = [c_void_p, c_int]
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
     lib.ml_farfield_add_vectors.argtypes = [c_void_p, c_void_p]
     lib.ml_profile_select.argtypes = [c_void_p, ctypes.c_uint]
@@ -209,6 +212,19 @@ class Context:
         """'f64' (default) or 'f32': arithmetic of the folded aperture -> direction GEMMs
         (include/metalens_hip.h, ml_farfield_set_precision); everything else stays fp64"""
         check(self.lib.ml_farfield_set_precision(self.handle, {'f64': 0, 'f32': 1}[precision]))
+
+    def set_method(self, method):
+        """'auto' (default): axes whose direction grid sits on the aperture's FFT lattice run as
+        output-pruned FFTs, the others as GEMMs; 'gemm': GEMMs everywhere.  Applies to the
+        next plan."""
+        check(self.lib.ml_farfield_set_method(self.handle, {'auto': 0, 'gemm': 1}[method]))
+
+    def plan_kernels(self):
+        """(stage 1, stage 2) of the active plan: 'gemm', 'folded' or 'fft'"""
+        s1, s2 = c_int(0), c_int(0)
+        check(self.lib.ml_farfield_plan_kernels(self.handle, byref(s1), byref(s2)))
+        names = ('gemm', 'folded', 'fft')
+        return names[s1.value], names[s2.value]
 
     def profile(self, on=True, kernels=None, every=1):
         """time kernel launches with HIP events; ``kernels`` = names to time (default all),

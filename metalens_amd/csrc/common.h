@@ -142,8 +142,19 @@ struct CellRec {
     double pad;
 };
 
+// One axis of a plan whose direction grid sits on the aperture's FFT lattice (zfft.hip): the
+// transform along that axis runs as an output-pruned FFT instead of a GEMM.
+struct ZfftAxis {
+    bool ok = false;
+    int N_eff = 0, j0 = 0, pad1 = 0, pad2 = 0;
+    DevBuf wk, pj, kbin;   // per-bin Horner ratio, origin phasor, reduced bin (zfft.hip FftArgs)
+};
+
 struct FarfieldPlan {
     bool ready = false;
+    int method = 0;    // ml_farfield_set_method value the plan was made under
+    ZfftAxis fft_y, fft_x;
+    DevBuf fft_tw1;
     long serial = 0;   // incremented by every ml_farfield_plan call
     bool amplitudes_reduced = false;   // ml_farfield_project_reduce ran on the current vectors
     int nx_total = 0, ny = 0, mx = 0, my = 0, pair_list = 0;
@@ -234,6 +245,7 @@ struct ml_ctx {
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
+    int ff_method = 0;  // ml_farfield_set_method: 0 auto (FFT on lattice grids), 1 GEMMs only
     hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
     // ml_nearfield_premodulate: the synthesis applies the active plan's stage-1 input modulation;
     // fields_premod_serial = serial of the plan whose modulation the resident fields carry (-1: none)
@@ -308,6 +320,28 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
                  FoldIO io = FoldIO());
 // number of split-K slabs zfold_stage1 will actually write for (T, ksplit)
 int zfold_splits(int T, int ksplit);
+// zfft.hip: output-pruned FFT along one axis for lattice-commensurate direction grids
+struct ZfftCall {
+    int N_eff, n_valid, M, j0, pad1, pad2;
+    const double *in;           // complex
+    int64_t in_s1, in_s2, in_es;
+    int in_rb, a0, h0, a1, h1;
+    const int *row_first;
+    int rf_mod;
+    double *out;                // complex
+    int64_t out_s1, out_s2, out_es;
+    int out_rb;
+    const double *tw1, *wk, *pj;
+    const int *kbin;
+    double alpha[4];
+    int alpha_rb, rows, accumulate;
+};
+bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
+                       long double tol, int *N_eff, int *j0);
+int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M,
+                      int j0, int N_eff, int c);
+void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2);
+int zfft_run(hipStream_t stream, const ZfftCall &c);
 // comm.hip
 void comm_release(ml_ctx *ctx);
 // farfield.hip: undo ml_nearfield_premodulate on the resident fields (no-op if plain)

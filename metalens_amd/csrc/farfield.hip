@@ -487,6 +487,30 @@ static int plan_fold(ml_ctx *ctx, const double *uy) {
     return ML_OK;
 }
 
+// Does the direction grid along one axis sit on the FFT lattice of that aperture axis (zfft.hip)?
+// If so build its per-bin tables.  n samples `step` apart, sample j at (j - ceil(n/2)) step.
+static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const double *u, int m) {
+    FarfieldPlan &pl = ctx->plan;
+    ax.ok = false;
+    const long double kappa = (long double)pl.n_glass / (long double)pl.wavelength;
+    const long double p_max = 0.5L * (n + 1) * fabsl((long double)step);
+    int N_eff = 0, j0 = 0;
+    if (!zfft_commensurate(n, step, kappa, u, m, symmetry_tolerance(kappa, p_max, u, m), &N_eff, &j0))
+        return ML_OK;
+    ML_TRY(pl.fft_tw1.reserve(256 * 2 * sizeof(double)));
+    ML_TRY(ax.wk.reserve((size_t)m * 2 * sizeof(double)));
+    ML_TRY(ax.pj.reserve((size_t)m * 2 * sizeof(double)));
+    ML_TRY(ax.kbin.reserve((size_t)m * sizeof(int)));
+    ProfScope scope(ctx, ML_K_TWIDDLE);
+    ML_TRY(zfft_build_tables(ctx->stream, pl.fft_tw1.as<double>(), ax.wk.as<double>(),
+                             ax.pj.as<double>(), ax.kbin.as<int>(), m, j0, N_eff, n - n / 2));
+    zfft_choose_pads(N_eff, m, j0, &ax.pad1, &ax.pad2);
+    ax.N_eff = N_eff;
+    ax.j0 = j0;
+    ax.ok = true;
+    return ML_OK;
+}
+
 // Stage 2 can be folded the same way when ux is centre-symmetric; its tables depend on
 // which aperture rows are resident and are built in the transform call.
 static int plan_fold2(ml_ctx *ctx, const double *ux) {
@@ -692,7 +716,10 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     pl.unfold_pending = false;   // vectors of the previous plan that nobody asked for
     // Same geometry as the active plan (a sweep over sources re-plans every pass): its phase
     // tables depend on nothing else, keep them.  ML_NO_PLAN_CACHE=1 rebuilds them every call.
-    if (pl.ready && !plan_cache_disabled() && pl.nx_total == nx_total && pl.ny == ny &&
+    // the fp32 GEMM mode is a request for the matrix-core path: it keeps the GEMMs
+    const int method = ctx->gemm_f32 ? ML_METHOD_GEMM : ctx->ff_method;
+    if (pl.ready && !plan_cache_disabled() && pl.method == method &&
+        pl.nx_total == nx_total && pl.ny == ny &&
         pl.mx == mx && pl.my == my && pl.pair_list == pair_list && pl.dxp == dxp &&
         pl.dyp == dyp && pl.wavelength == wavelength && pl.n_glass == n_glass &&
         pl.h_ux.size() == (size_t)mx && pl.h_uy.size() == (size_t)my &&
@@ -715,6 +742,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     pl.dyp = dyp;
     pl.wavelength = wavelength;
     pl.n_glass = n_glass;
+    pl.method = method;
     ML_TRY(upload_if_changed(ctx, pl.ux, pl.h_ux, ux, mx));
     ML_TRY(upload_if_changed(ctx, pl.uy, pl.h_uy, uy, my));
     ML_TRY(pl.tw_x.reserve((size_t)mx * nx_total * 2 * sizeof(double)));
@@ -722,10 +750,17 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     ML_TRY(pl.vectors.reserve(4 * out_elems * 2 * sizeof(double)));
     ML_TRY(pl.power.reserve(out_elems * sizeof(double)));
     ML_TRY(pl.amplitudes.reserve(2 * out_elems * 2 * sizeof(double)));
-    // stage 1 operand: the folded cos/sin tables when uy is centre-symmetric, else the complex
-    // twiddles tw_y[k][j] (sample-major, B operand of the generic GEMM)
-    ML_TRY(plan_fold(ctx, uy));
-    if (!pl.fold) {
+    // direction grids on the aperture's FFT lattice: that axis runs as an output-pruned FFT
+    pl.fft_y.ok = pl.fft_x.ok = false;
+    if (method == ML_METHOD_AUTO && !pair_list) {
+        ML_TRY(plan_fft_axis(ctx, pl.fft_y, ny, dyp, uy, my));
+        ML_TRY(plan_fft_axis(ctx, pl.fft_x, nx_total, dxp, ux, mx));
+    }
+    // stage 1 operand otherwise: the folded cos/sin tables when uy is centre-symmetric, else the
+    // complex twiddles tw_y[k][j] (sample-major, B operand of the generic GEMM)
+    pl.fold = false;
+    if (!pl.fft_y.ok) ML_TRY(plan_fold(ctx, uy));
+    if (!pl.fold && !pl.fft_y.ok) {
         ML_TRY(pl.tw_y.reserve((size_t)ny * my * 2 * sizeof(double)));
         ML_TRY(launch_twiddle(ctx, pl.tw_y.as<double>(), ny, my, 1, ny, dyp, wavelength, n_glass,
                               pl.uy.as<double>()));
@@ -801,7 +836,8 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     }();
     const bool whole = (row0 == 0 && nxl == pl.nx_total);
     const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
-    const bool use_fold2 = !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole);
+    const bool fft1 = pl.fft_y.ok, fft2 = pl.fft_x.ok && !pl.pair_list;
+    const bool use_fold2 = !fft2 && !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole);
     // both stages folded: stage 1 writes its result already transposed for stage 2
     static const bool no_direct = [] {
         const char *e = getenv("ML_NO_GT_DIRECT");
@@ -831,7 +867,39 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
-        if (pl.fold)
+        if (fft1) {
+            ZfftCall c;
+            c.N_eff = pl.fft_y.N_eff;
+            c.n_valid = ny;
+            c.M = my;
+            c.j0 = pl.fft_y.j0;
+            c.pad1 = pl.fft_y.pad1;
+            c.pad2 = pl.fft_y.pad2;
+            c.in = ctx->fields.as<double>();
+            c.rows = 4 * nxl;
+            c.in_rb = c.rows;
+            c.in_s1 = 0;
+            c.in_s2 = ny;
+            c.in_es = 1;
+            c.a0 = 0;
+            c.h0 = ny;
+            c.a1 = c.h1 = 0;
+            c.row_first = ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr;
+            c.rf_mod = nxl;
+            c.out = pl.stage1.as<double>();
+            c.out_rb = c.rows;
+            c.out_s1 = 0;
+            c.out_s2 = my;
+            c.out_es = 1;
+            c.tw1 = pl.fft_tw1.as<double>();
+            c.wk = pl.fft_y.wk.as<double>();
+            c.pj = pl.fft_y.pj.as<double>();
+            c.kbin = pl.fft_y.kbin.as<int>();
+            for (int k = 0; k < 4; ++k) c.alpha[k] = 1.0;
+            c.alpha_rb = c.rows;
+            c.accumulate = 0;
+            ML_TRY(zfft_run(ctx->stream, c));
+        } else if (pl.fold)
             ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->fields.as<double>(), ny,
                                 pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
                                 pl.fold_r4.as<double>(), pl.fold_T,
@@ -857,7 +925,50 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
         }
         return ML_OK;
     };
-    if (use_fold2) {
+    if (fft2) {
+        // stage 2 along x as a pruned FFT over the columns of stage 1's result: row (f, b) reads
+        // G[f][n1][b] for the resident n1 (zero elsewhere) and writes V[3 - f][a][b] * alpha_f
+        ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        ML_TRY(collapse_stage1());
+        ZfftCall c;
+        c.N_eff = pl.fft_x.N_eff;
+        c.n_valid = pl.nx_total;
+        c.M = mx;
+        c.j0 = pl.fft_x.j0;
+        c.pad1 = pl.fft_x.pad1;
+        c.pad2 = pl.fft_x.pad2;
+        c.in = pl.stage1.as<double>();
+        c.rows = 4 * my;
+        c.in_rb = my;
+        c.in_s1 = (int64_t)nxl * my;
+        c.in_s2 = 1;
+        c.in_es = my;
+        if (mirrored) {
+            c.a0 = row0;
+            c.h0 = nxl / 2;
+            c.a1 = pl.nx_total - row0 - nxl / 2;
+            c.h1 = nxl / 2;
+        } else {
+            c.a0 = row0;
+            c.h0 = nxl;
+            c.a1 = c.h1 = 0;
+        }
+        c.row_first = nullptr;
+        c.rf_mod = 1;
+        c.out = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
+        c.out_rb = my;
+        c.out_s1 = -(int64_t)mx * my;
+        c.out_s2 = 1;
+        c.out_es = my;
+        c.tw1 = pl.fft_tw1.as<double>();
+        c.wk = pl.fft_x.wk.as<double>();
+        c.pj = pl.fft_x.pj.as<double>();
+        c.kbin = pl.fft_x.kbin.as<int>();
+        for (int k = 0; k < 4; ++k) c.alpha[k] = alpha[k];
+        c.alpha_rb = my;
+        c.accumulate = accumulate;
+        ML_TRY(zfft_run(ctx->stream, c));
+    } else if (use_fold2) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha, gt_direct, gt_direct,
                              want_split2));
@@ -1013,7 +1124,22 @@ int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel) {
         set_error("ml_farfield_plan has not been called");
         return ML_ESTATE;
     }
-    *stage1_kernel = ctx->plan.fold ? 1 : 0;
+    *stage1_kernel = ctx->plan.fft_y.ok ? 2 : ctx->plan.fold ? 1 : 0;
+    return ML_OK;
+}
+
+int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel) {
+    ML_REQUIRE(ctx && stage1_kernel && stage2_kernel, "NULL argument");
+    ML_TRY(ml_farfield_plan_info(ctx, stage1_kernel));
+    const FarfieldPlan &pl = ctx->plan;
+    *stage2_kernel = (pl.fft_x.ok && !pl.pair_list) ? 2 : pl.fold2 ? 1 : 0;
+    return ML_OK;
+}
+
+int ml_farfield_set_method(ml_ctx *ctx, int method) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(method == ML_METHOD_AUTO || method == ML_METHOD_GEMM, "unknown method %d", method);
+    ctx->ff_method = method;
     return ML_OK;
 }
 

@@ -1,0 +1,246 @@
+// Aperture -> direction transform along one axis as an output-pruned FFT in LDS (zfft_core.h),
+// for direction grids that sit on the FFT lattice of the aperture - the reference's own far-field
+// grid (nearfield_farfield.py:35-39) and any M consecutive bins of it.  HBM-bound: every aperture
+// sample is read once, 2 x 16-point butterflies + R3 Horner steps per wanted bin are all the
+// arithmetic, where the folded GEMM (zfold.hip) spends M / 2 real multiply-adds per sample on the
+// matrix cores (4096 -> 512: 0.59 ms at 100 % matrix-pipe rate against ~0.25 ms of HBM time).
+// Direction grids off the lattice (zoomed, shifted by a fraction of a bin, pair lists) keep the GEMMs.
+//
+// One workgroup = 16 R3 threads = one row of N_eff = 256 R3 samples at a time:
+//   16 coalesced 16-byte loads per thread -> stage 1 -> LDS -> stage 2 -> LDS -> stage 3 (Horner
+//   over the R3 residues, wanted bins only) -> output phasor, scale, store.
+// LDS: one buffer of N_eff complex (both exchanges alias it), 64 KB for 4096 samples, so two
+// workgroups share a CU and one's loads fly while the other computes.  Rows are handed out so
+// that the workgroups of one XCD walk neighbouring rows (the column pass of stage 2 re-uses
+// cache lines between neighbouring columns).
+#include <cmath>
+#include <cstdlib>
+
+#include "common.h"
+#include "zfft_core.h"
+
+namespace ml {
+
+using zf::cd;
+
+struct FftArgs {
+    zf::Geo g;
+    // input: row r starts at in + (r / in_rb) * in_s1 + (r % in_rb) * in_s2; resident sample q sits
+    // in_es elements further per step.  Global sample n is resident as q = n - a0 for n in
+    // [a0, a0 + h0), q = h0 + n - a1 for n in [a1, a1 + h1) (a mirrored shard has two runs), and
+    // is zero otherwise.
+    const cd *in;
+    int64_t in_s1, in_s2, in_es;
+    int in_rb;
+    int a0, h0, a1, h1;
+    // rows of a synthesised field are zero outside the lens circle: samples with
+    // min(n, n_valid - 1 - n) < row_first[r % rf_mod] are not read (nullptr: read everything)
+    const int *row_first;
+    int rf_mod;
+    // output: bin j of row r at out + (r / out_rb) * out_s1 + (r % out_rb) * out_s2 + j * out_es
+    cd *out;
+    int64_t out_s1, out_s2, out_es;
+    int out_rb;
+    const cd *tw1;     // [16][16]  W_256^(n1 k2)
+    const cd *wk;      // [M]       W_N^(k_j): the Horner ratio of bin j
+    const cd *pj;      // [M]       exp(+2 pi i c k_j / N): moves the origin to sample c
+    const int *kbin;   // [M]       k_j reduced to [0, N)
+    double alpha[4];   // row r is scaled by alpha[r / alpha_rb]
+    int alpha_rb;
+    int rows, chunk, accumulate;
+};
+
+template <int R3T>
+__device__ __forceinline__ zf::Geo geo_of(const FftArgs &a) {
+    zf::Geo g = a.g;
+    if (R3T > 0) g.R3 = R3T;
+    return g;
+}
+
+// R3T > 0: residues known at compile time (the div / mod by R3 become shifts), R3T == 0: any R3
+template <int R3T, int NTMAX, int MINW>
+__global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
+    extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
+    cd *lds = reinterpret_cast<cd *>(zfft_lds_raw);
+    const zf::Geo g = geo_of<R3T>(a);
+    const int NT = 16 * g.R3, tid = threadIdx.x;
+
+    // per-thread constants: the stage-1 twiddles of n1 = tid / R3
+    cd tw1[16];
+    {
+        const int n1 = tid / g.R3;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) tw1[k2] = a.tw1[n1 * 16 + k2];
+    }
+    const int xcd = blockIdx.x & 7;
+    for (int idx = blockIdx.x >> 3; idx < a.chunk; idx += gridDim.x >> 3) {
+        const int row = xcd * a.chunk + idx;   // block-uniform
+        if (row >= a.rows) break;
+        const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2;
+        const int first = a.row_first ? a.row_first[row % a.rf_mod] : 0;
+        cd v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int n = tid + NT * n2;
+            int q = -1;
+            if (n >= a.a0 && n < a.a0 + a.h0) q = n - a.a0;
+            if (n >= a.a1 && n < a.a1 + a.h1) q = a.h0 + n - a.a1;
+            if (min(n, g.n_valid - 1 - n) < first) q = -1;
+            v[n2] = q >= 0 ? src[q * a.in_es] : zf::mk(0.0, 0.0);
+        }
+        zf::stage1(g, tid, v, tw1, lds);
+        __syncthreads();
+        zf::gather2(g, tid, v, lds);
+        __syncthreads();
+        zf::scatter2(g, tid, v, lds);
+        __syncthreads();
+        cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
+        const double al = a.alpha[row / a.alpha_rb];
+        for (int o = tid; o < g.M; o += NT) {
+            const cd w = a.wk[o], p = a.pj[o];
+            cd x = zf::cmul(zf::stage3(g, a.kbin[o], w, lds), p);
+            x.x *= al;
+            x.y *= al;
+            cd *d = dst + o * a.out_es;
+            if (a.accumulate) x = zf::cadd(x, *d);
+            *d = x;
+        }
+        __syncthreads();   // the next row's stage 1 overwrites the buffer
+    }
+}
+
+// tables of one axis: tw1 (shared by all axes), wk / pj / kbin per plan axis
+__global__ __launch_bounds__(256) void zfft_tables_kernel(cd *tw1, cd *wk, cd *pj, int *kbin, int M,
+                                                          int j0, int N, int c) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < 256) {
+        const int n1 = e >> 4, k2 = e & 15;
+        double s, co;
+        sincospi(-2.0 * ((n1 * k2) & 255) / 256.0, &s, &co);
+        tw1[e] = zf::mk(co, s);
+    }
+    if (e < M) {
+        const long long kj = (long long)e + j0;          // true bin (may be negative)
+        long long k = kj % N;
+        if (k < 0) k += N;
+        kbin[e] = (int)k;
+        double s, co;
+        sincospi(-2.0 * (double)k / (double)N, &s, &co);
+        wk[e] = zf::mk(co, s);
+        long long m = ((long long)c * kj) % N;           // exp(+2 pi i c k_j / N)
+        if (m < 0) m += N;
+        sincospi(2.0 * (double)m / (double)N, &s, &co);
+        pj[e] = zf::mk(co, s);
+    }
+}
+
+// Is the uniform grid u[0..M) a run of consecutive bins of the FFT lattice of an axis of n samples
+// `step` apart?  kappa = n_glass / wavelength (turns per unit length per unit direction cosine).
+// `tol`: allowed phase deviation [rad] at the aperture edge.  On success fills N_eff and j0.
+bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
+                       long double tol, int *N_eff, int *j0) {
+    if (M < 2 || n < 2) return false;
+    const long double du = ((long double)u[M - 1] - (long double)u[0]) / (M - 1);
+    const long double turns = kappa * fabsl((long double)step) * du;   // per (sample, bin)
+    if (!(turns > 0)) return false;                    // descending or degenerate grids: GEMM
+    if (step < 0) return false;
+    const long double inv = 1.0L / turns;
+    if (!(inv < 1e7L)) return false;
+    const long N = lrintl(inv);
+    if (N < n || N < M || N % 256 != 0) return false;
+    const int R3 = (int)(N / 256);
+    if (R3 < 1 || R3 > 32) return false;               // LDS: 257 * R3 * 16 bytes per workgroup
+    const long double du_exact = 1.0L / (kappa * fabsl((long double)step) * N);
+    const long jj = lrintl((long double)u[0] / du_exact);
+    if (labs(jj) > (1L << 30)) return false;
+    // worst phase error over the grid at the outermost sample
+    const long double p_max = 0.5L * n * fabsl((long double)step) + fabsl((long double)step);
+    long double worst = 0;
+    for (int j = 0; j < M; ++j)
+        worst = fmaxl(worst, fabsl((long double)u[j] - (jj + j) * du_exact));
+    if (2 * M_PIl * kappa * p_max * worst > tol) return false;
+    *N_eff = (int)N;
+    *j0 = (int)jj;
+    return true;
+}
+
+int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M, int j0,
+                      int N_eff, int c) {
+    const int n = M > 256 ? M : 256;
+    hipLaunchKernelGGL(zfft_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<cd *>(tw1), reinterpret_cast<cd *>(wk),
+                       reinterpret_cast<cd *>(pj), kbin, M, j0, N_eff, c);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+template <int R3T, int NTMAX, int MINW>
+static int launch_one(hipStream_t stream, const FftArgs &a, int grid, size_t lds_bytes) {
+    auto kern = zfft_kernel<R3T, NTMAX, MINW>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        ML_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(16 * a.g.R3), lds_bytes, stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+int zfft_run(hipStream_t stream, const ZfftCall &c) {
+    FftArgs a;
+    a.g.R3 = c.N_eff / 256;
+    a.g.n_valid = c.n_valid;
+    a.g.M = c.M;
+    a.g.j0 = c.j0;
+    a.g.pad1 = c.pad1;
+    a.g.pad2 = c.pad2;
+    a.in = reinterpret_cast<const cd *>(c.in);
+    a.in_s1 = c.in_s1;
+    a.in_s2 = c.in_s2;
+    a.in_es = c.in_es;
+    a.in_rb = c.in_rb;
+    a.a0 = c.a0;
+    a.h0 = c.h0;
+    a.a1 = c.a1;
+    a.h1 = c.h1;
+    a.row_first = c.row_first;
+    a.rf_mod = c.rf_mod > 0 ? c.rf_mod : 1;
+    a.out = reinterpret_cast<cd *>(c.out);
+    a.out_s1 = c.out_s1;
+    a.out_s2 = c.out_s2;
+    a.out_es = c.out_es;
+    a.out_rb = c.out_rb;
+    a.tw1 = reinterpret_cast<const cd *>(c.tw1);
+    a.wk = reinterpret_cast<const cd *>(c.wk);
+    a.pj = reinterpret_cast<const cd *>(c.pj);
+    a.kbin = c.kbin;
+    for (int k = 0; k < 4; ++k) a.alpha[k] = c.alpha[k];
+    a.alpha_rb = c.alpha_rb;
+    a.rows = c.rows;
+    a.accumulate = c.accumulate;
+    a.chunk = (c.rows + 7) / 8;
+    const size_t lds_bytes = (size_t)zf::lds_elems(a.g) * sizeof(cd);
+    // workgroups resident per CU (LDS-limited), 256 CUs; a multiple of 8 so that a workgroup
+    // stays on the rows of one XCD
+    const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds_bytes));
+    int grid = std::min(256 * per_cu, a.chunk * 8);
+    grid = (grid + 7) / 8 * 8;
+    switch (a.g.R3) {
+        case 4: return launch_one<4, 64, 2>(stream, a, grid, lds_bytes);
+        case 8: return launch_one<8, 128, 2>(stream, a, grid, lds_bytes);
+        case 16: return launch_one<16, 256, 2>(stream, a, grid, lds_bytes);
+        case 32: return launch_one<32, 512, 2>(stream, a, grid, lds_bytes);
+        default: return launch_one<0, 512, 1>(stream, a, grid, lds_bytes);
+    }
+}
+
+void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2) {
+    zf::Geo g{N_eff / 256, N_eff, M, j0, 0, 0};
+    zf::choose_pads(g);
+    *pad1 = g.pad1;
+    *pad2 = g.pad2;
+}
+
+}  // namespace ml

@@ -19,7 +19,7 @@ class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
                  c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None,
-                 reduce='amplitudes', fuse_modulation=True):
+                 reduce='amplitudes', fuse_modulation=True, method=None):
         """``reduce`` (multi-GPU only): 'amplitudes' all-reduces the two projected complex
         amplitudes (half the payload; the radiation vectors in ``results()`` are then this
         rank's partial sums), 'vectors' all-reduces Nx, Ny, Lx, Ly and projects afterwards."""
@@ -31,6 +31,8 @@ class HotPath:
         self.ctx = ctx or _lib.default_context()
         if precision is not None:   # 'f64' | 'f32': arithmetic of the far-field GEMMs
             self.ctx.set_precision(precision)
+        if method is not None:      # 'auto' | 'gemm': see _lib.Context.set_method
+            self.ctx.set_method(method)
         self.rank, self.world = rank, world
         self.c0 = constants.c0 if c0 is None else c0
         self.Z0 = constants.Z0 if Z0 is None else Z0

@@ -1,0 +1,72 @@
+// Host emulation of zfft.hip's per-thread programme (metalens_amd/csrc/zfft_core.h): runs the
+// phases thread by thread against a direct DFT in long double and reports the LDS bank-conflict
+// cycles of the chosen paddings.  Build + run:  make -C tools zfft_emul && tools/zfft_emul
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../metalens_amd/csrc/zfft_core.h"
+
+using zf::cd;
+
+static double run(int R3, int n_valid, int M, int j0, bool verbose) {
+    zf::Geo g{R3, n_valid, M, j0, 0, 0};
+    zf::choose_pads(g);
+    const int NT = 16 * R3, N = 256 * R3;
+    std::vector<cd> in(N), lds(zf::lds_elems(g));
+    srand(R3 * 7919 + M);
+    for (int n = 0; n < N; ++n)
+        in[n] = n < n_valid ? zf::mk(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5)
+                            : zf::mk(0, 0);
+    std::vector<std::vector<cd>> v(NT, std::vector<cd>(16));
+    // stage 1
+    for (int t = 0; t < NT; ++t) {
+        cd tw1[16];
+        const int n1 = t / R3;
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const long double a = -2 * M_PIl * ((n1 * k2) % 256) / 256;
+            tw1[k2] = zf::mk((double)cosl(a), (double)sinl(a));
+        }
+        for (int n2 = 0; n2 < 16; ++n2) v[t][n2] = in[t + NT * n2];
+        zf::stage1(g, t, v[t].data(), tw1, lds.data());
+    }
+    for (int u = 0; u < NT; ++u) zf::gather2(g, u, v[u].data(), lds.data());
+    for (int u = 0; u < NT; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
+    double worst = 0, scale = 0;
+    std::vector<cd> out(M);
+    for (int j = 0; j < M; ++j) {
+        const int k = zf::bin_of(g, j);
+        const long double a = -2 * M_PIl * k / N;
+        out[j] = zf::stage3(g, k, zf::mk((double)cosl(a), (double)sinl(a)), lds.data());
+    }
+    for (int j = 0; j < M; ++j) {
+        long double re = 0, im = 0;
+        const int k = zf::bin_of(g, j);
+        for (int n = 0; n < n_valid; ++n) {
+            const long double a = -2 * M_PIl * (((long long)n * k) % N) / N;
+            re += in[n].x * cosl(a) - in[n].y * sinl(a);
+            im += in[n].x * sinl(a) + in[n].y * cosl(a);
+        }
+        worst = fmax(worst, fmax(fabs((double)(re - out[j].x)), fabs((double)(im - out[j].y))));
+        scale = fmax(scale, fmax(fabsl(re), fabsl(im)));
+    }
+    const zf::LdsCost c = zf::lds_cost(g);
+    if (verbose)
+        printf("R3=%2d N=%5d valid=%5d M=%4d j0=%5d pads=(%d,%d) lds=%6d B  err=%.2e  cycles ex1 w/r %ld/%ld "
+               "ex2 w/r %ld/%ld (ideal w %ld r %ld)\n",
+               R3, N, n_valid, M, j0, g.pad1, g.pad2, zf::lds_elems(g) * 16, worst / scale, c.ex1_write,
+               c.ex1_read, c.ex2_write, c.ex2_read, c.ideal_rw * 8 / 12, c.ideal_rw * 4 / 12);
+    return worst / scale;
+}
+
+int main() {
+    double worst = 0;
+    const int cases[][4] = {{16, 4096, 512, -256}, {8, 2048, 256, -128}, {32, 8192, 512, -256},
+                            {16, 4000, 512, -256}, {4, 1024, 64, -32},   {4, 1000, 100, -37},
+                            {16, 4096, 300, 1000}, {1, 256, 64, -32},    {2, 512, 512, -256},
+                            {16, 4096, 4096, -2048}, {5, 1280, 77, -3}, {12, 3072, 512, -256}};
+    for (auto &c : cases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true));
+    printf("worst relative error %.3e -> %s\n", worst, worst < 1e-13 ? "OK" : "FAIL");
+    return worst < 1e-13 ? 0 : 1;
+}
