@@ -9,14 +9,20 @@ grid -> (all-reduce over ranks) -> theta/phi projection + power.  Inputs (tables
 are resident in HBM before the timed region; nothing crosses PCIe inside it.
 
 Metric (BASELINE.json): aperture x far-field pair evaluations per second,
-N_aperture^2 * M^2 / t.  Default workload = BASELINE.json configs[1]: 1 mm diameter,
-NA 0.5, 580 nm, 2048 x 2048 aperture -> 256 x 256 far field, fp64, read per SURVEY.md D3
-as a 2048^2 window at the reference's pitch lambda/2.2 centred on the 1 mm lens.
+N_aperture^2 * M^2 / t.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling - the aperture
-area per GPU is fixed (side = 2048*sqrt(N), lens diameter scaled alike), rows sharded over
-ranks, partial radiation vectors all-reduced with RCCL.  --scaling strong keeps the
-aperture fixed instead.
+Workloads
+  N = 1   the size BASELINE.json's north_star target is quoted on: 1 mm diameter NA 0.5 lens,
+          580 nm, 4096 x 4096 aperture window at the reference's pitch lambda/2.2 -> the central
+          512 x 512 bins of the aperture's FFT lattice, fp64.  (--aperture 2048 --farfield 256
+          is BASELINE configs[1].)
+  N > 1   BASELINE configs[2], a FIXED problem tiled over the ranks ("scaling": "strong"):
+          2 mm NA 0.94 lens, 8192 x 8192 -> 512 x 512, aperture rows sharded as mirrored pairs,
+          one RCCL all-reduce of the two projected amplitudes.  --scaling weak instead grows
+          the N = 1 workload with the rank count (side * sqrt(N), lens scaled alike).
+  --replicas wavelength   BASELINE configs[3]: every rank runs the whole N = 1 aperture at its
+          own wavelength (450 / 532 / 635 nm, cycled) with explicit n_glass; no collective in the
+          data path.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,27 +43,44 @@ import numpy as np  # noqa: E402
 # (one v_mfma_f64_16x16x4_f64 = 2048 flop per 64 cycles per SIMD).
 FP64_MFMA_PEAK_TFLOPS = 78.6
 FP32_MFMA_PEAK_TFLOPS = 157.3     # v_mfma_f32_16x16x4_f32, MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0             # spec; ~6300 GB/s is what a streaming copy reaches (same guide)
+
+RGB = ((450e-9, 1.4656), (532e-9, 1.4607), (635e-9, 1.4570))   # configs[3]; n_glass of fused silica
+
+# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads), measured
+# for the default N = 1 command: profiles/r02*_summary.txt.  None until measured for a config.
+PMC_TRAFFIC = {}
 
 
-def build_workload(aperture, farfield, diameter, na, wavelength, zoom):
+def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0):
     import metalens_amd as ma
     from metalens_amd import layout, synthetic
     degree = math.pi / 180
     lens = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet),
                                layout.make_design, radius=diameter / 2, numerical_aperture=na,
                                wavelength=wavelength, switch_angle=12 * degree, num_gratings=24,
-                               num_entries=12)
+                               num_entries=12, n_glass=n_glass,
+                               design_kwargs={'wavelength': wavelength} if n_glass else None)
     pitch = wavelength / 2.2
     x = (np.arange(aperture) - (aperture - 1) / 2) * pitch
     # far-field grid: M x M directions centred on the collimated beam, `zoom` FFT-lattice
     # spacings apart (zoom = 1 -> the central M x M bins of the FFT lattice)
     # (the lattice of nearfield_farfield.py:35-39, built like the reference builds it: from the
     # sample spacing the aperture axis actually has, x[1] - x[0])
-    n_glass = 1.459
-    du = zoom * (wavelength / n_glass) / ((x[1] - x[0]) * aperture)
+    ng = n_glass or 1.459
+    du = zoom * (wavelength / ng) / ((x[1] - x[0]) * aperture)
     u = (np.arange(farfield) - farfield // 2) * du
     return lens, x, u
+
+
+def _one_thread(fn):
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        return fn()
+    with threadpool_limits(limits=1):
+        return fn()
 
 
 def cpu_baseline(lens, x, u, wavelength, sample_rows, source):
@@ -66,10 +89,6 @@ def cpu_baseline(lens, x, u, wavelength, sample_rows, source):
     the centre of the same workload, near field + direct far-field transform to the same
     direction grid.  One thread."""
     from oracle import farfield_oracle, nearfield_oracle
-    try:
-        from threadpoolctl import threadpool_limits
-    except Exception:  # pragma: no cover
-        threadpool_limits = None
     r0 = (x.size - sample_rows) // 2
     xs = x[r0:r0 + sample_rows]
     args = dict(source_x=source[0], source_y=source[1], source_z=source[2], source_pol=source[3],
@@ -81,15 +100,11 @@ def cpu_baseline(lens, x, u, wavelength, sample_rows, source):
         t0 = time.perf_counter()
         Ex, Ey, Hx, Hy, _, _, _, n_glass = nearfield_oracle.build_nearfield(**args)
         t1 = time.perf_counter()
-        out = farfield_oracle.farfield_direct(Ex, Ey, Hx, Hy, xs, x, wavelength, n_glass, u, u)
+        farfield_oracle.farfield_direct(Ex, Ey, Hx, Hy, xs, x, wavelength, n_glass, u, u)
         t2 = time.perf_counter()
-        return t1 - t0, t2 - t1, out
+        return t1 - t0, t2 - t1
 
-    if threadpool_limits is not None:
-        with threadpool_limits(limits=1):
-            t_nf, t_ff, _ = run()
-    else:
-        t_nf, t_ff, _ = run()
+    t_nf, t_ff = _one_thread(run)
     pairs = float(sample_rows) * x.size * u.size * u.size
     return {'value': pairs / (t_nf + t_ff), 'unit': 'pair-evals/s', 'cores': 1, 'kind': 'port',
             'sample': '%d of %d aperture rows (x %d columns) of the same lens -> the same %dx%d '
@@ -98,20 +113,68 @@ def cpu_baseline(lens, x, u, wavelength, sample_rows, source):
             'host_cpu_count': os.cpu_count()}
 
 
+def cpu_reference_route(lens, x, wavelength, side, source):
+    """The reference's OWN far-field route (README.md:27, nearfield_farfield.py:18-75) restated by
+    the oracle, on a bounded sample: build_nearfield on the central side x side window ->
+    numpy.fft.fft2(fftshift(F)) for the four fields -> farfield_from_nearfield, which yields ALL
+    side^2 lattice directions (it has no M argument).  One thread."""
+    from oracle import farfield_oracle, nearfield_oracle
+    r0 = (x.size - side) // 2
+    xs = x[r0:r0 + side]
+    args = dict(source_x=source[0], source_y=source[1], source_z=source[2], source_pol=source[3],
+                wavelength=wavelength, lens_periphery_summary=lens['lens_periphery_summary'],
+                lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'],
+                x_pts=xs, y_pts=xs)
+
+    def run():
+        t0 = time.perf_counter()
+        Ex, Ey, Hx, Hy, _, _, _, n_glass = nearfield_oracle.build_nearfield(**args)
+        t1 = time.perf_counter()
+        ffts = [np.fft.fft2(np.fft.fftshift(F)) for F in (Ex, Ey, Hx, Hy)]
+        t2 = time.perf_counter()
+        farfield_oracle.farfield_from_nearfield(*ffts, xs, xs, wavelength, n_glass)
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2
+
+    t_nf, t_fft, t_pr = _one_thread(run)
+    total = t_nf + t_fft + t_pr
+    return {'value': float(side) ** 4 / total, 'unit': 'pair-evals/s (side^2 samples x side^2 '
+            'lattice directions, which the FFT route always produces)', 'cores': 1, 'kind': 'port',
+            'samples_per_s': float(side) ** 2 / total,
+            'sample': 'central %dx%d window of the same lens: oracle near field %.2f s + 4 x '
+                      'numpy fft2(fftshift) %.2f s + oracle farfield_from_nearfield %.2f s'
+                      % (side, side, t_nf, t_fft, t_pr)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--aperture', type=int, default=2048, help='aperture samples per side at N=1')
-    ap.add_argument('--farfield', type=int, default=256, help='far-field directions per side')
-    ap.add_argument('--diameter', type=float, default=1e-3, help='lens diameter at N=1 [m]')
-    ap.add_argument('--na', type=float, default=0.5)
+    ap.add_argument('--aperture', type=int, default=None,
+                    help='aperture samples per side (default 4096; 8192 for N > 1)')
+    ap.add_argument('--farfield', type=int, default=512, help='far-field directions per side')
+    ap.add_argument('--diameter', type=float, default=None,
+                    help='lens diameter [m] (default 1e-3; 2e-3 for N > 1)')
+    ap.add_argument('--na', type=float, default=None, help='default 0.5; 0.94 for N > 1')
     ap.add_argument('--wavelength', type=float, default=580e-9)
     ap.add_argument('--zoom', type=float, default=1.0)
-    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak')
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default=None,
+                    help='N > 1: strong (default) = BASELINE configs[2] tiled over the ranks; weak = '
+                         'the N = 1 workload grown with sqrt(N)')
+    ap.add_argument('--replicas', choices=('none', 'wavelength'), default='none',
+                    help='wavelength: BASELINE configs[3], every rank runs the whole aperture at its '
+                         'own wavelength, no collective in the data path')
+    ap.add_argument('--pair-list', type=int, default=0,
+                    help='> 0: that many arbitrary directions (ux[d], uy[d]) inside the NA cone '
+                         'instead of the M x M tensor grid')
+    ap.add_argument('--blocks', type=int, default=5,
+                    help='K-step blocks run back to back; the FIRST is the timed region `value` '
+                         'comes from, the median block is reported beside it')
     ap.add_argument('--cpu-rows', type=int, default=1024,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-fft-side', type=int, default=1024,
+                    help="side of the window the reference's FFT route is timed on (0 = skip)")
     ap.add_argument('--check', type=int, default=1, help='verify a sample against the oracle')
     ap.add_argument('--fuse-modulation', type=int, default=1,
                     help='1: the stage-1 input modulation rides in the synthesis kernel (default)')
@@ -148,16 +211,32 @@ def main():
     ctx = _lib.Context(local_rank)
     dist.init_comm(ctx, rank, world)
 
-    side = args.aperture
-    diameter = args.diameter
-    if world > 1 and args.scaling == 'weak':
-        side = int(round(args.aperture * math.sqrt(world) / 16)) * 16
-        diameter = args.diameter * side / args.aperture
-    lens, x, u = build_workload(side, args.farfield, diameter, args.na, args.wavelength, args.zoom)
+    replicas = args.replicas == 'wavelength'
+    scaling = args.scaling or ('strong' if world > 1 and not replicas else 'weak')
+    tiled = world > 1 and scaling == 'strong' and not replicas
+    side = args.aperture or (8192 if tiled else 4096)
+    diameter = args.diameter or (2e-3 if tiled else 1e-3)
+    na = args.na or (0.94 if tiled else 0.5)
+    wavelength, n_glass = args.wavelength, 0
+    if replicas:
+        wavelength, n_glass = RGB[rank % len(RGB)]
+    elif world > 1 and scaling == 'weak':
+        base = side
+        side = int(round(base * math.sqrt(world) / 16)) * 16
+        diameter = diameter * side / base
+    lens, x, u = build_workload(side, args.farfield, diameter, na, wavelength, args.zoom, n_glass)
+    ux, uy = u, u
+    if args.pair_list:
+        rng = np.random.default_rng(7)
+        th = np.arcsin(rng.uniform(0, 0.9 * na / 1.459, args.pair_list))
+        ph = rng.uniform(0, 2 * np.pi, args.pair_list)
+        ux, uy = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph)
     source = (0.0, 0.0, -lens['source_distance'], 'x')
-    hp = HotPath(source, args.wavelength, lens['lens_periphery_summary'],
-                 lens['lens_center_summary'], lens['hexgridset'], x, x, u, u, ctx=ctx,
-                 rank=rank, world=world, precision=args.precision, reduce=args.reduce,
+    hp = HotPath(source, wavelength, lens['lens_periphery_summary'],
+                 lens['lens_center_summary'], lens['hexgridset'], x, x, ux, uy, ctx=ctx,
+                 pair_list=bool(args.pair_list),
+                 rank=0 if replicas else rank, world=1 if replicas else world,
+                 precision=args.precision, reduce=args.reduce,
                  fuse_modulation=bool(args.fuse_modulation), method=args.method)
 
     for _ in range(args.warmup):
@@ -170,70 +249,89 @@ def main():
                 kernels=('nearfield', 'zgemm_stage1') if args.profile == 'main' else None,
                 every=every)
     ctx.profile_reset()
-    dist.barrier(ctx)
-    hp.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        hp.step()
-    hp.sync()
-    dist.barrier(ctx)
-    elapsed = time.perf_counter() - t0
-    elapsed = float(dist.allreduce_host(ctx, [elapsed], 'max')[0])
-    prof = ctx.profile_get()
-    ctx.profile(False)
+    block_ms = []
+    prof = None
+    for block in range(max(1, args.blocks)):
+        dist.barrier(ctx)
+        hp.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hp.step()
+        hp.sync()
+        dist.barrier(ctx)
+        dt = time.perf_counter() - t0
+        dt = float(dist.allreduce_host(ctx, [dt], 'max')[0])
+        block_ms.append(1e3 * dt / args.steps)
+        if block == 0:                # THE timed region: exactly K steps, max over ranks
+            elapsed = dt
+            prof = ctx.profile_get()
+            ctx.profile(False)
     res = hp.results()
     if args.dump and rank == 0:
         np.savez(args.dump, P=res['P'], a_theta=res['a_theta'], a_phi=res['a_phi'])
+    stage_kernels = ctx.plan_kernels()
 
     # ---- correctness of what was just timed (rank 0, N=1): a sample of directions against
     # the CPU oracle evaluated from the GPU's own near field rows
     rel_err = None
-    if args.check and world == 1:
+    if args.check and world == 1 and not args.pair_list:
         from oracle import farfield_oracle, nearfield_oracle
         rows = slice(side // 2 - 8, side // 2 + 8)
         Ex = [np.empty((side, side), dtype=np.complex128) for _ in range(4)]
         _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(a) for a in Ex]))
         want = nearfield_oracle.build_nearfield(
-            source[0], source[1], source[2], source[3], args.wavelength,
+            source[0], source[1], source[2], source[3], wavelength,
             lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'],
             x_pts=x[rows], y_pts=x)
         scale = max(np.abs(w).max() for w in want[:4])
         nf_err = max(np.abs(g[rows] - w).max() for g, w in zip(Ex, want[:4])) / scale
         sel = np.arange(0, u.size, max(1, u.size // 16))
-        ref = farfield_oracle.farfield_direct(*Ex, x, x, args.wavelength, hp.n_glass, u[sel], u[sel])
+        ref = farfield_oracle.farfield_direct(*Ex, x, x, wavelength, hp.n_glass, u[sel], u[sel])
         ff_err = max(np.abs(res[k][np.ix_(sel, sel)] - ref[k]).max() / np.abs(ref[k]).max()
                      for k in ('a_theta', 'a_phi'))
         rel_err = {'nearfield_vs_oracle': nf_err, 'farfield_E_vs_oracle': ff_err}
+        del Ex
 
-    pairs = float(side) * side * u.size * u.size
+    n_dir = float(args.pair_list) if args.pair_list else float(u.size) * u.size
+    pairs = float(side) * side * n_dir * (world if replicas else 1)
     ms_per_step = 1e3 * elapsed / args.steps
+    if replicas:
+        what = ('%d replicas of the N = 1 workload, one wavelength each (%s nm, explicit n_glass)'
+                % (world, '/'.join('%d' % round(RGB[r % len(RGB)][0] * 1e9) for r in range(world))))
+        par = 'replicas only: every rank runs the whole aperture at its own wavelength, no collective'
+    else:
+        what = ('%.3g mm dia NA=%.2g lens, lambda=%.0f nm, %dx%d aperture window at pitch lambda/2.2 '
+                '-> %s, fp64, on-axis x-dipole at the focus'
+                % (diameter * 1e3, na, wavelength * 1e9, side, side,
+                   '%d listed directions' % args.pair_list if args.pair_list else
+                   '%dx%d far-field directions (bins of the aperture FFT lattice x %g)'
+                   % (u.size, u.size, args.zoom)))
+        par = ('aperture rows (mirrored pairs) sharded over %d GPU(s), 1 RCCL all-reduce of the %s'
+               % (world, 'two projected amplitudes' if args.reduce == 'amplitudes'
+                  else 'four radiation vectors'))
     line = {
         'metric': 'aperture x far-field pair-evals/sec',
         'value': pairs * args.steps / elapsed,
         'unit': 'pair-evals/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': args.scaling,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': scaling,
         'vs_baseline': None,
         'dtype': 'f64' if args.precision == 'f64' else 'f32 GEMMs (f64 near field and storage)',
         'data': 'synthetic',
-        'config': {'workload': '%.3g mm dia NA=%.2g lens, lambda=%.0f nm, %dx%d aperture window at '
-                               'pitch lambda/2.2 -> %dx%d far-field directions, fp64, on-axis '
-                               'x-dipole at the focus'
-                               % (diameter * 1e3, args.na, args.wavelength * 1e9, side, side,
-                                  u.size, u.size),
-                   'aperture': side, 'farfield': u.size, 'rings': int(len(
-                       lens['lens_periphery_summary']['r_center_list'])),
+        'config': {'workload': what, 'aperture': side, 'farfield': u.size,
+                   'rings': int(len(lens['lens_periphery_summary']['r_center_list'])),
                    'centre_cells': int(len(lens['lens_center_summary'])),
-                   'parallelism': 'aperture rows (mirrored pairs) sharded over %d GPU(s), 1 RCCL '
-                                  'all-reduce of the %s' % (world, 'two projected amplitudes'
-                                                            if args.reduce == 'amplitudes'
-                                                            else 'four radiation vectors')},
+                   'parallelism': par,
+                   'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]}},
+        # the same K steps again, args.blocks times in all: spread of the measurement
+        'ms_per_step_blocks': block_ms, 'ms_per_step_median': float(np.median(block_ms)),
     }
     # ---- rooflines.  `roofline` describes the kernel that takes the most time per step; the
-    # other of the two large kernels goes to `roofline_other`.
-    #  * stage 1 (fp64 matrix cores): algorithmic flops per launch = 8 (complex MAC) x
-    #    (4 fields x local rows) x ny x my            (8 M N^2 per field)
+    # other of the two large kernels goes to `roofline_other`.  All fractions are <= 1.
     #  * near field (HBM): algorithmic bytes per launch = 64 B per sample written (4 complex128)
+    #  * stage 1 as a pruned FFT (HBM): 64 B per sample read + 64 B per (row, direction) written
+    #  * stage 1 as a GEMM (fp64 / fp32 matrix cores): EXECUTED flops / peak; the textbook count
+    #    of 8 flop per complex (sample, direction) pair goes to `algorithmic_tflops`
     # --profile main times one launch of each of its two kernels every `every` steps (one launch
     # per step each): the per-step figure is the average over the timed launches
     line['kernels_ms_per_step'] = {k: (v['total_ms'] / v['launches'] if every > 1
@@ -241,42 +339,49 @@ def main():
                                    for k, v in prof.items() if v['launches']}
     line['kernel_timing'] = {'mode': args.profile, 'timed_every_n_steps': every}
     local_rows = hp.x_local.size
-    default_cfg = (world == 1 and side == 2048 and u.size == 256)
+    cfg_key = (world, side, u.size, args.precision, args.method, args.zoom)
     roofs = {}
     s1 = prof['zgemm_stage1']
     if s1['launches']:
-        flops = 8.0 * 4 * local_rows * side * u.size
-        mfma_peak = FP64_MFMA_PEAK_TFLOPS if args.precision == 'f64' else FP32_MFMA_PEAK_TFLOPS
         avg_ms = s1['total_ms'] / s1['launches']
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        folded = _lib.c_int(0)
-        _lib.check(ctx.lib.ml_farfield_plan_info(ctx.handle, _lib.byref(folded)))
-        # flops the kernel really issues on the matrix cores: the folded kernel needs 2 real
-        # flop per complex (sample, direction) pair (both mirror symmetries), the generic 3M
-        # kernel 6, against the 8 of the textbook complex multiply-add that `achieved` counts
-        executed = flops * (0.25 if folded.value else 0.75)
-        if folded.value:
-            # the folded kernel also skips the all-zero outer part of each aperture row (samples
-            # outside the lens circle): kept fraction of each row = chord / window width
-            r_lens = float(lens['lens_periphery_summary']['r_max_list'][-1])
-            chord = 2 * np.sqrt(np.maximum(r_lens ** 2 - hp.x_local ** 2, 0.0))
-            executed *= float(np.minimum(chord / (x[-1] - x[0]), 1.0).mean())
-        roofs['zgemm_stage1'] = {
-            'bound': 'mfma',
-            'kernel': ('zfold_kernel' if folded.value else 'zgemm_kernel<3M>') + ' (stage 1)',
-            'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
-            'frac': achieved / mfma_peak,
-            # PMC, profiles/r01m_summary.txt: FETCH_SIZE x2 (272.1 MB) + WRITE_SIZE (69.8 MB: two
-            # split-K slabs) per launch [bytes]
-            'traffic': 341.9e6 if default_cfg and args.precision == 'f64' else None,
-            'avg_launch_ms': avg_ms, 'flops_per_launch': flops,
-            'executed_flops_per_launch': executed,
-            'mfma_pipe_frac': executed / (avg_ms * 1e-3) / 1e12 / mfma_peak,
-            'note': 'achieved = algorithmic flops (8 per complex MAC) / time; the kernel executes '
-                    'executed_flops_per_launch of them, so frac can exceed 1; mfma_pipe_frac is '
-                    'the matrix-pipe occupancy at 2.4 GHz'}
-        if args.precision == 'f32':
-            roofs['zgemm_stage1']['kernel'] += ', fp32 matrix cores'
+        if stage_kernels[0] == 'fft':
+            nbytes = 64.0 * local_rows * side + 64.0 * local_rows * u.size
+            achieved = nbytes / (avg_ms * 1e-3) / 1e9
+            roofs['zgemm_stage1'] = {
+                'bound': 'hbm', 'kernel': 'zfft_kernel (stage 1, output-pruned FFT in LDS)',
+                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('stage1'),
+                'avg_launch_ms': avg_ms, 'bytes_per_launch': nbytes,
+                'note': 'algorithmic bytes = every aperture sample read once (4 fields x 16 B) + the '
+                        'row transforms written; samples outside the lens circle are known zeros '
+                        'and are not read, so traffic can be below bytes_per_launch'}
+        else:
+            flops = 8.0 * 4 * local_rows * side * u.size
+            mfma_peak = FP64_MFMA_PEAK_TFLOPS if args.precision == 'f64' else FP32_MFMA_PEAK_TFLOPS
+            # flops the kernel really issues on the matrix cores: the folded kernel needs 2 real
+            # flop per complex (sample, direction) pair (both mirror symmetries), the generic 3M
+            # kernel 6, against the 8 of the textbook complex multiply-add
+            executed = flops * (0.25 if stage_kernels[0] == 'folded' else 0.75)
+            if stage_kernels[0] == 'folded':
+                # the folded kernel also skips the all-zero outer part of each aperture row
+                # (samples outside the lens circle): kept fraction of each row = chord / width
+                r_lens = float(lens['lens_periphery_summary']['r_max_list'][-1])
+                chord = 2 * np.sqrt(np.maximum(r_lens ** 2 - hp.x_local ** 2, 0.0))
+                executed *= float(np.minimum(chord / (x[-1] - x[0]), 1.0).mean())
+            achieved = executed / (avg_ms * 1e-3) / 1e12
+            roofs['zgemm_stage1'] = {
+                'bound': 'mfma',
+                'kernel': ('zfold_kernel' if stage_kernels[0] == 'folded' else 'zgemm_kernel<3M>')
+                          + ' (stage 1)' + (', fp32 matrix cores' if args.precision == 'f32' else ''),
+                'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
+                'frac': achieved / mfma_peak,
+                'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('stage1'),
+                'avg_launch_ms': avg_ms, 'flops_per_launch': executed,
+                'algorithmic_tflops': flops / (avg_ms * 1e-3) / 1e12,
+                'note': 'achieved = flops EXECUTED on the matrix cores / time (matrix-pipe occupancy '
+                        'at 2.4 GHz); algorithmic_tflops counts the textbook 8 flop per complex '
+                        '(sample, direction) pair, of which the folded kernel executes a quarter'}
     nf = prof['nearfield']
     if nf['launches']:
         nf_bytes = 64.0 * local_rows * side
@@ -285,22 +390,30 @@ def main():
         roofs['nearfield'] = {
             'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            # PMC, profiles/r01m_summary.txt: FETCH_SIZE x2 (56.7 MB) + WRITE_SIZE (270.6 MB) per launch
-            'traffic': 327.2e6 if default_cfg else None,
+            'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('nearfield'),
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-            'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by '
-                    'instruction issue (fp64 VALU) and dependent L1 gathers, not by HBM '
+            'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by its '
+                    'per-sample table gathers through the L1 and by fp64 issue, not by HBM '
                     '(DESIGN.md 4.1)'}
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
         if len(order) > 1:
             line['roofline_other'] = roofs[order[1]]
+        # the whole step against the north_star's bound: compulsory bytes (the
+        # four fields once + the four radiation vectors) / step time / HBM peak
+        step_bytes = (64.0 * side * side + 64.0 * n_dir) * (world if replicas else 1)
+        line['roofline']['step_hbm_frac'] = step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
+        line['roofline']['step_bytes'] = step_bytes
     if rel_err is not None:
         line['rel_err'] = rel_err
-    if rank == 0 and world == 1 and args.cpu_rows > 0:
-        line['cpu_baseline'] = cpu_baseline(lens, x, u, args.wavelength,
-                                            min(args.cpu_rows, side), source)
+    if rank == 0 and world == 1:
+        if args.cpu_rows > 0 and not args.pair_list:
+            line['cpu_baseline'] = cpu_baseline(lens, x, u, wavelength, min(args.cpu_rows, side),
+                                                source)
+        if args.cpu_fft_side > 0 and not args.pair_list:
+            line['cpu_baseline_reference_route'] = cpu_reference_route(
+                lens, x, wavelength, min(args.cpu_fft_side, side), source)
     ctx.close()
     if rank == 0:
         # anything native libraries left in C stdio buffers goes out first: the JSON line is the

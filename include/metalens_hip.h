@@ -190,12 +190,6 @@ int ml_farfield_allreduce(ml_ctx *ctx);
  * ml_farfield_project[_async] returns these results; the radiation vectors stay local partial
  * sums.  Without a communicator it is the plain projection.                                  */
 int ml_farfield_project_reduce(ml_ctx *ctx, double Z0);
-/* Two contexts on ONE GPU (each has its own stream) can work on two halves of the aperture
- * concurrently - near-field synthesis is latency/issue-bound with idle matrix cores, the GEMMs
- * are matrix-core-bound, so the two overlap.  This adds src's radiation vectors into dst's,
- * ordered by events on the two streams (dst waits for src's transform; src will not start
- * overwriting its vectors before the addition has run); no host synchronisation.          */
-int ml_farfield_add_vectors(ml_ctx *dst, ml_ctx *src);
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi);
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
 /* which stage-1 kernel the current plan uses: *stage1_kernel = 0 generic complex GEMM (3M),

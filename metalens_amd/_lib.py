@@ -33,7 +33,7 @@ SYMBOLS = (
     'ml_device_info', 'ml_upload_table', 'ml_upload_layout', 'ml_nearfield',
     'ml_fields_download', 'ml_fields_upload', 'ml_fields_shape', 'ml_farfield_lattice_power',
     'ml_farfield_plan', 'ml_farfield_transform', 'ml_farfield_allreduce', 'ml_farfield_project',
-    'ml_farfield_download', 'ml_farfield_plan_info', 'ml_farfield_set_precision', 'ml_farfield_project_reduce', 'ml_farfield_add_vectors', 'ml_profile_select',
+    'ml_farfield_download', 'ml_farfield_plan_info', 'ml_farfield_set_precision', 'ml_farfield_project_reduce', 'ml_profile_select',
     'ml_profile_sample',
     'ml_nearfield_premodulate', 'ml_comm_unique_id', 'ml_comm_init', 'ml_comm_allreduce_host',
     'ml_comm_barrier', 'ml_profile_enable', 'ml_profile_reset', 'ml_profile_get', 'ml_sync',
@@ -118,7 +118,6 @@ def load():
     lib.ml_farfield_plan_kernels.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.ml_farfield_set_method.argtypes = [c_void_p, c_int]
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
-    lib.ml_farfield_add_vectors.argtypes = [c_void_p, c_void_p]
     lib.ml_profile_select.argtypes = [c_void_p, ctypes.c_uint]
     lib.ml_profile_sample.argtypes = [c_void_p, c_int]
     lib.ml_nearfield_premodulate.argtypes = [c_void_p, c_int]

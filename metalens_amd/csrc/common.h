@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -40,6 +41,19 @@ void set_error(const char *fmt, ...);
         int rc_ = (expr);     \
         if (rc_ != ML_OK) return rc_; \
     } while (0)
+
+// Tuning and ablation knobs exist only in the diagnostic build (make EXTRA=-DML_DIAG BUILD=build_diag
+// TARGET=...): there diag_int() reads an environment variable, in the product library it is the
+// default, a constant.  The product reads no environment except the test communicator switch
+// (comm.hip, ML_COMM_BACKEND).
+#ifdef ML_DIAG
+inline int diag_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+constexpr int diag_int(const char *, int dflt) { return dflt; }
+#endif
 
 // A device allocation that only grows.
 struct DevBuf {
@@ -213,7 +227,6 @@ struct ml_ctx {
     std::vector<int32_t> h_ring_gc;
     ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
     ml::DevBuf rot_table, tie_table, ring_rot_center, ring_rot_half;
-    ml::DevBuf ring_i2, ring_t2;
     ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables
     ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
@@ -246,7 +259,6 @@ struct ml_ctx {
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
     int ff_method = 0;  // ml_farfield_set_method: 0 auto (FFT on lattice grids), 1 GEMMs only
-    hipEvent_t peer_event = nullptr;   // ml_farfield_add_vectors: cross-stream ordering
     // ml_nearfield_premodulate: the synthesis applies the active plan's stage-1 input modulation;
     // fields_premod_serial = serial of the plan whose modulation the resident fields carry (-1: none)
     bool premod_enabled = false;

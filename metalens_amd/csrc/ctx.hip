@@ -147,8 +147,6 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         i2[r] = i;
         t2[r] = (x - ax[i]) / (ax[i + 1] - ax[i]);
     }
-    ML_TRY(h2d(ctx, ctx->ring_i2, i2.data(), i2.size() * sizeof(int32_t)));
-    ML_TRY(h2d(ctx, ctx->ring_t2, t2.data(), t2.size() * sizeof(double)));
 
     // Fast kernel: per-ring tables with the period axis already interpolated
     // (v[..., i2] * (1 - t2) + v[..., i2 + 1] * t2), complex [order][n0][n1][4], and the
@@ -421,7 +419,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     ctx->center.order_k.release();
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
-                      &ctx->ring_i2, &ctx->ring_t2, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
+                      &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
@@ -441,7 +439,6 @@ void ml_ctx_destroy(ml_ctx *ctx) {
         (void)hipEventDestroy(pd.b);
     }
     for (auto e : ctx->prof.pool) (void)hipEventDestroy(e);
-    if (ctx->peer_event) (void)hipEventDestroy(ctx->peer_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -629,10 +626,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
         for (int c = 0; c < n_cells; ++c) ctx->h_slot_of_cell[si[c]] = c;
         ML_TRY(h2d(ctx, ctx->bin_start, start.data(), start.size() * sizeof(int32_t)));
         // lattice shortcut for the nearest-cell search (sorted slots index the arrays above)
-        static const bool no_lattice = [] {
-            const char *e = getenv("ML_NO_CELL_LATTICE");
-            return e && atoi(e) != 0;
-        }();
+        static const bool no_lattice = diag_int("ML_NO_CELL_LATTICE", 0) != 0;
         LatticeFit L = no_lattice ? LatticeFit() : fit_lattice(sx, sy);
         ctx->lat_ok = L.ok;
         if (L.ok) {
@@ -704,8 +698,8 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     ML_TRY(ctx->fields.reserve(4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
-    // one power partial per workgroup: exact kernel 256 x 1 samples, fast kernel 8 x 32 or 8 x 8
-    const int blocks = std::max(((ny + 255) / 256) * nx, ((ny + 7) / 8) * ((nx + 7) / 8));
+    // one power partial per wave (8 x 8 samples)
+    const int blocks = ((ny + 7) / 8) * ((nx + 7) / 8);
     ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
     ML_TRY(ctx->power.reserve(POWER_GROUPS * sizeof(double)));
     // two halves: each synthesis launch clears the one the next launch reports into

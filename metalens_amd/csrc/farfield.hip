@@ -158,17 +158,6 @@ __global__ __launch_bounds__(256) void zunmodulate_kernel(double2 *fields, const
     fields[at] = make_double2(v.x * e.x + v.y * e.y, v.y * e.x - v.x * e.y);
 }
 
-// dst += src (radiation vectors of another context on the same GPU)
-__global__ __launch_bounds__(256) void zadd_kernel(double2 *dst, const double2 *src, size_t n) {
-    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (at >= n) return;
-    const double2 v = src[at];
-    double2 d = dst[at];
-    d.x += v.x;
-    d.y += v.y;
-    dst[at] = d;
-}
-
 // in[0] += in[1] + ... + in[splits-1]  (split-K slabs of stage 1 when the consumer is not the
 // transposing kernel)
 __global__ __launch_bounds__(256) void zsum_slabs_kernel(double2 *in, size_t n, int splits) {
@@ -427,10 +416,7 @@ static long double symmetry_tolerance(long double kappa, long double p_max, cons
 static int plan_fold(ml_ctx *ctx, const double *uy) {
     FarfieldPlan &pl = ctx->plan;
     pl.fold = false;
-    static const bool disabled = [] {
-        const char *e = getenv("ML_NO_FOLD");
-        return e && atoi(e) != 0;
-    }();
+    static const bool disabled = diag_int("ML_NO_FOLD", 0) != 0;
     if (disabled || pl.pair_list || pl.my < 2 || pl.ny < 2) return ML_OK;
     const int ny = pl.ny, my = pl.my;
     const int T = (ny + 1) / 2, S = (my + 1) / 2;
@@ -516,10 +502,7 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
 static int plan_fold2(ml_ctx *ctx, const double *ux) {
     FarfieldPlan &pl = ctx->plan;
     pl.fold2 = false;
-    static const bool disabled = [] {
-        const char *e = getenv("ML_NO_FOLD2");
-        return e && atoi(e) != 0;
-    }();
+    static const bool disabled = diag_int("ML_NO_FOLD2", 0) != 0;
     if (disabled || pl.pair_list || pl.mx < 2 || pl.nx_total < 2) return ML_OK;
     const int mx = pl.mx, S = (mx + 1) / 2;
     const long double kappa = (long double)pl.n_glass / (long double)pl.wavelength;
@@ -555,10 +538,7 @@ static int stage2_tables(ml_ctx *ctx, int row0, int mirrored, int *want_split_ou
     const int nxl = ctx->nx, mx = pl.mx, my = pl.my, S = pl.fold2_S, T = (nxl + 1) / 2;
     // few rows (4*my) and a long reduction: split the pairs over several workgroups per tile
     const long tiles = (long)((4 * my + 31) / 32) * ((S + 63) / 64);
-    static const int forced_split2 = [] {
-        const char *e = getenv("ML_STAGE2_SPLIT");
-        return e ? atoi(e) : 0;
-    }();
+    static const int forced_split2 = diag_int("ML_STAGE2_SPLIT", 0);
     const int want_split = forced_split2 > 0
                                ? forced_split2
                                : (int)std::min<long>(8, std::max<long>(1, 1024 / std::max<long>(tiles, 1)));
@@ -650,10 +630,7 @@ static int stage2_folded(ml_ctx *ctx, int row0, int mirrored, int accumulate, co
     pl.unfold_splits = splits;
     pl.unfold_accumulate = accumulate;
     pl.unfold_pending = true;
-    static const bool eager = [] {
-        const char *e = getenv("ML_EAGER_UNFOLD");
-        return e && atoi(e) != 0;
-    }();
+    static const bool eager = diag_int("ML_EAGER_UNFOLD", 0) != 0;
     if (eager) ML_TRY(flush_unfold(ctx));
     return ML_OK;
 }
@@ -820,29 +797,20 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
             want_split1 = 2;
         else
             want_split1 = (int)std::min<long>(8, std::max<long>(1, (640 + t64 - 1) / std::max<long>(t64, 1)));
-        static const int forced_split = [] {
-            const char *e = getenv("ML_STAGE1_SPLIT");
-            return e ? atoi(e) : 0;
-        }();
+        static const int forced_split = diag_int("ML_STAGE1_SPLIT", 0);
         if (forced_split > 0) want_split1 = forced_split;
         pl.stage1_splits = zfold_splits(pl.fold_T, want_split1);
     }
     ML_TRY(pl.stage1.reserve((size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
-    static const long fold2_min_tiles = [] {
-        const char *e = getenv("ML_FOLD2_MIN_TILES");
-        return e ? atol(e) : 32L;   // with split-K the folded path wins from ~32 tiles up
-    }();
+    static const long fold2_min_tiles = diag_int("ML_FOLD2_MIN_TILES", 32);
     const bool whole = (row0 == 0 && nxl == pl.nx_total);
     const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
     const bool fft1 = pl.fft_y.ok, fft2 = pl.fft_x.ok && !pl.pair_list;
     const bool use_fold2 = !fft2 && !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole);
     // both stages folded: stage 1 writes its result already transposed for stage 2
-    static const bool no_direct = [] {
-        const char *e = getenv("ML_NO_GT_DIRECT");
-        return e && atoi(e) != 0;
-    }();
+    static const bool no_direct = diag_int("ML_NO_GT_DIRECT", 0) != 0;
     const bool gt_direct = pl.fold && use_fold2 && !no_direct;
     FoldIO io1;
     int want_split2 = 1;
@@ -1140,36 +1108,6 @@ int ml_farfield_set_method(ml_ctx *ctx, int method) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_REQUIRE(method == ML_METHOD_AUTO || method == ML_METHOD_GEMM, "unknown method %d", method);
     ctx->ff_method = method;
-    return ML_OK;
-}
-
-int ml_farfield_add_vectors(ml_ctx *dst, ml_ctx *src) {
-    ML_REQUIRE(dst && src && dst != src, "need two different contexts");
-    ML_REQUIRE(dst->device == src->device, "contexts live on different GPUs (%d, %d)", dst->device,
-               src->device);
-    FarfieldPlan &pd = dst->plan, &ps = src->plan;
-    if (!pd.ready || !pd.have_vectors || !ps.ready || !ps.have_vectors) {
-        set_error("both contexts need radiation vectors (ml_farfield_transform)");
-        return ML_ESTATE;
-    }
-    ML_REQUIRE(pd.mx == ps.mx && pd.my == ps.my && pd.pair_list == ps.pair_list,
-               "the two plans have different direction grids");
-    ML_HIP(hipSetDevice(dst->device));
-    ML_TRY(flush_unfold(dst));
-    ML_TRY(flush_unfold(src));
-    if (!dst->peer_event) ML_HIP(hipEventCreateWithFlags(&dst->peer_event, hipEventDisableTiming));
-    if (!src->peer_event) ML_HIP(hipEventCreateWithFlags(&src->peer_event, hipEventDisableTiming));
-    const size_t n = 4 * (size_t)pd.mx * (pd.pair_list ? 1 : pd.my);
-    // dst's stream waits for src's vectors, adds them, and src's stream waits for the add before
-    // it may overwrite them again: no host synchronisation
-    ML_HIP(hipEventRecord(src->peer_event, src->stream));
-    ML_HIP(hipStreamWaitEvent(dst->stream, src->peer_event, 0));
-    hipLaunchKernelGGL(zadd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dst->stream,
-                       pd.vectors.as<double2>(), ps.vectors.as<double2>(), n);
-    ML_HIP(hipGetLastError());
-    ML_HIP(hipEventRecord(dst->peer_event, dst->stream));
-    ML_HIP(hipStreamWaitEvent(src->stream, dst->peer_event, 0));
-    pd.amplitudes_reduced = false;
     return ML_OK;
 }
 

@@ -1,4 +1,5 @@
-// Device-side pieces shared by the two near-field kernels (exact / fast).
+// Device-side pieces of the near-field synthesis kernel: arguments, the exact discrete decisions
+// (ring, sector, nearest cell), bound reports, power partials, stores.
 #pragma once
 #include "common.h"
 
@@ -19,8 +20,8 @@ struct NfArgs {
     int nx, ny;
     // rings
     int n_rings;
-    const double *B, *rc, *period, *dphi, *lateral, *ring_t2;
-    const int *gc, *ring_i2, *lut, *rot_center, *rot_half;
+    const double *B, *rc, *period, *dphi, *lateral;
+    const int *gc, *lut, *rot_center, *rot_half;
     const double2 *rot_table;
     const double *tie_table;   // [rot_len][6]: boundary angle, cos, sin as (hi, lo) pairs
     int lut_buckets;
@@ -362,22 +363,7 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
     return boundaries_below(a, r);
 }
 
-// incident power: wave reduction, then one partial per block (fixed order)
-__device__ __forceinline__ void block_power(const NfArgs &a, double power_here) {
-    for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
-    __shared__ double wave_sum[4];
-    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = power_here;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
-            (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
-        for (int k = threadIdx.x; k < a.n_viol_keys; k += 256) a.viol_next[k] = 0ull;
-        if (threadIdx.x == 0) *a.tie_count_next = 0;
-    }
-}
-
-// the same for one-wave workgroups: one partial per wave, no barrier
+// incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream
 __device__ __forceinline__ void wave_power(const NfArgs &a, double power_here) {
     for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
     if (threadIdx.x == 0) a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = power_here;

@@ -1,6 +1,6 @@
-// Near-field synthesis, fast kernel (the default).
+// Near-field synthesis kernel (reference nearfield.py:117-477 per aperture sample).
 //
-// Same result as nearfield.hip's operation-by-operation kernel to ~1e-15, but only the
+// Agrees with the reference's operation order (oracle/nearfield_oracle.py) to ~1e-15; only the
 // arithmetic that feeds LARGE phases is kept in the reference's exact order:
 //   * ring / sector / nearest-cell decisions (r, atan2, round)            -> exact
 //   * local coordinates xp = x cos + y sin - r_center, yp                 -> exact
@@ -19,8 +19,6 @@
 //       Ex += Z0 g (kx ky U_fy + (ky^2+kz^2) U_fx) ph ; Ey += Z0 g (-(kx^2+kz^2) U_fy - kx ky U_fx) ph
 //     with g = 1/(k_glass kz n_glass)  (nearfield.py:313-327 rearranged);
 //   * use one reciprocal per sample and a branch-free Cody-Waite sin/cos.
-#include <cstdlib>
-
 #include "nearfield_dev.h"
 
 namespace ml {
@@ -248,11 +246,11 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 #define ML_MARK(k, dep)
 #endif
 
-// BW = waves per workgroup.  BW = 1: every wave is its own workgroup - no barrier at the end
-// (one power partial per wave), so a wave's slot is free the moment it finishes and the waves
-// of a SIMD drift out of phase instead of starting, stalling and finishing together.
-template <int WAVES, int BW>
-__global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const NfArgs a) {
+// Every wave is its own workgroup - no barrier at the end (one power partial per wave), so a
+// wave's slot is free the moment it finishes and the waves of a SIMD drift out of phase instead of
+// starting, stalling and finishing together.  4 waves per SIMD (124 VGPRs): measured best.
+__global__ __launch_bounds__(64, 4) void nearfield_fast_kernel(const NfArgs a) {
+    constexpr int BW = 1;
     // Thread -> sample map: each wave covers an 8 x 8 patch of the aperture (not a 64 x 1
     // line), so its lanes fall into 2-3 rings instead of ~10 and the table gathers of one
     // wave instruction touch few distinct cache lines (measured: -20 % at 4096^2).  The
@@ -469,10 +467,7 @@ __global__ __launch_bounds__(64 * BW, WAVES) void nearfield_fast_kernel(const Nf
         store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
         ML_MARK(11, power_here);
     }
-    if (BW == 1)
-        wave_power(a, power_here);
-    else
-        block_power(a, power_here);
+    wave_power(a, power_here);
 #ifdef ML_PHASE_TIMERS
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) etc.: the stores have left the wave
     stamp[12] = __builtin_amdgcn_s_memtime();
@@ -491,25 +486,9 @@ extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
 #endif
 
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
-    static const int waves = [] {
-        const char *e = getenv("ML_NF_WAVES");
-        return e ? atoi(e) : 4;   // measured: 4 waves/SIMD (124 VGPRs) beats 3 by 10 %, 5 spills
-    }();
-    static const int block_waves = [] {
-        const char *e = getenv("ML_NF_BLOCK_WAVES");
-        return e ? atoi(e) : 1;   // measured: one-wave workgroups -6 % (2048^2) / -9 % (4096^2)
-    }();
-    const int bw = block_waves == 1 ? 1 : 4;
-    const dim3 grid((a.ny + 8 * bw - 1) / (8 * bw), (a.nx + 7) / 8);
+    const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
     *n_partials = (int)(grid.x * grid.y);
-    if (bw == 1)
-        hipLaunchKernelGGL((nearfield_fast_kernel<4, 1>), grid, dim3(64), 0, ctx->stream, a);
-    else if (waves == 4)
-        hipLaunchKernelGGL((nearfield_fast_kernel<4, 4>), grid, dim3(256), 0, ctx->stream, a);
-    else if (waves == 5)
-        hipLaunchKernelGGL((nearfield_fast_kernel<5, 4>), grid, dim3(256), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((nearfield_fast_kernel<3, 4>), grid, dim3(256), 0, ctx->stream, a);
+    hipLaunchKernelGGL(nearfield_fast_kernel, grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

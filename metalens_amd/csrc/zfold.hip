@@ -24,8 +24,6 @@
 // aperture samples), 4 waves per SIMD.  LDS: the folded planes Ge, Go as (re, im) pairs
 // [32][34] = 35 KB; the cos/sin operand is generated in registers.  With my <= 256 the aperture
 // is read from HBM exactly once.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace ml {
@@ -62,7 +60,7 @@ struct FoldArgs {
     int64_t lda;
     int M, ny;
     const double *Cm, *Sm;  // [T][S] real, s contiguous
-    const double *R4c, *R4s; // [S] cos / sin of the rotation that advances t by 4 (FLY kernels)
+    const double *R4c, *R4s; // [S] cos / sin of the rotation that advances t by 4
     int T, S;
     const double2 *E;       // [ny] input modulation, or nullptr when u_c == 0
     const double2 *D;       // [my] output diagonal
@@ -82,7 +80,6 @@ struct FoldArgs {
     // TRANSPOSED per field, C[(field * my + j) * out_t_rows + n1] - the layout the folded
     // stage 2 reads - instead of C[row * ldc + j]
     int out_t_rows;
-    int debug_skip;
     const double2 *out_E;   // with out_t_rows: phasor per n1 multiplied into the output (the next
                             // stage's input modulation), or nullptr
 };
@@ -91,24 +88,21 @@ __device__ __forceinline__ double2 zmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT,
-          bool IN_SUM, bool OUT_T>
+template <int BM, int BN, int WM, int WN, int UNR, int BKT, int MINB, typename CT, bool IN_SUM,
+          bool OUT_T>
 __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs a) {
     typedef typename Mma<CT>::acc_t acc_t;
     typedef typename Mma<CT>::pair_t pair_t;
-    static_assert(FLY || sizeof(CT) == 8, "the table-operand variants are fp64 only");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int LDAS = BKT + 2, LDBS = BN + 16;
+    constexpr int LDAS = BKT + 2;
     constexpr int A_PER = BM * BKT / NT;          // (row, t) pairs per thread
-    constexpr int B_PER = BKT * BN / 2 / NT;      // double2 per thread per plane
-    static_assert(BM * BKT % NT == 0 && (BKT * BN / 2) % NT == 0, "tile/threads mismatch");
+    static_assert(BM * BKT % NT == 0, "tile/threads mismatch");
 
     // folded planes, (re, im) packed: one ds_read_b128 (fp64) / ds_read_b64 (fp32) per plane
     // and fragment; a row pitch of BKT + 2 pairs makes both conflict-free (lane groups of
     // MI355X_MICROARCH.md, LDS)
     __shared__ pair_t sGe[BM * LDAS], sGo[BM * LDAS];
-    __shared__ __align__(16) double sC[FLY ? 2 : BKT * LDBS], sS[FLY ? 2 : BKT * LDBS];
 
     const int b = blockIdx.x;
     const int linear = (b & 7) * a.chunk + (b >> 3);   // XCD-aware order, see zgemm.hip
@@ -137,7 +131,6 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
     t_begin = max(t_begin, (int)blockIdx.y * a.t_chunk);
 
     double2 gm[A_PER], gp[A_PER];   // F[k-], F[k+] (already modulated)
-    double2 rc[B_PER], rs[B_PER];
     auto load_tile = [&](int t0) {
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) {
@@ -169,30 +162,6 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             gm[p] = fm;
             gp[p] = fp;
         }
-#pragma unroll
-        for (int p = 0; p < (FLY ? 0 : B_PER); ++p) {
-            const int e = (tid + p * NT) * 2;
-            const int t = t0 + e / BN, s = s0 + e % BN;
-            double2 c = make_double2(0.0, 0.0), sn = make_double2(0.0, 0.0);
-            if (t < a.T) {
-                const int64_t at = (int64_t)t * a.S + s;
-                if (s + 1 < a.S && (at & 1) == 0) {
-                    c = *reinterpret_cast<const double2 *>(a.Cm + at);
-                    sn = *reinterpret_cast<const double2 *>(a.Sm + at);
-                } else {
-                    if (s < a.S) {
-                        c.x = a.Cm[at];
-                        sn.x = a.Sm[at];
-                    }
-                    if (s + 1 < a.S) {
-                        c.y = a.Cm[at + 1];
-                        sn.y = a.Sm[at + 1];
-                    }
-                }
-            }
-            rc[p] = c;
-            rs[p] = sn;
-        }
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -207,13 +176,6 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             sGe[at] = ev;
             sGo[at] = od;
         }
-#pragma unroll
-        for (int p = 0; p < (FLY ? 0 : B_PER); ++p) {
-            const int e = (tid + p * NT) * 2;
-            const int at = (e / BN) * LDBS + e % BN;
-            *reinterpret_cast<double2 *>(&sC[at]) = rc[p];
-            *reinterpret_cast<double2 *>(&sS[at]) = rs[p];
-        }
     };
 
     acc_t pcr[TM][TN], pci[TM][TN], psr[TM][TN], psi[TM][TN];
@@ -227,7 +189,7 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             psi[i][j] = (acc_t){0, 0, 0, 0};
         }
 
-    // FLY: the cos/sin operand never touches LDS.  Lane (fk, frow) needs, for each of its TN
+    // The cos/sin operand never touches LDS.  Lane (fk, frow) needs, for each of its TN
     // direction columns, the entries at t = t0 + 4 q + fk: successive s-steps are a rotation
     // by the fixed angle 4 kappa dy v_s, so each lane carries (cos, sin) per column, rotates it
     // after every s-step, and re-seeds it from the exact table every RESEED samples (rounding
@@ -243,33 +205,29 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             seed_s[j] = (CT)(ok ? a.Sm[(int64_t)t * a.S + s] : 0.0);
         }
     };
-    if (FLY) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int s = s0 + (wn * TN + j) * 16 + frow;
-            r4c[j] = (CT)(s < a.S ? a.R4c[s] : 1.0);
-            r4s[j] = (CT)(s < a.S ? a.R4s[s] : 0.0);
-        }
-        load_seed(t_begin);
+    for (int j = 0; j < TN; ++j) {
+        const int s = s0 + (wn * TN + j) * 16 + frow;
+        r4c[j] = (CT)(s < a.S ? a.R4c[s] : 1.0);
+        r4s[j] = (CT)(s < a.S ? a.R4s[s] : 0.0);
     }
+    load_seed(t_begin);
 
-    const bool wave_has_columns = s0 + wn * TN * 16 < a.S && !a.debug_skip;   // wave-uniform
+    const bool wave_has_columns = s0 + wn * TN * 16 < a.S;   // wave-uniform
     load_tile(t_begin);
     for (int t0 = t_begin; t0 < t_end; t0 += BKT) {
         __syncthreads();
         store_tile();
         __syncthreads();
         if (t0 + BKT < t_end) load_tile(t0 + BKT);
-        if (FLY) {
-            if (t0 % RESEED == 0 || t0 == t_begin) {
+        if (t0 % RESEED == 0 || t0 == t_begin) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    bc[j] = seed_c[j];
-                    bs[j] = seed_s[j];
-                }
+            for (int j = 0; j < TN; ++j) {
+                bc[j] = seed_c[j];
+                bs[j] = seed_s[j];
             }
-            if ((t0 + BKT) % RESEED == 0 && t0 + BKT < t_end) load_seed(t0 + BKT);
         }
+        if ((t0 + BKT) % RESEED == 0 && t0 + BKT < t_end) load_seed(t0 + BKT);
         // a wave whose direction columns all lie beyond S (the ragged last column tile) only
         // helps with the tile loads and barriers: its matrix-core slots go to the waves with
         // real columns
@@ -288,19 +246,13 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (FLY) {
-                    cc[j] = bc[j];
-                    ss[j] = bs[j];
-                    // advance t by 4: angle decreases by 4 kappa dy v_s
-                    const CT nc = fma(bc[j], r4c[j], bs[j] * r4s[j]);
-                    const CT ns = fma(bs[j], r4c[j], -bc[j] * r4s[j]);
-                    bc[j] = nc;
-                    bs[j] = ns;
-                } else {
-                    const int at = (s * 4 + fk) * LDBS + (wn * TN + j) * 16 + frow;
-                    cc[j] = (CT)sC[at];
-                    ss[j] = (CT)sS[at];
-                }
+                cc[j] = bc[j];
+                ss[j] = bs[j];
+                // advance t by 4: angle decreases by 4 kappa dy v_s
+                const CT nc = fma(bc[j], r4c[j], bs[j] * r4s[j]);
+                const CT ns = fma(bs[j], r4c[j], -bc[j] * r4s[j]);
+                bc[j] = nc;
+                bs[j] = ns;
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -365,17 +317,14 @@ __global__ __launch_bounds__(WM *WN * 64, MINB) void zfold_kernel(const FoldArgs
 }
 
 
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT>
-static int launch_fold_io(hipStream_t stream, FoldArgs &a, int ksplit);
-
-template <int BM, int BN, int WM, int WN, int UNR = 4, bool FLY = false, int BKT = 16, int MINB = 2,
-          typename CT = double, bool IN_SUM = false, bool OUT_T = false>
+template <int BM, int BN, int WM, int WN, int UNR, int BKT, int MINB, typename CT, bool IN_SUM,
+          bool OUT_T>
 static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.S + BN - 1) / BN;
     const int tiles = a.tiles_m * a.tiles_n;
     a.chunk = (tiles + 7) / 8;
-    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, IN_SUM, OUT_T>),
+    hipLaunchKernelGGL((zfold_kernel<BM, BN, WM, WN, UNR, BKT, MINB, CT, IN_SUM, OUT_T>),
                        dim3(a.chunk * 8, ksplit),
                        dim3(WM * WN * 64), 0,
                        stream, a);
@@ -385,13 +334,13 @@ static int launch_fold(hipStream_t stream, FoldArgs &a, int ksplit) {
 
 // the production tiles come in three I/O flavours: plain, slab-summing input (stage 2 fed with
 // stage 1's split-K slabs), transposed output (stage 1 feeding the folded stage 2)
-template <int BM, int BN, int WM, int WN, int UNR, bool FLY, int BKT, int MINB, typename CT>
+template <int BM, int BN, int WM, int WN, int UNR, int BKT, int MINB, typename CT>
 static int launch_fold_io(hipStream_t stream, FoldArgs &a, int ksplit) {
     if (a.out_t_rows > 0)
-        return launch_fold<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, false, true>(stream, a, ksplit);
+        return launch_fold<BM, BN, WM, WN, UNR, BKT, MINB, CT, false, true>(stream, a, ksplit);
     if (a.in_slabs > 1)
-        return launch_fold<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, true, false>(stream, a, ksplit);
-    return launch_fold<BM, BN, WM, WN, UNR, FLY, BKT, MINB, CT, false, false>(stream, a, ksplit);
+        return launch_fold<BM, BN, WM, WN, UNR, BKT, MINB, CT, true, false>(stream, a, ksplit);
+    return launch_fold<BM, BN, WM, WN, UNR, BKT, MINB, CT, false, false>(stream, a, ksplit);
 }
 
 int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda, const double *Cm,
@@ -403,8 +352,6 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.in_slab_stride = io.in_slab_stride;
     a.out_t_rows = io.out_t_rows;
     a.out_E = reinterpret_cast<const double2 *>(io.out_E);
-    static const int skip_mfma = getenv("ML_ZFOLD_SKIP_MFMA") ? atoi(getenv("ML_ZFOLD_SKIP_MFMA")) : 0;
-    a.debug_skip = skip_mfma;   // diagnostic only: time the kernel's memory skeleton
     a.A = reinterpret_cast<const double2 *>(A);
     a.lda = lda;
     a.M = M;
@@ -427,46 +374,28 @@ int zfold_stage1(hipStream_t stream, int M, int ny, const double *A, int64_t lda
     a.t_chunk = ((T + ksplit - 1) / ksplit + 63) / 64 * 64;
     ksplit = (T + a.t_chunk - 1) / a.t_chunk;
     a.split_stride = split_stride;
-    static const int forced = [] {
-        const char *e = getenv("ML_ZFOLD_TILE");
-        return e ? atoi(e) : -1;
-    }();
     // Measured (tools/zfold_shape_sweep.py, bench.py): 128 half-directions per tile read the
     // aperture fewer times (once when S <= 128); 8 waves per workgroup at 4 waves per SIMD beat 4
     // waves at 2 by 6-9 %; with the (re, im)-packed LDS planes a wave tile of 32 rows x 16
     // half-directions (1 x 8 waves: 4 wide LDS reads + 4 rotation instructions per 8 MFMAs) beats
     // 16 x 32 (2 x 4 waves: 2 + 8) by 7 % (fp64) / 9 % (fp32).  Take it whenever tiles x split-K
     // slabs give ~2 workgroups per CU, else 64-wide tiles of 4 waves (the folded stage 2: few
-    // rows, long reduction).  The on-the-fly-rotation variants are 2-5 % faster than the table
-    // variants (8, 9).  Tried and slower: 256-wide tiles of 16 waves, 64-row tiles at 2 waves per
-    // SIMD, deeper unrolling.
+    // rows, long reduction).  Tried and slower: cos/sin tables through LDS,
+    // 256-wide tiles of 16 waves, 64-row tiles at 2 waves per SIMD, deeper unrolling.
     const long wide = (long)((M + 31) / 32) * ((S + 127) / 128) * ksplit;
-    static const int pick_wide = getenv("ML_ZFOLD_PICK_WIDE") ? atoi(getenv("ML_ZFOLD_PICK_WIDE")) : 50;
-    static const int pick_small = getenv("ML_ZFOLD_PICK_SMALL") ? atoi(getenv("ML_ZFOLD_PICK_SMALL")) : 31;
-    int pick = wide >= 480 ? pick_wide : pick_small;
-    if (forced >= 0) pick = forced;
-    if (f32) {
-        static const int f32_wide = getenv("ML_ZFOLD_F32_WIDE") ? atoi(getenv("ML_ZFOLD_F32_WIDE")) : 141;
-        static const int f32_small = getenv("ML_ZFOLD_F32_SMALL") ? atoi(getenv("ML_ZFOLD_F32_SMALL")) : 132;
-        switch (wide >= 480 ? f32_wide : f32_small) {
-            case 131: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, float>(stream, a, ksplit);
-            case 132: return launch_fold_io<32, 64, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
-            case 141: return launch_fold_io<32, 128, 1, 8, 1, true, 32, 4, float>(stream, a, ksplit);
-            default: return launch_fold_io<32, 128, 2, 4, 1, true, 32, 4, float>(stream, a, ksplit);
-        }
-    }
-    const bool special_io = a.out_t_rows > 0 || a.in_slabs > 1;
-    if (special_io && pick != 31 && pick != 40 && pick != 51) pick = 50;   // only these have the I/O flavours
-    switch (pick) {
-        // 8, 9: the cos/sin operand read from tables through LDS (kept as the comparison for the
-        // on-the-fly operand); 31 / 50: the production shapes; 40 (default case), 51: shapes they replaced
-        case 8: return launch_fold<32, 64, 2, 2, 1>(stream, a, ksplit);
-        case 9: return launch_fold<32, 128, 2, 2, 2>(stream, a, ksplit);
-        case 31: return launch_fold_io<32, 64, 2, 2, 2, true, 32, 2, double>(stream, a, ksplit);
-        case 50: return launch_fold_io<32, 128, 1, 8, 1, true, 32, 4, double>(stream, a, ksplit);
-        case 51: return launch_fold_io<32, 64, 1, 4, 2, true, 32, 2, double>(stream, a, ksplit);
-        default: return launch_fold_io<32, 128, 2, 4, 1, true, 32, 4, double>(stream, a, ksplit);
-    }
+    const bool take_wide = wide >= 480;
+#ifdef ML_DIAG   // shape sweeps: ML_ZFOLD_TILE = 31 | 50 | 40 | 51 forces a shape (fp64)
+    const int forced = diag_int("ML_ZFOLD_TILE", -1);
+    if (!f32 && forced == 40) return launch_fold_io<32, 128, 2, 4, 1, 32, 4, double>(stream, a, ksplit);
+    if (!f32 && forced == 51) return launch_fold_io<32, 64, 1, 4, 2, 32, 2, double>(stream, a, ksplit);
+    if (!f32 && forced == 31) return launch_fold_io<32, 64, 2, 2, 2, 32, 2, double>(stream, a, ksplit);
+    if (!f32 && forced == 50) return launch_fold_io<32, 128, 1, 8, 1, 32, 4, double>(stream, a, ksplit);
+#endif
+    if (f32)
+        return take_wide ? launch_fold_io<32, 128, 1, 8, 1, 32, 4, float>(stream, a, ksplit)
+                         : launch_fold_io<32, 64, 2, 4, 1, 32, 4, float>(stream, a, ksplit);
+    return take_wide ? launch_fold_io<32, 128, 1, 8, 1, 32, 4, double>(stream, a, ksplit)
+                     : launch_fold_io<32, 64, 2, 2, 2, 32, 2, double>(stream, a, ksplit);
 }
 
 int zfold_splits(int T, int ksplit) {

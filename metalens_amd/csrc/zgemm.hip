@@ -22,8 +22,6 @@
 //   current one is multiplied; several workgroups per CU cover the barrier bubbles
 // The fp64 MFMA issues once per 64 cycles per SIMD (2048 flop), so LDS and L2 traffic are far
 // from limiting: per 16 MFMAs a wave issues 10 ds_read_b64.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace ml {
@@ -225,10 +223,7 @@ static int launch(hipStream_t stream, ZArgs &a, int batch) {
 // take 32x32 tiles so that the grid still covers the 256 CUs; ML_ZGEMM_TILE=<id> forces a
 // configuration (tuning / tests).
 static int pick_tile(int M, int N, int batch) {
-    static const int forced = [] {
-        const char *e = getenv("ML_ZGEMM_TILE");
-        return e ? atoi(e) : -1;
-    }();
+    static const int forced = diag_int("ML_ZGEMM_TILE", -1);
     if (forced >= 0) return forced;
     // measured on MI355X (tools/zgemm_sweep.py): the 3M variants win everywhere; 128x64 tiles
     // with 8 waves are best as soon as they give one workgroup per CU
@@ -260,18 +255,20 @@ int zgemm(hipStream_t stream, int M, int N, int K, const double *alpha, const do
     for (int k = 0; k < 4; ++k) a.alpha[k] = alpha[k < batch ? k : 0];
     a.accumulate = accumulate;
     switch (pick_tile(M, N, batch)) {
+        case 11: return launch<32, 32, 2, 2, true>(stream, a, batch);
+        case 15: return launch<128, 64, 4, 2, true>(stream, a, batch);
+#ifdef ML_DIAG   // shapes and the 4-product form the sweeps compared them with (tools/zgemm_sweep.py)
         case 1: return launch<32, 32, 2, 2>(stream, a, batch);
         case 2: return launch<128, 64, 2, 2>(stream, a, batch);
         case 3: return launch<64, 128, 2, 2>(stream, a, batch);
         case 4: return launch<128, 128, 2, 2>(stream, a, batch);
         case 5: return launch<128, 64, 4, 2>(stream, a, batch);
         case 6: return launch<128, 128, 4, 2>(stream, a, batch);
-        case 10: return launch<64, 64, 2, 2, true>(stream, a, batch);
-        case 11: return launch<32, 32, 2, 2, true>(stream, a, batch);
-        case 15: return launch<128, 64, 4, 2, true>(stream, a, batch);
         case 16: return launch<128, 128, 4, 2, true>(stream, a, batch);
         case 12: return launch<128, 64, 2, 2, true>(stream, a, batch);
-        default: return launch<64, 64, 2, 2>(stream, a, batch);
+        case 0: return launch<64, 64, 2, 2>(stream, a, batch);
+#endif
+        default: return launch<64, 64, 2, 2, true>(stream, a, batch);   // tile id 10
     }
 }
 

@@ -140,14 +140,19 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
     max_v = 64
     viol = (_lib.BoundViolation * max_v)()
     n_viol = _lib.c_int(0)
+    known = None
     for attempt in range(3):
         _lib.check(ctx.lib.ml_nearfield(ctx.handle, _lib.byref(p), _lib.dptr(xs), xs.size,
                                         _lib.dptr(ys), ys.size, _lib.byref(power), viol, max_v,
                                         _lib.byref(n_viol)))
         # samples exactly equidistant from two centre cells: the reference's choice is
         # cKDTree's (nearfield.py:363-364); ask it about those samples and run again
-        if ties.settle(ctx, lens_center_summary, xs, ys) is None:
+        known = ties.settle(ctx, lens_center_summary, xs, ys, known)
+        if known is None:
             break
+    else:
+        raise _lib.MetalensHipError('nearest-cell ties were still being reported after three '
+                                    'passes (%d samples)' % ties.pending(ctx).size)
     if n_viol.value:
         _raise_violation(viol[0], ctx)
     power_passing_through_lens = power.value * (x_pts[1] - x_pts[0]) * (y_pts[1] - y_pts[0])

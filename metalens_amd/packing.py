@@ -153,10 +153,15 @@ def pack_layout(lens_periphery_summary, lens_center_summary):
 
 def upload_layout(ctx, lens_periphery_summary, lens_center_summary):
     L = pack_layout(lens_periphery_summary, lens_center_summary)
-    token = ('layout', L['boundaries'].tobytes(), L['period'].tobytes(), L['dphi'].tobytes(),
-             L['ring_gc'].tobytes(), L['cells'].shape,
-             float(L['cells'].sum()) if L['cells'].size else 0.0,
-             float((L['cells'] * np.arange(1, 4)).sum()) if L['cells'].size else 0.0)
+    # content hash over EVERY packed array, like the tables: a cheaper checksum (shape + sums)
+    # cannot see a re-ordered cell list or a swap of two cell types, and tie answers
+    # (ties.py) are row indices into exactly this cell order
+    h = hashlib.blake2b(digest_size=16)
+    for key in ('boundaries', 'r_center', 'period', 'dphi', 'lateral', 'ring_gc', 'cells'):
+        a = np.ascontiguousarray(L[key])
+        h.update(key.encode() + str(a.shape).encode())
+        h.update(a.tobytes())
+    token = ('layout', h.digest())
     if ctx.layout_token == token:
         return
     n_rings = L['r_center'].size

@@ -15,6 +15,16 @@ from .grating import n_glass as tabulated_n_glass
 from .nearfield import _check_axis, _raise_violation, nearfield_params
 
 
+def _check_source(source):
+    """the reference's assertions on a source (nearfield.py:84-85,224): below the lens, polarised
+    along x, y or z, and no z-polarised plane wave"""
+    source_x, source_y, source_z, source_pol = source
+    assert source_z < 0 and source_pol in ('x', 'y', 'z')
+    if source_z == -float('inf'):
+        assert source_pol != 'z'
+    return source_x, source_y, source_z, source_pol
+
+
 class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
@@ -29,15 +39,14 @@ class HotPath:
         # ml_nearfield_premodulate); host downloads of the fields are un-modulated first
         self.fuse_modulation = bool(fuse_modulation)
         self.ctx = ctx or _lib.default_context()
-        if precision is not None:   # 'f64' | 'f32': arithmetic of the far-field GEMMs
-            self.ctx.set_precision(precision)
-        if method is not None:      # 'auto' | 'gemm': see _lib.Context.set_method
-            self.ctx.set_method(method)
+        # both are properties of the context that later plans inherit: set them on every
+        # construction so that an earlier HotPath(precision='f32') cannot leak into this one
+        self.ctx.set_precision(precision or 'f64')   # 'f64' | 'f32': arithmetic of the GEMMs
+        self.ctx.set_method(method or 'auto')        # 'auto' | 'gemm': _lib.Context.set_method
         self.rank, self.world = rank, world
         self.c0 = constants.c0 if c0 is None else c0
         self.Z0 = constants.Z0 if Z0 is None else Z0
-        source_x, source_y, source_z, source_pol = source
-        assert source_z < 0 and source_pol in ('x', 'y', 'z')
+        source_x, source_y, source_z, source_pol = _check_source(source)
         _check_axis(x_pts, wavelength)
         _check_axis(y_pts, wavelength)
         S = lens_periphery_summary
@@ -54,9 +63,13 @@ class HotPath:
                                        n_glass, dipole_moment, self.c0, self.Z0)
         self.x_all = _lib.f64(x_pts)
         self.y = _lib.f64(y_pts)
+        self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
+        self.pair_list = bool(pair_list)
         # rows of this rank: mirrored row pairs when the aperture has an even number of rows
-        # (both far-field stages fold), one contiguous block otherwise
-        self.mirrored = world > 1 and self.x_all.size % 2 == 0
+        # (both far-field stages fold), one contiguous block otherwise (pair lists have no
+        # folded form: csrc/farfield.hip rejects mirrored shards for them)
+        self.mirrored = world > 1 and not self.pair_list and self.x_all.size % 2 == 0
+        self._shard_weights = None
         if self.mirrored:
             # rows through the centre disc cost more near-field time (nearest-cell search, more
             # scattered table gathers); the GEMM cost per row is uniform.  Measured per-row totals
@@ -67,6 +80,7 @@ class HotPath:
             chord = 2 * np.sqrt(np.maximum(r_c ** 2 - xs ** 2, 0.0))
             span = float(self.y[-1] - self.y[0]) or 1.0
             weights = 1.0 + 0.13 * np.minimum(chord / span, 1.0)
+            self._shard_weights = weights
             self.row0, self.row1 = dist.mirrored_block(self.x_all.size, world, rank,
                                                        weights=weights)
             self.rows = dist.mirrored_rows(self.x_all.size, self.row0, self.row1)
@@ -74,18 +88,29 @@ class HotPath:
             self.row0, self.row1 = dist.row_block(self.x_all.size, world, rank)
             self.rows = np.arange(self.row0, self.row1)
         self.x_local = np.ascontiguousarray(self.x_all[self.rows])
-        self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
-        self.pair_list = bool(pair_list)
+        # an empty shard would leave this rank without radiation vectors while the others wait
+        # for it inside the all-reduce: refuse identically on every rank instead
+        if world > 1:
+            smallest = min(len(r) for r in (self._rows_of(k) for k in range(world)))
+            if smallest == 0:
+                raise ValueError('%d aperture rows cannot be sharded over %d ranks: a rank would '
+                                 'hold no rows' % (self.x_all.size, world))
         self.shape = (self.ux.size,) if pair_list else (self.ux.size, self.uy.size)
         self.dxp = x_pts[1] - x_pts[0]
         self.dyp = y_pts[1] - y_pts[0]
 
+    def _rows_of(self, rank):
+        """aperture rows rank ``rank`` owns under this object's partition"""
+        n = self.x_all.size
+        if self.mirrored:
+            q0, q1 = dist.mirrored_block(n, self.world, rank, weights=self._shard_weights)
+            return dist.mirrored_rows(n, q0, q1)
+        r0, r1 = dist.row_block(n, self.world, rank)
+        return np.arange(r0, r1)
+
     def set_source(self, source):
         """switch to another dipole / plane-wave source; tables, layout and grids stay resident"""
-        source_x, source_y, source_z, source_pol = source
-        assert source_z < 0 and source_pol in ('x', 'y', 'z')
-        if source_z == -float('inf'):
-            assert source_pol != 'z'
+        source_x, source_y, source_z, source_pol = _check_source(source)
         self.params = nearfield_params(source_x, source_y, source_z, source_pol, self.wavelength,
                                        self.n_glass, self.dipole_moment, self.c0, self.Z0)
 
@@ -171,62 +196,3 @@ class HotPath:
         local_power = power.value * self.dxp * self.dyp
         return {'P': P, 'a_theta': a_theta, 'a_phi': a_phi, 'Nx': vec[0], 'Ny': vec[1],
                 'Lx': vec[2], 'Ly': vec[3], 'power_local_rows': local_power}
-
-
-class HotPath2Stream:
-    """The same pass with the aperture rows of this rank split over TWO contexts (= two HIP
-    streams) on one GPU: while one half is in the matrix-core-bound GEMMs the other half's
-    near-field synthesis (latency / issue-bound, matrix cores idle) runs beside it.  The halves
-    are mirrored row-pair shards, exactly as two ranks would own them; the second half's
-    radiation vectors are added into the first's on the device (``ml_farfield_add_vectors``,
-    ordered by events) before the projection.  Single-GPU use only (world == 1)."""
-
-    def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
-                 hexgridset, x_pts, y_pts, ux, uy, ctx=None, precision=None, **kw):
-        self.ctx = ctx or _lib.default_context()
-        self.ctx_b = _lib.Context(self.ctx.device)
-        common = dict(kw)
-        self.a = HotPath(source, wavelength, lens_periphery_summary, lens_center_summary,
-                         hexgridset, x_pts, y_pts, ux, uy, ctx=self.ctx, rank=0, world=2,
-                         precision=precision, **common)
-        self.b = HotPath(source, wavelength, lens_periphery_summary, lens_center_summary,
-                         hexgridset, x_pts, y_pts, ux, uy, ctx=self.ctx_b, rank=1, world=2,
-                         precision=precision, **common)
-        self.Z0 = self.a.Z0
-        self.n_glass = self.a.n_glass
-        self.x_local = self.a.x_all          # all rows are resident on this GPU
-        self.shape = self.a.shape
-
-    def set_source(self, source):
-        self.a.set_source(source)
-        self.b.set_source(source)
-
-    def step(self):
-        lib = self.ctx.lib
-        self.a.step_local()
-        self.b.step_local()
-        _lib.check(lib.ml_farfield_add_vectors(self.ctx.handle, self.ctx_b.handle))
-        _lib.check(lib.ml_farfield_project_async(self.ctx.handle, self.Z0))
-
-    def sync(self):
-        self.ctx_b.sync()
-        self.ctx.sync()
-
-    def results(self):
-        tied_a, tied_b = self.a.settle_ties(), self.b.settle_ties()
-        if tied_a or tied_b:
-            self.step()
-            self.sync()
-        out = self.a._fetch()
-        power_b = _lib.c_double(0)
-        viol = (_lib.BoundViolation * 8)()
-        n_viol = _lib.c_int(0)
-        _lib.check(self.ctx_b.lib.ml_nearfield_result(self.ctx_b.handle, _lib.byref(power_b), viol,
-                                                      8, _lib.byref(n_viol)))
-        if n_viol.value:
-            _raise_violation(viol[0], self.ctx_b)
-        out['power_local_rows'] += power_b.value * self.a.dxp * self.a.dyp
-        return out
-
-    def close(self):
-        self.ctx_b.close()
