@@ -255,6 +255,11 @@ struct ml_ctx {
     // settle, and the host's answers for the current (grid, layout)
     ml::DevBuf tie_count, tie_list, ovr_key, ovr_slot;
     int n_ovr = 0;
+    long ovr_serial = 0;                    // bumped whenever the override list changes
+    // per-sample geometry records (nearfield_fast.hip) and what they were built for:
+    // (grid_serial, layout_serial, ovr_serial, samples)
+    ml::DevBuf geo_ab, geo_ix;
+    long geo_key[4] = {-1, -1, -1, -1};
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores

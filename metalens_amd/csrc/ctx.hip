@@ -424,7 +424,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
                       &ctx->cell_lattice_map, &ctx->cell_lattice_rec, &ctx->tie_count, &ctx->tie_list,
-                      &ctx->ovr_key, &ctx->ovr_slot, &ctx->fields,
+                      &ctx->ovr_key, &ctx->ovr_slot, &ctx->geo_ab, &ctx->geo_ix, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->row_first, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
@@ -711,15 +711,18 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     }
     ML_TRY(ctx->row_first.reserve((size_t)nx * sizeof(int)));
     ctx->row_first_valid = true;
-    // nearest-cell ties: the record of this launch starts empty; answers for another geometry
-    // are dropped
-    // (two counters, used alternately like the violation halves: a launch clears the other one)
+    // nearest-cell ties: answers for another geometry are dropped
     if (!ctx->tie_count.p) {
         ML_TRY(ctx->tie_count.reserve(2 * sizeof(int)));
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, 2 * sizeof(int), ctx->stream));
     }
     ML_TRY(ctx->tie_list.reserve((size_t)ML_TIE_CAPACITY * sizeof(long long)));
-    if (ctx->ovr_for[0] != ctx->grid_serial || ctx->ovr_for[1] != ctx->layout_serial) ctx->n_ovr = 0;
+    if (ctx->n_ovr && (ctx->ovr_for[0] != ctx->grid_serial || ctx->ovr_for[1] != ctx->layout_serial)) {
+        ctx->n_ovr = 0;
+        ++ctx->ovr_serial;
+    }
+    ML_TRY(ctx->geo_ab.reserve(plane * 2 * sizeof(double)));
+    ML_TRY(ctx->geo_ix.reserve(plane * 2 * sizeof(int)));
     return nearfield_launch(ctx, p, nx, ny);
 }
 
@@ -744,7 +747,7 @@ int ml_nearfield_ties(ml_ctx *ctx, int64_t *sample_ids, int max_ids, int *n_ties
     }
     ML_HIP(hipSetDevice(ctx->device));
     int count = 0;
-    ML_HIP(hipMemcpyAsync(&count, ctx->tie_count.as<int>() + ctx->viol_half, sizeof count,
+    ML_HIP(hipMemcpyAsync(&count, ctx->tie_count.as<int>(), sizeof count,
                           hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     *n_ties = count;
@@ -780,6 +783,7 @@ int ml_nearfield_tie_answers(ml_ctx *ctx, const int64_t *sample_ids, const int32
         ML_HIP(hipStreamSynchronize(ctx->stream));   // the staging vectors go out of scope
     }
     ctx->n_ovr = n;
+    ++ctx->ovr_serial;
     ctx->ovr_for[0] = ctx->grid_serial;
     ctx->ovr_for[1] = ctx->layout_serial;
     return ML_OK;

@@ -19,6 +19,10 @@
 
 namespace ml {
 
+#ifndef NF_MODE_DEFAULT
+#define NF_MODE_DEFAULT 0
+#endif
+
 // Per aperture row: how far from the row's two ends the first sample inside the lens is,
 // min(j, ny-1-j).  Samples outside the lens are exactly zero, so the far-field GEMM skips that
 // outer part of each row (zfold.hip).  Inside-the-lens is the kernels' own test
@@ -115,8 +119,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.inv_bh = 1.0 / ctx->bin_h;
     a.lat_map = ctx->lat_ok ? ctx->cell_lattice_map.as<int>() : nullptr;
     a.lat_rec = ctx->lat_ok ? ctx->cell_lattice_rec.as<CellRec>() : nullptr;
-    a.tie_count = ctx->tie_count.as<int>() + ctx->viol_half;
-    a.tie_count_next = ctx->tie_count.as<int>() + (1 - ctx->viol_half);
+    a.tie_count = ctx->tie_count.as<int>();
     a.tie_list = ctx->tie_list.as<long long>();
     a.tie_cap = ML_TIE_CAPACITY;
     a.ovr_key = ctx->ovr_key.as<long long>();
@@ -138,6 +141,8 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     a.ring_tab_off = ctx->ring_tab_off.as<long long>();
     a.ring_ok = ctx->ring_ok.as<double>();
     a.ring_ok_off = ctx->ring_ok_off.as<int>();
+    a.geo_ab = ctx->geo_ab.as<double2>();
+    a.geo_ix = ctx->geo_ix.as<int2>();
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
     a.row_first = ctx->row_first.as<int>();
@@ -164,6 +169,19 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
         hipLaunchKernelGGL(row_extent_kernel, dim3((nx + 255) / 256), dim3(256), 0, ctx->stream, a);
         ctx->row_first_key[0] = ctx->grid_serial;
         ctx->row_first_key[1] = ctx->layout_serial;
+    }
+    // the per-sample records depend on the grid, the layout and the tie answers: rebuilt when one
+    // of them changes (the samples the kernel cannot settle are counted from zero each time)
+    const long geo_key[4] = {ctx->grid_serial, ctx->layout_serial, ctx->ovr_serial, (long)nx * ny};
+    static const int nf_mode = diag_int("ML_NF_MODE", NF_MODE_DEFAULT);   // 0 records, 1 fused
+    if (nf_mode == 1) {
+        a.geo_ix = nullptr;
+        ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
+    } else if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
+        ProfScope scope(ctx, ML_K_TWIDDLE);
+        ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
+        ML_TRY(nearfield_geometry_launch(ctx, a));
+        memcpy(ctx->geo_key, geo_key, sizeof geo_key);
     }
     {
         ProfScope scope(ctx, ML_K_NEARFIELD);

@@ -41,7 +41,7 @@ struct NfArgs {
     // count).  The reference takes whichever cell scipy's cKDTree meets first, which only scipy
     // can tell: the kernel records such samples (tie_list, up to tie_cap) and, once the host has
     // asked cKDTree about them, finds the answer in the sorted override list.
-    int *tie_count, *tie_count_next;   // this launch's counter; the next one's (cleared here)
+    int *tie_count;   // samples the geometry kernel could not settle (zeroed before its launch)
     long long *tie_list;
     int tie_cap;
     const long long *ovr_key;   // sorted sample ids (row * ny + column)
@@ -69,6 +69,9 @@ struct NfArgs {
     const long long *ring_tab_off;
     const double *ring_ok;
     const int *ring_ok_off;
+    // per-sample geometry records (nearfield_fast.hip, kernel 1 writes, kernel 2 reads)
+    double2 *geo_ab;   // [nx][ny]
+    int2 *geo_ix;      // [nx][ny]
     // outputs
     double *fields;
     double *partial_power;
@@ -364,13 +367,11 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
 }
 
 // incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream
-__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here) {
+__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int by) {
     for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
-    if (threadIdx.x == 0) a.partial_power[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = power_here;
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0) a.partial_power[(size_t)by * gridDim.x + blockIdx.x] = power_here;
+    if (blockIdx.x == 0 && by == 0)
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
-        if (threadIdx.x == 0) *a.tie_count_next = 0;
-    }
 }
 
 __device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 Ex, c2 Ey, c2 Hx,
@@ -388,5 +389,7 @@ __device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 E
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a);
 // writes the number of per-block power partials it produces to *n_partials
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
+// the source-independent records of the current (grid, layout, tie answers)
+int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a);
 
 }  // namespace ml

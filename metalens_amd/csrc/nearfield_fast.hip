@@ -19,6 +19,8 @@
 //       Ex += Z0 g (kx ky U_fy + (ky^2+kz^2) U_fx) ph ; Ey += Z0 g (-(kx^2+kz^2) U_fy - kx ky U_fx) ph
 //     with g = 1/(k_glass kz n_glass)  (nearfield.py:313-327 rearranged);
 //   * use one reciprocal per sample and a branch-free Cody-Waite sin/cos.
+#include <algorithm>
+
 #include "nearfield_dev.h"
 
 namespace ml {
@@ -230,51 +232,167 @@ __device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int 
     acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
 }
 
-// Diagnostic build (-DML_PHASE_TIMERS, see the Makefile and tools/nearfield_phase_timers.py):
-// every wave stamps s_memtime at fixed points; `dep` is a value that must have arrived by then.
-#ifdef ML_PHASE_TIMERS
-constexpr int PHASE_SLOTS = 16, PHASE_WAVES = 1 << 18;
-__device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
-#define ML_MARK(k, dep)                                   \
-    do {                                                  \
-        asm volatile("" ::"v"(dep));                      \
-        __builtin_amdgcn_sched_barrier(0);                \
-        stamp[k] = __builtin_amdgcn_s_memtime();          \
-        __builtin_amdgcn_sched_barrier(0);                \
-    } while (0)
-#else
-#define ML_MARK(k, dep)
-#endif
+// The same with the node values taken from a block staged in LDS: blk[(node c) * 4 + amplitude q],
+// c = 2 * (i0 step) + (i1 step) (see the staging in nearfield_field_kernel)
+__device__ __forceinline__ void order_term_lds(Acc &acc, const double2 *blk, double t0, double t1,
+                                               double Hw_x, double Hw_y, double kx, double ky,
+                                               double kz2, double k_glass, double inv_n, double Z0,
+                                               double arg) {
+    const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
+    double ufy_r = 0, ufy_i = 0, ufx_r = 0, ufx_i = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double2 xfy = blk[c * 4 + 0], xfx = blk[c * 4 + 1], yfy = blk[c * 4 + 2],
+                      yfx = blk[c * 4 + 3];
+        const double wx = w[c] * Hw_x, wy = w[c] * Hw_y;
+        ufy_r = fma(wx, xfy.x, fma(wy, yfy.x, ufy_r));
+        ufy_i = fma(wx, xfy.y, fma(wy, yfy.y, ufy_i));
+        ufx_r = fma(wx, xfx.x, fma(wy, yfx.x, ufx_r));
+        ufx_i = fma(wx, xfx.y, fma(wy, yfx.y, ufx_i));
+    }
+    double sn, cs;
+    sincos_cw(arg, sn, cs);
+    const double vy_r = fma(ufy_r, cs, -ufy_i * sn), vy_i = fma(ufy_r, sn, ufy_i * cs);
+    const double vx_r = fma(ufx_r, cs, -ufx_i * sn), vx_i = fma(ufx_r, sn, ufx_i * cs);
+    acc.Hx.r += vy_r;
+    acc.Hx.i += vy_i;
+    acc.Hy.r += vx_r;
+    acc.Hy.i += vx_i;
+    const double g = Z0 * inv_n * recip(k_glass) * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
+    const double cxy = kx * ky * g, cxx = fma(ky, ky, kz2) * g, cyy = -fma(kx, kx, kz2) * g;
+    acc.Ex.r += fma(cxy, vy_r, cxx * vx_r);
+    acc.Ex.i += fma(cxy, vy_i, cxx * vx_i);
+    acc.Ey.r += fma(cyy, vy_r, -cxy * vx_r);
+    acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
+}
 
-// Every wave is its own workgroup - no barrier at the end (one power partial per wave), so a
-// wave's slot is free the moment it finishes and the waves of a SIMD drift out of phase instead of
-// starting, stalling and finishing together.  4 waves per SIMD (124 VGPRs): measured best.
-__global__ __launch_bounds__(64, 4) void nearfield_fast_kernel(const NfArgs a) {
-    constexpr int BW = 1;
-    // Thread -> sample map: each wave covers an 8 x 8 patch of the aperture (not a 64 x 1
-    // line), so its lanes fall into 2-3 rings instead of ~10 and the table gathers of one
-    // wave instruction touch few distinct cache lines (measured: -20 % at 4096^2).  The
-    // waves of a workgroup sit side by side along y: 8 rows x 8 BW columns per workgroup;
-    // stores are 128-byte row segments per plane.
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.y * 8 + (lane >> 3);               // x index
-    const int j = blockIdx.x * (8 * BW) + wave * 8 + (lane & 7);    // y index (fastest in memory)
+// ---- kernel 1 of 2: the source-INDEPENDENT decisions of every sample ---------------------------
+// Ring (nearfield.py:125-128), sector and rotated local coordinates (:169,200-201), nearest
+// centre cell (:363-367) depend on the sample grid and the layout only.  They are evaluated once
+// per (grid, layout, tie answers) into a 24-byte record per sample,
+//     geo_ab = (xp, yp)        periphery       geo_ix = (idx, index into the rotation table)
+//              (cell x, cell y) centre                   (0, cell type; -1: no cells)
+//                                                        (n_rings + 1, -) outside the lens
+// and every synthesis on that geometry - a sweep over sources, the steps of a benchmark - starts
+// from the records (kernel 2).  Same thread -> sample map as kernel 2 (8 x 8 patch per wave).
+// the decisions of one sample (see the geometry kernel below): idx, aux, (ga, gb)
+__device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, double y, long long sample_id,
+                                                int &idx, int &aux, double &ga, double &gb) {
+    const double r = sqrt(x * x + y * y);
+    idx = boundaries_below_fast(a, r);
+    ga = 0.0;
+    gb = 0.0;
+    aux = -1;
+    if (idx >= 1 && idx <= a.n_rings) {
+        const int ring = idx - 1;
+        const double dphi = a.dphi[ring], rcen = a.rc[ring];
+        const int rot_half = a.rot_half[ring], rot_center = a.rot_center[ring];
+        // sector decision: exact (nearfield.py:169)
+        const int sector = sector_of_fast(a, rot_half, rot_center, x, y, dphi, recip(dphi));
+        aux = rot_center + sector;
+        const double2 cs = a.rot_table[aux];
+        // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
+        ga = x * cs.x + y * cs.y - rcen;
+        gb = -x * cs.y + y * cs.x;
+    } else if (idx == 0 && a.n_cells > 0) {
+        // nearest cell: the lattice shortcut returns the cell itself from the node map (one
+        // load); anything it cannot settle goes through nearest_cell_fast
+        bool have_cell = false;
+        if (a.lat_rec) {
+            int ia, ib;
+            const int node = lattice_pick(a, x, y, ia, ib);
+            if (node >= 0) {
+                typedef double rec_t __attribute__((ext_vector_type(4)));
+                const rec_t q = *reinterpret_cast<const rec_t *>(a.lat_rec + node);
+                const double ex = x - q.x, ey = y - q.y;
+                if (ex * ex + ey * ey <= a.lat_accept_r2) {   // false for a NaN (empty) node
+                    ga = q.x;
+                    gb = q.y;
+                    aux = (int)(__double_as_longlong(q.z) & 0xffffffffll);
+                    have_cell = true;
+                }
+            }
+        }
+        if (!have_cell) {
+            const int s = nearest_cell_fast(a, x, y, sample_id);
+            const double2 cc = a.cxy[s];
+            ga = cc.x;
+            gb = cc.y;
+            aux = a.cwhich[s];
+        }
+        aux = max(aux, 0);   // a (never produced) negative cell type would read as "no cells"
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.y * 8 + (lane >> 3);
+    const int j = blockIdx.x * 8 + (lane & 7);
+    if (j >= a.ny || i >= a.nx) return;
+    const size_t at = (size_t)i * a.ny + j;
+    int idx, aux;
+    double ga, gb;
+    sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
+    a.geo_ab[at] = make_double2(ga, gb);
+    a.geo_ix[at] = make_int2(idx, aux);
+}
+
+// ---- kernel 2 of 2: fields from the records ----------------------------------------------------
+// Periphery tables through LDS.  A sample needs, per diffraction order, the 4 table nodes around
+// (uxp, uyp) x 4 amplitudes = 16 complex of its ring's table: gathered per lane that is 48
+// wave-wide 16-byte loads per sample (3 orders), and the vector memory path moves 64 B per clock
+// per CU whether or not the lanes ask for the same address - the kernel was bound by exactly that.
+// But the 64 samples of a wave (an 8 x 8 patch) fall into 2-4 rings and usually one table cell:
+// the wave finds its distinct (ring, cell) blocks, fetches each ONCE (one wave-wide load = the
+// 16 complex of 4 orders), parks them in LDS, and every lane then reads its block from LDS, where
+// equal addresses broadcast and a wave-wide 16-byte read costs 4 cycles instead of 16.
+constexpr int NF_SLOTS = 6;                  // distinct (ring, cell) blocks staged per round
+constexpr int NF_CHUNK = 4;                  // orders per staging pass (64 lanes = 4 x 4 x 4)
+constexpr int NF_PITCH = NF_CHUNK * 16 + 1;  // +1: blocks start in different 16-byte bank slots
+
+template <bool RECORDS>
+__global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) {
+    __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];
+    const int lane = threadIdx.x & 63;
     const ml_nearfield_params &p = a.p;
-    double power_here = 0.0;
-    Acc acc = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-#ifdef ML_PHASE_TIMERS
-    unsigned long long stamp[PHASE_SLOTS] = {0};
-    stamp[0] = __builtin_amdgcn_s_memtime();
-#endif
-    if (j < a.ny && i < a.nx) {
-        const double x = a.x_pts[i], y = a.y_pts[j];
-        const double r = sqrt(x * x + y * y);
-        const int idx = boundaries_below_fast(a, r);
-        ML_MARK(1, idx);
-        if (idx <= a.n_rings) {
+    const int by = blockIdx.y;
+    const int i = by * 8 + (lane >> 3);                       // x index
+    const int j = blockIdx.x * 8 + (lane & 7);                // y index (fastest in memory)
+    const bool inb = j < a.ny && i < a.nx;
+    const size_t at = (size_t)i * a.ny + j;
+    int idx = a.n_rings + 1, aux = -1;
+    double ga = 0.0, gb = 0.0;
+    if (inb) {
+        if (RECORDS) {
+            // both records at once (the second does not wait for the first)
+            const int2 ix = a.geo_ix[at];
+            const double2 ab = a.geo_ab[at];
+            idx = ix.x;
+            aux = ix.y;
+            ga = ab.x;
+            gb = ab.y;
+        } else {
+            sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
+        }
+    }
+    const bool lens = idx <= a.n_rings;
+    const bool peri = lens && idx >= 1;
+    const double inv_n = recip(p.n_glass);
+    // what the order loop of a periphery sample needs (everything else is re-read afterwards:
+    // registers are what limits this kernel to four waves per SIMD)
+    int key = -1, n_orders = 0, stride0 = 0, stride_o = 0;
+    double uxp = 0.0, uyp = 0.0, Hw_x = 0.0, Hw_y = 0.0, t0 = 0.0, t1 = 0.0;
+    const double *ok = a.ring_ok;
+    const double2 *node00 = a.ring_tab;
+    bool outside = false;
+    {
+        double power_here = 0.0;
+        double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 1.0, Hx_i = 0.0, Hy_i = 0.0;
+        if (lens) {
             // ---- incidence direction and incident field (amplitude-type arithmetic)
-            double ux = 0.0, uy = 0.0, uz = 1.0;
-            double Hx_i, Hy_i, Ex_i, Ey_i;
+            x = a.x_pts[i];
+            y = a.y_pts[j];
+            double Ex_i, Ey_i;
             if (p.plane_wave) {
                 Ex_i = p.pol[0] * p.dipole_moment;
                 Ey_i = p.pol[1] * p.dipole_moment;
@@ -294,157 +412,48 @@ __global__ __launch_bounds__(64, 4) void nearfield_fast_kernel(const NfArgs a) {
                 Ey_i = (Hz_i * ux - Hx_i * uz) * p.Z0;
             }
             power_here = Ex_i * Hy_i - Ey_i * Hx_i;
-            const double inv_n = recip(p.n_glass);
-            ML_MARK(2, power_here);
+        }
+        wave_power(a, power_here, by);
 
-            if (idx >= 1) {
-                // ================= periphery =================
-                const int ring = idx - 1;
-                // everything that depends on the ring alone is fetched here, in one batch (the
-                // compiler otherwise leaves each load next to its use, a chain of round trips)
-                const int slot = a.gc[ring];
-                const double dphi = a.dphi[ring], rcen = a.rc[ring], period = a.period[ring];
-                const int rot_half = a.rot_half[ring], rot_center = a.rot_center[ring];
-                const double *ok = a.ring_ok + a.ring_ok_off[ring];
-                const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
-                const TableDesc &T = a.tables[slot];
-                // ... and the table bounds in one batch as well: as a || chain they become six
-                // dependent loads with a wait after each
-                const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3],
-                             b4 = T.bounds[4], b5 = T.bounds[5];
-                // sector decision: exact (nearfield.py:169)
-                const int sector = sector_of_fast(a, rot_half, rot_center, x, y, dphi, recip(dphi));
-                const double2 cs = a.rot_table[rot_center + sector];
-                const double cosr = cs.x, sinr = cs.y;
-                ML_MARK(3, cosr);
-                // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
-                const double xp = x * cosr + y * sinr - rcen;
-                const double yp = -x * sinr + y * cosr;
-                const double uxp = fma(ux, cosr, uy * sinr), uyp = fma(uy, cosr, -ux * sinr);
-                const double Hw_y = fma(Hx_i, cosr, Hy_i * sinr);    // H along x' <-> y table
-                const double Hw_x = fma(Hy_i, cosr, -Hx_i * sinr);   // H along y' <-> x table
-                int i0, i1;
-                double t0, t1;
-                locate_uv(T, uxp, uyp, i0, t0, i1, t1);
-                const int stride1 = 4, stride0 = T.n1 * 4, stride_o = T.n0 * T.n1 * 4;
-                // the table-bound tests do not depend on the order: evaluate them once, and only
-                // take the reporting path (per order, in the reference's check order) on failure
-                const bool outside = (int)(uxp < b0) | (int)(uxp > b1) | (int)(uyp < b2) |
-                                     (int)(uyp > b3) | (int)(period < b4) | (int)(period > b5);
-                Acc pr = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-                ML_MARK(4, t0 + t1 + period);
-                for (int o = 0; o < T.n_orders; ++o) {
-                    const double kxp = fma(p.kvac, uxp, ok[2 * o]);
-                    const double kyp = fma(p.kvac, uyp, ok[2 * o + 1]);
-                    const double kt2 = fma(kxp, kxp, kyp * kyp);
-                    if (kt2 <= p.kvac2) {
-                        if (outside) check_bounds(a, T, slot, o, uxp, uyp, period, true);
-                        order_term(pr, tab + o * stride_o + i0 * stride0 + i1 * stride1, stride0,
-                                   stride1, 1, t0, t1, Hw_x, Hw_y, kxp, kyp, p.k_glass2 - kt2,
-                                   p.k_glass, inv_n, p.Z0, kxp * xp + kyp * yp);
-                    }
-                }
-                ML_MARK(5, pr.Ex.r + pr.Hy.i);
-                // input modulation of the far-field plan's stage 1, applied here for free (see
-                // NfArgs); loaded late so that it does not occupy registers through the order loop
-                c2 tilt = {1.0, 0.0};
-                if (a.premod) {
-                    const double2 t2 = a.premod[j];
-                    tilt = {t2.x, t2.y};
-                }
-                // phase-critical: propagation from the grating centre (nearfield.py:337-341)
-                if (!p.plane_wave) {
-                    const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
-                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
-                    double sn, cn;
-                    sincos_cw(p.kvac * air, sn, cn);
-                    c2 e = {cn, sn};
-                    if (a.premod) e = cmul(e, tilt);   // free ride: one more phasor product
-                    pr.Ex = cmul(pr.Ex, e);
-                    pr.Ey = cmul(pr.Ey, e);
-                    pr.Hx = cmul(pr.Hx, e);
-                    pr.Hy = cmul(pr.Hy, e);
-                } else if (a.premod) {
-                    pr.Ex = cmul(pr.Ex, tilt);
-                    pr.Ey = cmul(pr.Ey, tilt);
-                    pr.Hx = cmul(pr.Hx, tilt);
-                    pr.Hy = cmul(pr.Hy, tilt);
-                }
-                // back to the lab frame (nearfield.py:351-354)
-                acc.Ex = {fma(pr.Ex.r, cosr, -pr.Ey.r * sinr), fma(pr.Ex.i, cosr, -pr.Ey.i * sinr)};
-                acc.Ey = {fma(pr.Ex.r, sinr, pr.Ey.r * cosr), fma(pr.Ex.i, sinr, pr.Ey.i * cosr)};
-                acc.Hx = {fma(pr.Hx.r, cosr, -pr.Hy.r * sinr), fma(pr.Hx.i, cosr, -pr.Hy.i * sinr)};
-                acc.Hy = {fma(pr.Hx.r, sinr, pr.Hy.r * cosr), fma(pr.Hx.i, sinr, pr.Hy.i * cosr)};
-                ML_MARK(6, acc.Ex.r + acc.Hy.i);
-            } else if (a.n_cells > 0) {
-                // ================= centre: nearest hexagonal cell =================
+        if (lens && !peri) {
+            // ================= centre: the record holds the nearest hexagonal cell =================
+            Acc acc = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            if (aux >= 0) {
                 const TableDesc &T = a.center_desc;
-                // what does not depend on the cell first: the (ux, uy) table cell and the
-                // bound tests (bitwise |: one batch of descriptor loads, no chain of branches)
                 int i0, i1;
-                double t0, t1;
-                locate_uv(T, ux, uy, i0, t0, i1, t1);
+                double c0, c1;
+                locate_uv(T, ux, uy, i0, c0, i1, c1);
                 const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3];
-                const bool outside = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
+                const bool out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
                 const int n2 = T.n2;
-                const int stride1 = n2 * 4, stride0 = T.n1 * n2 * 4;
-                const size_t stride_o = (size_t)T.n0 * T.n1 * n2 * 4;
-                // nearest cell: the lattice shortcut returns the cell itself from the node map
-                // (one load); anything it cannot settle goes through nearest_cell_fast
-                double ccx, ccy;
-                int which_raw;
-                bool have_cell = false;
-                if (a.lat_rec) {
-                    int ia, ib;
-                    const int node = lattice_pick(a, x, y, ia, ib);
-                    if (node >= 0) {
-                        typedef double rec_t __attribute__((ext_vector_type(4)));
-                        const rec_t q = *reinterpret_cast<const rec_t *>(a.lat_rec + node);
-                        const double ex = x - q.x, ey = y - q.y;
-                        if (ex * ex + ey * ey <= a.lat_accept_r2) {   // false for a NaN (empty) node
-                            ccx = q.x;
-                            ccy = q.y;
-                            which_raw = (int)(__double_as_longlong(q.z) & 0xffffffffll);
-                            have_cell = true;
-                        }
-                    }
-                }
-                if (!have_cell) {
-                    const int s = nearest_cell_fast(a, x, y, (long long)i * a.ny + j);
-                    const double2 cc = a.cxy[s];
-                    ccx = cc.x;
-                    ccy = cc.y;
-                    which_raw = a.cwhich[s];
-                }
-                ML_MARK(7, ccx);
-                const int which = min(max(which_raw, 0), n2 - 1);
+                const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
+                const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
+                const double ccx = ga, ccy = gb;
+                const int which = min(aux, n2 - 1);
                 // centre table, amplitude-major: [order][i0][i1][4][K]
                 const double2 *tab = a.center_tab;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
                 const double ox_ = x - ccx, oy_ = y - ccy;
-                ML_MARK(8, t0 + t1 + ccx + (double)which);
                 for (int o = 0; o < T.n_orders; ++o) {
                     const double kx = fma(p.kvac, ux, T.center_kx[o]);
                     const double ky = fma(p.kvac, uy, T.center_ky[o]);
                     const double kt2 = fma(kx, kx, ky * ky);
                     if (kt2 <= p.kvac2) {
-                        if (outside) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                        if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
                         // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
-                        order_term(acc, tab + o * stride_o + (size_t)i0 * stride0 + i1 * stride1 +
-                                            which,
-                                   stride0, stride1, n2, t0, t1, Hy_i, Hx_i, kx, ky,
-                                   p.k_glass2 - kt2,
-                                   p.k_glass, inv_n, p.Z0, kx * ox_ + ky * oy_);
+                        order_term(acc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which, st0, st1,
+                                   n2, c0, c1, Hy_i, Hx_i, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n,
+                                   p.Z0, kx * ox_ + ky * oy_);
                     }
                 }
-                ML_MARK(9, acc.Ex.r + acc.Hy.i);
-                // input modulation of the far-field plan's stage 1, (see the periphery branch)
+                // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
                 c2 tilt = {1.0, 0.0};
                 if (a.premod) {
                     const double2 t2 = a.premod[j];
                     tilt = {t2.x, t2.y};
                 }
                 if (!p.plane_wave) {
+                    // phase-critical: propagation from the cell centre (nearfield.py:453-461)
                     const double gx = ccx - p.source_x, gy = ccy - p.source_y;
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double sn, cn;
@@ -461,34 +470,159 @@ __global__ __launch_bounds__(64, 4) void nearfield_fast_kernel(const NfArgs a) {
                     acc.Hx = cmul(acc.Hx, tilt);
                     acc.Hy = cmul(acc.Hy, tilt);
                 }
-                ML_MARK(10, acc.Ex.r + acc.Hy.i);
+            }
+            store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
+        } else if (inb && !lens) {
+            const c2 zero = {0.0, 0.0};
+            store_fields(a, i, j, zero, zero, zero, zero);
+        }
+
+        // ================= periphery: set-up =================
+        if (peri) {
+            const int ring = idx - 1;
+            // everything that depends on the ring alone, in one batch
+            const int slot = a.gc[ring];
+            const double period = a.period[ring];
+            ok = a.ring_ok + a.ring_ok_off[ring];
+            const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
+            const double2 cs = a.rot_table[aux];
+            const TableDesc &T = a.tables[slot];
+            const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3],
+                         b4 = T.bounds[4], b5 = T.bounds[5];
+            const double cosr = cs.x, sinr = cs.y;
+            uxp = fma(ux, cosr, uy * sinr);
+            uyp = fma(uy, cosr, -ux * sinr);
+            Hw_y = fma(Hx_i, cosr, Hy_i * sinr);    // H along x' <-> y table
+            Hw_x = fma(Hy_i, cosr, -Hx_i * sinr);   // H along y' <-> x table
+            int i0, i1;
+            locate_uv(T, uxp, uyp, i0, t0, i1, t1);
+            n_orders = T.n_orders;
+            stride0 = T.n1 * 4;
+            stride_o = T.n0 * T.n1 * 4;
+            node00 = tab + i0 * stride0 + i1 * 4;
+            // the table-bound tests do not depend on the order: evaluate them once, and only take
+            // the reporting path (per order, in the reference's check order) on failure
+            outside = (int)(uxp < b0) | (int)(uxp > b1) | (int)(uyp < b2) | (int)(uyp > b3) |
+                      (int)(period < b4) | (int)(period > b5);
+            // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
+            // block per lane (still correct, just not shared)
+            key = (T.n0 > 64 || T.n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
+        }
+    }
+    // ================= periphery: order loop over LDS-staged table blocks =================
+    Acc pr = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    const double xp = ga, yp = gb;
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
+        int myslot = -1, lead[NF_SLOTS];
+        unsigned long long rest = todo;
+#pragma unroll
+        for (int s = 0; s < NF_SLOTS; ++s) {
+            lead[s] = -1;
+            if (rest) {   // wave-uniform
+                const int l = __ffsll((long long)rest) - 1;
+                const int kl = __builtin_amdgcn_readlane(key, l);
+                const bool mine = key == kl && ((rest >> lane) & 1ull);
+                if (mine) myslot = s;
+                rest &= ~__ballot(mine);
+                lead[s] = l;
             }
         }
-        store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
-        ML_MARK(11, power_here);
+        todo = rest;
+        for (int o0 = 0; o0 < MAX_ORDERS; o0 += NF_CHUNK) {
+            if (!__any(myslot >= 0 && o0 < n_orders)) break;
+            // stage: lane e of the wave fetches (order o0 + e / 16, node (e / 4) % 4, amplitude e % 4)
+            // of the block owner's table position
+#pragma unroll
+            for (int s = 0; s < NF_SLOTS; ++s) {
+                if (lead[s] >= 0) {   // wave-uniform
+                    const unsigned long long bits = (unsigned long long)node00;
+                    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, lead[s]);
+                    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lead[s]);
+                    const int so = __builtin_amdgcn_readlane(stride_o, lead[s]);
+                    const int s0 = __builtin_amdgcn_readlane(stride0, lead[s]);
+                    const int no = __builtin_amdgcn_readlane(n_orders, lead[s]);
+                    const double2 *base = reinterpret_cast<const double2 *>(((unsigned long long)hi << 32) | lo);
+                    const int o = o0 + (lane >> 4), c = (lane >> 2) & 3, q = lane & 3;
+                    if (o < no)
+                        s_tab[s * NF_PITCH + lane] =
+                            base[(long long)o * so + (c >> 1) * s0 + (c & 1) * 4 + q];
+                }
+            }
+            __syncthreads();
+            if (myslot >= 0) {
+                const int o1 = min(o0 + NF_CHUNK, n_orders);
+                for (int o = o0; o < o1; ++o) {
+                    const double kxp = fma(p.kvac, uxp, ok[2 * o]);
+                    const double kyp = fma(p.kvac, uyp, ok[2 * o + 1]);
+                    const double kt2 = fma(kxp, kxp, kyp * kyp);
+                    if (kt2 <= p.kvac2) {
+                        if (outside) {
+                            const int slot = a.gc[idx - 1];
+                            check_bounds(a, a.tables[slot], slot, o, uxp, uyp, a.period[idx - 1], true);
+                        }
+                        order_term_lds(pr, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1, Hw_x,
+                                       Hw_y, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                       kxp * xp + kyp * yp);
+                    }
+                }
+            }
+            __syncthreads();   // the next pass overwrites the blocks
+        }
     }
-    wave_power(a, power_here);
-#ifdef ML_PHASE_TIMERS
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) etc.: the stores have left the wave
-    stamp[12] = __builtin_amdgcn_s_memtime();
-    const size_t wid = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * BW + wave;
-    if (lane == 0 && wid < PHASE_WAVES)
-        for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = stamp[k];
-#endif
+    if (peri) {
+        const double2 cs = a.rot_table[aux];
+        const double cosr = cs.x, sinr = cs.y, rcen = a.rc[idx - 1];
+        // input modulation of the far-field plan's stage 1, applied here for free (see NfArgs)
+        c2 tilt = {1.0, 0.0};
+        if (a.premod) {
+            const double2 t2 = a.premod[j];
+            tilt = {t2.x, t2.y};
+        }
+        // phase-critical: propagation from the grating centre (nearfield.py:337-341)
+        if (!p.plane_wave) {
+            const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
+            const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+            double sn, cn;
+            sincos_cw(p.kvac * air, sn, cn);
+            c2 e = {cn, sn};
+            if (a.premod) e = cmul(e, tilt);   // free ride: one more phasor product
+            pr.Ex = cmul(pr.Ex, e);
+            pr.Ey = cmul(pr.Ey, e);
+            pr.Hx = cmul(pr.Hx, e);
+            pr.Hy = cmul(pr.Hy, e);
+        } else if (a.premod) {
+            pr.Ex = cmul(pr.Ex, tilt);
+            pr.Ey = cmul(pr.Ey, tilt);
+            pr.Hx = cmul(pr.Hx, tilt);
+            pr.Hy = cmul(pr.Hy, tilt);
+        }
+        // back to the lab frame (nearfield.py:351-354)
+        const c2 Ex = {fma(pr.Ex.r, cosr, -pr.Ey.r * sinr), fma(pr.Ex.i, cosr, -pr.Ey.i * sinr)};
+        const c2 Ey = {fma(pr.Ex.r, sinr, pr.Ey.r * cosr), fma(pr.Ex.i, sinr, pr.Ey.i * cosr)};
+        const c2 Hx = {fma(pr.Hx.r, cosr, -pr.Hy.r * sinr), fma(pr.Hx.i, cosr, -pr.Hy.i * sinr)};
+        const c2 Hy = {fma(pr.Hx.r, sinr, pr.Hy.r * cosr), fma(pr.Hx.i, sinr, pr.Hy.i * cosr)};
+        store_fields(a, i, j, Ex, Ey, Hx, Hy);
+    }
 }
 
-#ifdef ML_PHASE_TIMERS
-extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase),
-                                    n_waves * PHASE_SLOTS * sizeof(unsigned long long), 0,
-                                    hipMemcpyDeviceToHost);
+int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
+    const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
+    hipLaunchKernelGGL(nearfield_geometry_kernel, grid, dim3(64), 0, ctx->stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
 }
-#endif
 
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
+    // one wave (= one workgroup) per 8 x 8 patch.  A wave that walks several patches so that its
+    // stores drain under the next patch's arithmetic was tried: the loop costs registers the
+    // kernel does not have (spills) and ran 25-40 % slower.
     const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
     *n_partials = (int)(grid.x * grid.y);
-    hipLaunchKernelGGL(nearfield_fast_kernel, grid, dim3(64), 0, ctx->stream, a);
+    if (a.geo_ix)
+        hipLaunchKernelGGL(nearfield_field_kernel<true>, grid, dim3(64), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(nearfield_field_kernel<false>, grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

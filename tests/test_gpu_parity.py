@@ -917,7 +917,7 @@ def test_north_star_size_properties(ma, side, M, diameter, na, precision, method
             assert np.array_equal(r1[key], r1b[key]), key
         assert r1['power_local_rows'] == r1b['power_local_rows']
         # (c) homogeneity: twice the dipole moment is an exact power-of-two scaling of every field
-        two_p = HotPath(*args, ctx=ctx, dipole_moment=2e-30)
+        two_p = HotPath(*args, ctx=ctx, dipole_moment=2e-30, precision=precision, method=method)
         two_p.step()
         two_p.sync()
         r2 = two_p.results()
@@ -929,7 +929,7 @@ def test_north_star_size_properties(ma, side, M, diameter, na, precision, method
         total = {k: 0 for k in ('Nx', 'Ny', 'Lx', 'Ly')}
         power = 0.0
         for rank in (0, 1):
-            half = HotPath(*args, ctx=ctx, rank=rank, world=2)
+            half = HotPath(*args, ctx=ctx, rank=rank, world=2, precision=precision, method=method)
             half.step_local()
             half.sync()
             vec = [np.empty(half.shape, dtype=np.complex128) for _ in range(4)]

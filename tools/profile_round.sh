@@ -3,6 +3,8 @@
 # counter passes (each in its own run, kernel-trace only, as MI355X_MICROARCH.md prescribes) and
 # the bench lines at the configurations DESIGN.md quotes.  Run on the GPU box:
 #     tools/profile_round.sh TAG        -> gpurun_out/TAG/...
+# EVERY rocprofv3 call runs under `timeout`: a counter set the profiler cannot collect makes it
+# abort and then wait forever (round 2 lost 40 GPU-minutes to exactly that with TA_* counters).
 # then digest locally with tools/profile_summary.py / tools/pmc_digest.py into profiles/.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
@@ -10,9 +12,9 @@ mkdir -p $O
 CMD="python $R/bench.py --steps 7 --warmup 2 --cpu-rows 0"
 cd /tmp && export TMPDIR=/tmp
 # the kernel-trace pass runs EXACTLY the default command (what the driver runs at N = 1)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py > $O/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-180} rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py > $O/stats.log 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-180} rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $CMD > $O/fetch.log 2>&1
+timeout -k 5 ${PMC_TIMEOUT:-180} rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $CMD > $O/write.log 2>&1
 bash $R/tools/pmc_mfma.sh $O/mfma -- $CMD > $O/mfma.log 2>&1
 bash $R/tools/pmc_pass2.sh $O/sq2 -- $CMD > $O/sq2.log 2>&1
 cd $R
