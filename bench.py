@@ -168,6 +168,10 @@ def main():
     ap.add_argument('--pair-list', type=int, default=0,
                     help='> 0: that many arbitrary directions (ux[d], uy[d]) inside the NA cone '
                          'instead of the M x M tensor grid')
+    ap.add_argument('--pols', default='x',
+                    help="polarisations of the dipole; more than one letter (e.g. xyz, the incoherent "
+                         "emitter of nearfield.py:69-73) makes a step ONE batched synthesis pass + a "
+                         "transform and projection per member, sums kept on the GPU (N = 1 only)")
     ap.add_argument('--blocks', type=int, default=5,
                     help='K-step blocks run back to back; the FIRST is the timed region `value` '
                          'comes from, the median block is reported beside it')
@@ -231,7 +235,7 @@ def main():
         th = np.arcsin(rng.uniform(0, 0.9 * na / 1.459, args.pair_list))
         ph = rng.uniform(0, 2 * np.pi, args.pair_list)
         ux, uy = np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph)
-    source = (0.0, 0.0, -lens['source_distance'], 'x')
+    source = (0.0, 0.0, -lens['source_distance'], args.pols[0])
     hp = HotPath(source, wavelength, lens['lens_periphery_summary'],
                  lens['lens_center_summary'], lens['hexgridset'], x, x, ux, uy, ctx=ctx,
                  pair_list=bool(args.pair_list),
@@ -239,6 +243,17 @@ def main():
                  precision=args.precision, reduce=args.reduce,
                  fuse_modulation=bool(args.fuse_modulation), method=args.method)
 
+    n_pols = len(args.pols)
+    if n_pols > 1:
+        assert world == 1 and not args.pair_list, '--pols batches are a single-GPU tensor-grid mode'
+        from metalens_amd.sweep import SourceSweep
+        sw = SourceSweep(wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                         lens['hexgridset'], x, x, ux, uy, ctx=ctx, precision=args.precision,
+                         method=args.method)
+        batch = [(0.0, 0.0, -lens['source_distance'], pol) for pol in args.pols]
+        sw.run(batch)                 # priming pass; settles ties, checks the table bounds
+        one_step = hp.step
+        hp.step = lambda: sw.queue(batch)
     # one priming pass: first-touch allocations, plan tables, and results() raises if the
     # workload left the tables and settles nearest-cell ties (a property of grid and layout).
     # The W warm-up steps then run back to back with the timed region, no host work in between.
@@ -271,6 +286,10 @@ def main():
             elapsed = dt
             prof = ctx.profile_get()
             ctx.profile(False)
+    if n_pols > 1:
+        hp.step = one_step
+        hp.step()
+        hp.sync()
     res = hp.results()
     if args.dump and rank == 0:
         np.savez(args.dump, P=res['P'], a_theta=res['a_theta'], a_phi=res['a_phi'])
@@ -298,7 +317,7 @@ def main():
         del Ex
 
     n_dir = float(args.pair_list) if args.pair_list else float(u.size) * u.size
-    pairs = float(side) * side * n_dir * (world if replicas else 1)
+    pairs = float(side) * side * n_dir * (world if replicas else 1) * n_pols
     ms_per_step = 1e3 * elapsed / args.steps
     if replicas:
         what = ('%d replicas of the N = 1 workload, one wavelength each (%s nm, explicit n_glass)'
@@ -326,7 +345,7 @@ def main():
         'config': {'workload': what, 'aperture': side, 'farfield': u.size,
                    'rings': int(len(lens['lens_periphery_summary']['r_center_list'])),
                    'centre_cells': int(len(lens['lens_center_summary'])),
-                   'parallelism': par,
+                   'parallelism': par, 'sources_per_step': n_pols,
                    'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]}},
         # the same K steps again, args.blocks times in all: spread of the measurement
         'ms_per_step_blocks': block_ms, 'ms_per_step_median': float(np.median(block_ms)),

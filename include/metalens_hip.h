@@ -269,6 +269,30 @@ int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p,
 int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_project_async(ml_ctx *ctx, double Z0);
+/* ---- batched sources --------------------------------------------
+ * The reference's use of this path is the INCOHERENT sum over x-, y- and z-polarised dipoles,
+ * possibly at several positions or wavelengths (nearfield.py:69-73).  Sources that differ only in
+ * polarisation / dipole moment share everything per aperture sample except the two weights the
+ * incident H enters with, so ml_nearfield_batch_async synthesises up to three of them in ONE pass
+ * over the cached per-sample geometry (p[0..n): same position, wavelength and constants); member m
+ * becomes resident field set m.  ml_fields_select picks the set that ml_farfield_transform*,
+ * ml_fields_download work on; ml_nearfield_powers returns the incident power of every member.
+ * ml_nearfield_async / ml_nearfield are the n = 1 case.                                       */
+int ml_nearfield_batch_async(ml_ctx *ctx, const ml_nearfield_params *p, int n, const double *x_pts,
+                             int nx, const double *y_pts, int ny);
+int ml_fields_select(ml_ctx *ctx, int set);
+int ml_nearfield_powers(ml_ctx *ctx, double *power, int n);
+/* Sums over the sources of a sweep, kept on the GPU: after ml_farfield_project[_async],
+ *   P_sum (+)= weight * P                              (reset != 0 starts a new sum)
+ *   slot's total_P = sum of finite P * dux * duy       (nearfield_farfield.py:74)
+ *   slot's cone_P  = the same over (ux - cone_ux0)^2 + (uy - cone_uy0)^2 <= cone_u^2  (encircled power)
+ * asynchronous; ml_farfield_sums downloads P_sum [mx][my] (or NULL) and the first n_slots pairs.
+ * Only P_sum and two scalars per source cross PCIe, whatever the sweep's length.             */
+#define ML_MAX_SWEEP_SLOTS 4096
+int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double cone_ux0, double cone_uy0,
+                           int slot, int reset);
+int ml_farfield_sums(ml_ctx *ctx, double *P_sum, double *total_P, double *cone_P, int n_slots);
+
 /* Exact ties of the nearest-cell search.  A centre-region sample that is exactly equidistant
  * from two cells (it sits on a mirror line of the cell lattice: the x = 0 row of a symmetric
  * grid with an odd number of samples) has no defined nearest cell; the reference takes the one

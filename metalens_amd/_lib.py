@@ -41,6 +41,8 @@ SYMBOLS = (
     'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
     'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
     'ml_farfield_plan_kernels', 'ml_farfield_set_method',
+    'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
+    'ml_farfield_accumulate', 'ml_farfield_sums',
 )
 
 
@@ -94,6 +96,12 @@ def load():
     lib.ml_nearfield.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int, _dp,
                                  POINTER(BoundViolation), c_int, POINTER(c_int)]
     lib.ml_nearfield_async.argtypes = [c_void_p, POINTER(NearfieldParams), _dp, c_int, _dp, c_int]
+    lib.ml_nearfield_batch_async.argtypes = [c_void_p, POINTER(NearfieldParams), c_int, _dp, c_int,
+                                             _dp, c_int]
+    lib.ml_fields_select.argtypes = [c_void_p, c_int]
+    lib.ml_nearfield_powers.argtypes = [c_void_p, _dp, c_int]
+    lib.ml_farfield_accumulate.argtypes = [c_void_p, c_double, c_double, c_double, c_double, c_int, c_int]
+    lib.ml_farfield_sums.argtypes = [c_void_p, _dp, _dp, _dp, c_int]
     lib.ml_nearfield_result.argtypes = [c_void_p, _dp, POINTER(BoundViolation), c_int,
                                         POINTER(c_int)]
     lib.ml_nearfield_ties.argtypes = [c_void_p, POINTER(c_int64), c_int, POINTER(c_int)]

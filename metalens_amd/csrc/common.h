@@ -239,9 +239,16 @@ struct ml_ctx {
     int bins_x = 0, bins_y = 0;
     double bin_x0 = 0, bin_y0 = 0, bin_h = 0;
 
-    // resident field set: complex [4][nx][ny]
-    int nx = 0, ny = 0;
+    // resident field sets: complex [n_sets][4][nx][ny] (one set per member of a polarisation
+    // batch); the far-field and download entry points work on set `field_set`
+    int nx = 0, ny = 0, n_sets = 1, field_set = 0;
     ml::DevBuf fields;
+    double *set_ptr() const {
+        return reinterpret_cast<double *>(fields.p) + (size_t)field_set * 4 * nx * ny * 2;
+    }
+    // far-field sums kept on the GPU across the sources of a sweep (farfield.hip, ml_farfield_accumulate)
+    ml::DevBuf acc_P, acc_partials, acc_sums;
+    int acc_blocks = 0;
     ml::DevBuf lattice_in;   // staging for ml_farfield_lattice_power
 
     // near-field scratch
@@ -368,8 +375,8 @@ int flush_unfold(ml_ctx *ctx);
 // in-place sum of `count` doubles over the communicator, on the context's stream (no-op without one)
 int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count);
 
-// nearfield.hip
-int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny);
+// nearfield.hip: synthesis of a batch of n sources that differ in polarisation only
+int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny);
 // sum the pending power partials now (no-op if none are pending)
 int power_flush(ml_ctx *ctx);
 // ML_NO_PLAN_CACHE=1: rebuild every geometry-only table on every call (for timing them)

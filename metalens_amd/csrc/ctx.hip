@@ -426,7 +426,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->cell_lattice_map, &ctx->cell_lattice_rec, &ctx->tie_count, &ctx->tie_list,
                       &ctx->ovr_key, &ctx->ovr_slot, &ctx->geo_ab, &ctx->geo_ix, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
-                      &ctx->violations, &ctx->row_first, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
+                      &ctx->violations, &ctx->row_first, &ctx->acc_P, &ctx->acc_partials, &ctx->acc_sums, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
                       &ctx->plan.amplitudes, &ctx->comm_scratch, &ctx->lattice_in,
                       &ctx->plan.fold_cm, &ctx->plan.fold_sm, &ctx->plan.fold_E, &ctx->plan.fold_D,
@@ -666,10 +666,17 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     return ML_OK;
 }
 
-static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const double *x_pts,
+static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, const double *x_pts,
                              int nx, const double *y_pts, int ny) {
     ML_REQUIRE(ctx && p && x_pts && y_pts, "NULL argument");
     ML_REQUIRE(nx >= 1 && ny >= 1, "empty grid (%d x %d)", nx, ny);
+    ML_REQUIRE(n >= 1 && n <= 3, "a polarisation batch has 1 to 3 members, got %d", n);
+    for (int m = 1; m < n; ++m)
+        ML_REQUIRE(p[m].source_x == p[0].source_x && p[m].source_y == p[0].source_y &&
+                       p[m].source_z == p[0].source_z && p[m].kvac == p[0].kvac &&
+                       p[m].k_glass == p[0].k_glass && p[m].n_glass == p[0].n_glass &&
+                       p[m].Z0 == p[0].Z0 && p[m].plane_wave == p[0].plane_wave,
+                   "members of a batch may differ in polarisation and dipole moment only (member %d)", m);
     if (!ctx->have_layout) {
         set_error("ml_upload_layout has not been called");
         return ML_ESTATE;
@@ -695,13 +702,15 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     ML_TRY(grid_axis(ctx->x_pts, ctx->h_x_pts, x_pts, nx));
     ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
-    ML_TRY(ctx->fields.reserve(4 * plane * 2 * sizeof(double)));
+    ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
+    ctx->n_sets = n;
+    ctx->field_set = 0;
     // one power partial per wave (8 x 8 samples)
     const int blocks = ((ny + 7) / 8) * ((nx + 7) / 8);
-    ML_TRY(ctx->partial_power.reserve((size_t)blocks * sizeof(double)));
-    ML_TRY(ctx->power.reserve(POWER_GROUPS * sizeof(double)));
+    ML_TRY(ctx->partial_power.reserve((size_t)n * blocks * sizeof(double)));
+    ML_TRY(ctx->power.reserve((size_t)n * POWER_GROUPS * sizeof(double)));
     // two halves: each synthesis launch clears the one the next launch reports into
     const size_t viol_bytes = (size_t)2 * (MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
     ML_TRY(ctx->violations.reserve(viol_bytes));
@@ -723,12 +732,43 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, const do
     }
     ML_TRY(ctx->geo_ab.reserve(plane * 2 * sizeof(double)));
     ML_TRY(ctx->geo_ix.reserve(plane * 2 * sizeof(int)));
-    return nearfield_launch(ctx, p, nx, ny);
+    return nearfield_launch(ctx, p, n, nx, ny);
 }
 
 int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p, const double *x_pts, int nx,
                        const double *y_pts, int ny) {
-    return nearfield_prepare(ctx, p, x_pts, nx, y_pts, ny);
+    return nearfield_prepare(ctx, p, 1, x_pts, nx, y_pts, ny);
+}
+
+int ml_nearfield_batch_async(ml_ctx *ctx, const ml_nearfield_params *p, int n, const double *x_pts,
+                             int nx, const double *y_pts, int ny) {
+    return nearfield_prepare(ctx, p, n, x_pts, nx, y_pts, ny);
+}
+
+int ml_fields_select(ml_ctx *ctx, int set) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(set >= 0 && set < ctx->n_sets, "field set %d out of range (%d resident)", set,
+               ctx->n_sets);
+    ctx->field_set = set;
+    return ML_OK;
+}
+
+int ml_nearfield_powers(ml_ctx *ctx, double *power, int n) {
+    ML_REQUIRE(ctx && power, "NULL argument");
+    ML_REQUIRE(n >= 1 && n <= ctx->n_sets, "%d powers asked for, %d field sets resident", n, ctx->n_sets);
+    ML_REQUIRE(ctx->power.p, "no near field has been synthesised");
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(power_flush(ctx));
+    std::vector<double> groups((size_t)n * POWER_GROUPS);
+    ML_HIP(hipMemcpyAsync(groups.data(), ctx->power.p, groups.size() * sizeof(double),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    for (int m = 0; m < n; ++m) {
+        double pw = 0;
+        for (int g = 0; g < POWER_GROUPS; ++g) pw += groups[(size_t)m * POWER_GROUPS + g];
+        power[m] = pw;
+    }
+    return ML_OK;
 }
 
 static double decode_key(unsigned long long k, int check) {
@@ -836,7 +876,7 @@ int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violatio
 int ml_nearfield(ml_ctx *ctx, const ml_nearfield_params *p, const double *x_pts, int nx,
                  const double *y_pts, int ny, double *power, ml_bound_violation *violations,
                  int max_violations, int *n_violations) {
-    ML_TRY(nearfield_prepare(ctx, p, x_pts, nx, y_pts, ny));
+    ML_TRY(nearfield_prepare(ctx, p, 1, x_pts, nx, y_pts, ny));
     return ml_nearfield_result(ctx, power, violations, max_violations, n_violations);
 }
 
@@ -859,7 +899,7 @@ int ml_fields_download(ml_ctx *ctx, double *Ex, double *Ey, double *Hx, double *
     double *dst[4] = {Ex, Ey, Hx, Hy};
     for (int f = 0; f < 4; ++f)
         if (dst[f])
-            ML_HIP(hipMemcpyAsync(dst[f], (char *)ctx->fields.p + f * plane_bytes, plane_bytes,
+            ML_HIP(hipMemcpyAsync(dst[f], (char *)ctx->set_ptr() + f * plane_bytes, plane_bytes,
                                   hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return ML_OK;
@@ -880,6 +920,8 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
     ML_HIP(hipStreamSynchronize(ctx->stream));
     ctx->nx = nx;
     ctx->ny = ny;
+    ctx->n_sets = 1;
+    ctx->field_set = 0;
     ctx->row_first_valid = false;   // caller-supplied fields: nothing known about zeros
     return ML_OK;
 }

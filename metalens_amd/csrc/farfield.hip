@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <cfloat>
 
@@ -667,7 +668,7 @@ int fields_unmodulate(ml_ctx *ctx) {
                   "cannot be restored");
         return ML_ESTATE;
     }
-    const size_t n = (size_t)4 * ctx->nx * ctx->ny;
+    const size_t n = (size_t)4 * ctx->n_sets * ctx->nx * ctx->ny;   // every resident set
     hipLaunchKernelGGL(zunmodulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        ctx->stream, ctx->fields.as<double2>(), pl.fold_E.as<double2>(), ctx->ny, n);
     ML_HIP(hipGetLastError());
@@ -843,7 +844,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
             c.j0 = pl.fft_y.j0;
             c.pad1 = pl.fft_y.pad1;
             c.pad2 = pl.fft_y.pad2;
-            c.in = ctx->fields.as<double>();
+            c.in = ctx->set_ptr();
             c.rows = 4 * nxl;
             c.in_rb = c.rows;
             c.in_s1 = 0;
@@ -868,7 +869,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
             c.accumulate = 0;
             ML_TRY(zfft_run(ctx->stream, c));
         } else if (pl.fold)
-            ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->fields.as<double>(), ny,
+            ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->set_ptr(), ny,
                                 pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
                                 pl.fold_r4.as<double>(), pl.fold_T,
                                 pl.fold_S,
@@ -877,7 +878,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                                 ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr, nxl,
                                 want_split1, (int64_t)4 * nxl * my, ctx->gemm_f32 != 0, io1));
         else
-            ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->fields.as<double>(), ny, 0,
+            ML_TRY(zgemm(ctx->stream, 4 * nxl, my, ny, one, ctx->set_ptr(), ny, 0,
                          pl.tw_y.as<double>(), my, 0, pl.stage1.as<double>(), my, 0, 1, 0));
     }
     const double dA = pl.dxp * pl.dyp;
@@ -1084,6 +1085,133 @@ int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, doub
                               hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return prof_harvest(ctx);
+}
+
+// ---- sums over the sources of a sweep, kept on the GPU -----------------
+// P_sum (+)= weight * P  (NaN outside the unit circle stays NaN), and per source slot the
+// reference's total_P = sum of the finite P * dux * duy (nearfield_farfield.py:74) plus the same
+// restricted to the cone sqrt(ux^2 + uy^2) <= cone_u.  Two-level fixed-order sums: deterministic.
+struct AccArgs {
+    const double *P, *ux, *uy;
+    double *P_sum, *partials;   // partials[block][2]
+    int mx, my, pair_list, reset;
+    double weight, cell, cone_u2, cone_ux0, cone_uy0;
+};
+
+__global__ __launch_bounds__(256) void accumulate_kernel(const AccArgs a) {
+    __shared__ double s_tot[256], s_cone[256];
+    const size_t n = (size_t)a.mx * (a.pair_list ? 1 : a.my);
+    const size_t at = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double tot = 0.0, cone = 0.0;
+    if (at < n) {
+        const double P = a.P[at];
+        a.P_sum[at] = a.reset ? a.weight * P : a.P_sum[at] + a.weight * P;
+        if (isfinite(P)) {
+            const int i = a.pair_list ? (int)at : (int)(at / a.my), j = a.pair_list ? (int)at : (int)(at % a.my);
+            const double ux = a.ux[i] - a.cone_ux0, uy = a.uy[j] - a.cone_uy0;
+            tot = P * a.cell;
+            if (ux * ux + uy * uy <= a.cone_u2) cone = tot;
+        }
+    }
+    s_tot[threadIdx.x] = tot;
+    s_cone[threadIdx.x] = cone;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s_tot[threadIdx.x] += s_tot[threadIdx.x + w];
+            s_cone[threadIdx.x] += s_cone[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.partials[2 * blockIdx.x] = s_tot[0];
+        a.partials[2 * blockIdx.x + 1] = s_cone[0];
+    }
+}
+
+// sums[2 * slot + {0, 1}] = fixed-order sum of the block partials
+__global__ __launch_bounds__(256) void accumulate_finish_kernel(const double *partials, int n_blocks,
+                                                                double *sums) {
+    __shared__ double s[256];
+    for (int k = 0; k < 2; ++k) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < n_blocks; b += 256) v += partials[2 * b + k];
+        __syncthreads();
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[k] = s[0];
+    }
+}
+
+int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double cone_ux0, double cone_uy0,
+                           int slot, int reset) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    FarfieldPlan &pl = ctx->plan;
+    if (!pl.ready || !pl.have_vectors) {
+        set_error("nothing projected: call ml_farfield_transform and ml_farfield_project first");
+        return ML_ESTATE;
+    }
+    ML_REQUIRE(slot >= 0 && slot < ML_MAX_SWEEP_SLOTS, "slot %d out of range [0, %d)", slot,
+               ML_MAX_SWEEP_SLOTS);
+    ML_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    const int blocks = (int)((n + 255) / 256);
+    ML_TRY(ctx->acc_P.reserve(n * sizeof(double)));
+    ML_TRY(ctx->acc_partials.reserve((size_t)blocks * 2 * sizeof(double)));
+    if (!ctx->acc_sums.p) {
+        ML_TRY(ctx->acc_sums.reserve((size_t)ML_MAX_SWEEP_SLOTS * 2 * sizeof(double)));
+        ML_HIP(hipMemsetAsync(ctx->acc_sums.p, 0, (size_t)ML_MAX_SWEEP_SLOTS * 2 * sizeof(double), ctx->stream));
+    }
+    AccArgs a;
+    a.P = pl.power.as<double>();
+    a.ux = pl.ux.as<double>();
+    a.uy = pl.uy.as<double>();
+    a.P_sum = ctx->acc_P.as<double>();
+    a.partials = ctx->acc_partials.as<double>();
+    a.mx = pl.mx;
+    a.my = pl.my;
+    a.pair_list = pl.pair_list;
+    a.reset = reset;
+    a.weight = weight;
+    // dux * duy as the reference takes them (nearfield_farfield.py:71-74); a pair list has no cell
+    a.cell = 1.0;
+    if (!pl.pair_list && pl.mx > 1 && pl.my > 1)
+        a.cell = (pl.h_ux[1] - pl.h_ux[0]) * (pl.h_uy[1] - pl.h_uy[0]);
+    a.cone_u2 = cone_u * cone_u;
+    a.cone_ux0 = cone_ux0;
+    a.cone_uy0 = cone_uy0;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(256), 0, ctx->stream, a);
+    ML_HIP(hipGetLastError());
+    hipLaunchKernelGGL(accumulate_finish_kernel, dim3(1), dim3(256), 0, ctx->stream,
+                       ctx->acc_partials.as<double>(), blocks, ctx->acc_sums.as<double>() + 2 * slot);
+    ML_HIP(hipGetLastError());
+    ctx->acc_blocks = blocks;
+    return ML_OK;
+}
+
+int ml_farfield_sums(ml_ctx *ctx, double *P_sum, double *total_P, double *cone_P, int n_slots) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(n_slots >= 0 && n_slots <= ML_MAX_SWEEP_SLOTS, "n_slots %d out of range", n_slots);
+    ML_REQUIRE(ctx->acc_P.p && ctx->acc_sums.p, "ml_farfield_accumulate has not run");
+    ML_HIP(hipSetDevice(ctx->device));
+    FarfieldPlan &pl = ctx->plan;
+    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    std::vector<double> sums((size_t)2 * std::max(n_slots, 1));
+    if (P_sum)
+        ML_HIP(hipMemcpyAsync(P_sum, ctx->acc_P.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (n_slots)
+        ML_HIP(hipMemcpyAsync(sums.data(), ctx->acc_sums.p, (size_t)2 * n_slots * sizeof(double),
+                              hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_slots; ++k) {
+        if (total_P) total_P[k] = sums[2 * k];
+        if (cone_P) cone_P[k] = sums[2 * k + 1];
+    }
+    return ML_OK;
 }
 
 int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel) {

@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256) void row_extent_kernel(const NfArgs a) {
 // the projection kernel when a transform follows, farfield.hip)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const double *partial, int n,
                                                            double *groups) {
-    sum_partials_group(partial, n, groups, blockIdx.x, threadIdx.x);
+    // blockIdx.y = field set (member of a polarisation batch)
+    sum_partials_group(partial + (size_t)blockIdx.y * n, n, groups + blockIdx.y * POWER_GROUPS,
+                       blockIdx.x, threadIdx.x);
 }
 
 bool plan_cache_disabled() {
@@ -71,15 +73,24 @@ bool plan_cache_disabled() {
 
 int power_flush(ml_ctx *ctx) {
     if (!ctx->power_pending) return ML_OK;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(POWER_GROUPS), dim3(256), 0, ctx->stream,
-                       ctx->partial_power.as<double>(), ctx->n_partials, ctx->power.as<double>());
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(POWER_GROUPS, ctx->n_sets), dim3(256), 0,
+                       ctx->stream, ctx->partial_power.as<double>(), ctx->n_partials,
+                       ctx->power.as<double>());
     ML_HIP(hipGetLastError());
     ctx->power_pending = false;
     return ML_OK;
 }
 
-void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a) {
-    a.p = *p;
+void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a) {
+    a.p = p[0];
+    a.n_pol = n;
+    a.n_partials = ((ny + 7) / 8) * ((nx + 7) / 8);
+    for (int m = 0; m < MAX_POL; ++m) {
+        const ml_nearfield_params &q = p[m < n ? m : 0];
+        for (int k = 0; k < 3; ++k) a.pol[m][k] = q.pol[k];
+        a.hcoef[m] = q.H_coef;
+        a.dmom[m] = q.dipole_moment;
+    }
     a.x_pts = ctx->x_pts.as<double>();
     a.y_pts = ctx->y_pts.as<double>();
     a.nx = nx;
@@ -157,11 +168,11 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfA
     ctx->fields_premod_serial = premod ? pl.serial : -1;
 }
 
-int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) {
+int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny) {
     NfArgs a;
     // this launch reports into the half the previous launch cleared
     ctx->viol_half = 1 - ctx->viol_half;
-    fill_nf_args(ctx, p, nx, ny, a);
+    fill_nf_args(ctx, p, n, nx, ny, a);
     int n_partials = 0;
     // row extents for the far-field GEMM: a function of the grid and the lens radius
     if (plan_cache_disabled() || ctx->row_first_key[0] != ctx->grid_serial ||
@@ -191,6 +202,9 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny) 
     // the partials are summed by the projection kernel if one follows, else on demand
     ctx->n_partials = n_partials;
     ctx->power_pending = true;
+    // a batch sums the partials of all its members now (the projection kernel's spare block,
+    // which does it for free in the single-source pipeline, knows one set only)
+    if (n > 1) ML_TRY(power_flush(ctx));
     return ML_OK;
 }
 

@@ -14,8 +14,14 @@ __device__ __forceinline__ c2 cmul(c2 a, c2 b) {
 }
 __device__ __forceinline__ c2 scale(c2 a, double s) { return {a.r * s, a.i * s}; }
 
+constexpr int MAX_POL = 3;   // members of a polarisation batch (three span every orientation)
+
 struct NfArgs {
-    ml_nearfield_params p;
+    ml_nearfield_params p;      // member 0; position, wavelength and constants are the batch's
+    // polarisation batch (ml_nearfield_batch_async): unit vector, H_coef and dipole moment of
+    // every member; member m writes field set m and power partials [m][n_partials]
+    int n_pol, n_partials;
+    double pol[MAX_POL][3], hcoef[MAX_POL], dmom[MAX_POL];
     const double *x_pts, *y_pts;
     int nx, ny;
     // rings
@@ -367,26 +373,27 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
 }
 
 // incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream
-__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int by) {
+__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int by, int member) {
     for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
-    if (threadIdx.x == 0) a.partial_power[(size_t)by * gridDim.x + blockIdx.x] = power_here;
-    if (blockIdx.x == 0 && by == 0)
+    if (threadIdx.x == 0)
+        a.partial_power[(size_t)member * a.n_partials + (size_t)by * gridDim.x + blockIdx.x] = power_here;
+    if (blockIdx.x == 0 && by == 0 && member == 0)
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
 }
 
-__device__ __forceinline__ void store_fields(const NfArgs &a, int i, int j, c2 Ex, c2 Ey, c2 Hx,
-                                             c2 Hy) {
-    // 16 B per lane per plane, coalesced along y
+__device__ __forceinline__ void store_fields(const NfArgs &a, int member, int i, int j, c2 Ex, c2 Ey,
+                                             c2 Hx, c2 Hy) {
+    // 16 B per lane per plane, coalesced along y; field set `member` = 4 planes
     const size_t plane = (size_t)a.nx * a.ny;
     const size_t at = (size_t)i * a.ny + j;
-    double2 *F = reinterpret_cast<double2 *>(a.fields);
+    double2 *F = reinterpret_cast<double2 *>(a.fields) + (size_t)member * 4 * plane;
     F[at] = make_double2(Ex.r, Ex.i);
     F[plane + at] = make_double2(Ey.r, Ey.i);
     F[2 * plane + at] = make_double2(Hx.r, Hx.i);
     F[3 * plane + at] = make_double2(Hy.r, Hy.i);
 }
 
-void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int nx, int ny, NfArgs &a);
+void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a);
 // writes the number of per-block power partials it produces to *n_partials
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
 // the source-independent records of the current (grid, layout, tie answers)

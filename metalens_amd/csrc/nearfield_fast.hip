@@ -191,79 +191,81 @@ struct Acc {
     c2 Ex, Ey, Hx, Hy;
 };
 
-// one diffraction order: bilinear table read at 4 nodes, both polarisations, phase multiply
-// (`qs` = distance in double2 between the four amplitudes of one node: 1 for the per-ring
-// periphery tables, K for the centre table, which is stored amplitude-major so that lanes
-// with different cell types still read neighbouring addresses)
-__device__ __forceinline__ void order_term(Acc &acc, const double2 *node00, int stride0,
-                                           int stride1, int qs, double t0, double t1, double Hw_x,
-                                           double Hw_y, double kx, double ky, double kz2,
-                                           double k_glass, double inv_n, double Z0, double arg) {
-    const double w00 = (1 - t0) * (1 - t1), w01 = (1 - t0) * t1, w10 = t0 * (1 - t1), w11 = t0 * t1;
-    // U_fy = sum_p Hw_p a_fy,p ; U_fx = sum_p Hw_p a_fx,p with a = sum_nodes w v
-    double ufy_r = 0, ufy_i = 0, ufx_r = 0, ufx_i = 0;
-    const double2 *nodes[4] = {node00, node00 + stride1, node00 + stride0,
-                               node00 + stride0 + stride1};
-    const double w[4] = {w00, w01, w10, w11};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double2 xfy = nodes[c][0], xfx = nodes[c][qs], yfy = nodes[c][2 * qs],
-                      yfx = nodes[c][3 * qs];
-        const double wx = w[c] * Hw_x, wy = w[c] * Hw_y;
-        ufy_r = fma(wx, xfy.x, fma(wy, yfy.x, ufy_r));
-        ufy_i = fma(wx, xfy.y, fma(wy, yfy.y, ufy_i));
-        ufx_r = fma(wx, xfx.x, fma(wy, yfx.x, ufx_r));
-        ufx_i = fma(wx, xfx.y, fma(wy, yfx.y, ufx_i));
-    }
-    double sn, cs;
-    sincos_cw(arg, sn, cs);
-    // V = U * exp(i arg)
-    const double vy_r = fma(ufy_r, cs, -ufy_i * sn), vy_i = fma(ufy_r, sn, ufy_i * cs);
-    const double vx_r = fma(ufx_r, cs, -ufx_i * sn), vx_i = fma(ufx_r, sn, ufx_i * cs);
-    acc.Hx.r += vy_r;
-    acc.Hx.i += vy_i;
-    acc.Hy.r += vx_r;
-    acc.Hy.i += vx_i;
+// One diffraction order in two steps.  What depends on the direction of incidence alone - the
+// four interpolated table amplitudes a = (x,ampfy) (x,ampfx) (y,ampfy) (y,ampfx), the order's
+// phasor and the E-from-H factors - is evaluated once per sample (OrderCommon); what depends on
+// the source's POLARISATION enters through two real weights only (Hw_x, Hw_y: incident H along
+// y' and x'), so a batch of polarisations at one source position (the x, y, z dipoles of an
+// incoherent emitter, nearfield.py:69-73) shares everything above and pays order_apply per member.
+struct OrderCommon {
+    double ar[4], ai[4];     // interpolated amplitudes
+    double cs, sn;           // exp(i (kx x' + ky y'))
+    double cxy, cxx, cyy;    // Z0 / (n k_glass kz) x (kx ky, ky^2 + kz^2, -(kx^2 + kz^2))
+};
+
+__device__ __forceinline__ void order_factors(OrderCommon &oc, double kx, double ky, double kz2,
+                                              double k_glass, double inv_n, double Z0, double arg) {
+    sincos_cw(arg, oc.sn, oc.cs);
     const double g = Z0 * inv_n * recip(k_glass) * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
-    const double cxy = kx * ky * g, cxx = fma(ky, ky, kz2) * g, cyy = -fma(kx, kx, kz2) * g;
-    acc.Ex.r += fma(cxy, vy_r, cxx * vx_r);
-    acc.Ex.i += fma(cxy, vy_i, cxx * vx_i);
-    acc.Ey.r += fma(cyy, vy_r, -cxy * vx_r);
-    acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
+    oc.cxy = kx * ky * g;
+    oc.cxx = fma(ky, ky, kz2) * g;
+    oc.cyy = -fma(kx, kx, kz2) * g;
 }
 
-// The same with the node values taken from a block staged in LDS: blk[(node c) * 4 + amplitude q],
-// c = 2 * (i0 step) + (i1 step) (see the staging in nearfield_field_kernel)
-__device__ __forceinline__ void order_term_lds(Acc &acc, const double2 *blk, double t0, double t1,
-                                               double Hw_x, double Hw_y, double kx, double ky,
-                                               double kz2, double k_glass, double inv_n, double Z0,
-                                               double arg) {
+// amplitudes from a block staged in LDS: blk[(node c) * 4 + amplitude q], c = 2 (i0 step) + (i1 step)
+__device__ __forceinline__ void order_common_lds(OrderCommon &oc, const double2 *blk, double t0,
+                                                 double t1) {
     const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
-    double ufy_r = 0, ufy_i = 0, ufx_r = 0, ufx_i = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double2 xfy = blk[c * 4 + 0], xfx = blk[c * 4 + 1], yfy = blk[c * 4 + 2],
-                      yfx = blk[c * 4 + 3];
-        const double wx = w[c] * Hw_x, wy = w[c] * Hw_y;
-        ufy_r = fma(wx, xfy.x, fma(wy, yfy.x, ufy_r));
-        ufy_i = fma(wx, xfy.y, fma(wy, yfy.y, ufy_i));
-        ufx_r = fma(wx, xfx.x, fma(wy, yfx.x, ufx_r));
-        ufx_i = fma(wx, xfx.y, fma(wy, yfx.y, ufx_i));
-    }
-    double sn, cs;
-    sincos_cw(arg, sn, cs);
-    const double vy_r = fma(ufy_r, cs, -ufy_i * sn), vy_i = fma(ufy_r, sn, ufy_i * cs);
-    const double vx_r = fma(ufx_r, cs, -ufx_i * sn), vx_i = fma(ufx_r, sn, ufx_i * cs);
+    for (int q = 0; q < 4; ++q) oc.ar[q] = oc.ai[q] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = blk[c * 4 + q];
+            oc.ar[q] = fma(w[c], v.x, oc.ar[q]);
+            oc.ai[q] = fma(w[c], v.y, oc.ai[q]);
+        }
+}
+
+// amplitudes gathered from global memory (`qs` = distance in double2 between the four amplitudes
+// of one node: the centre table is stored amplitude-major, [order][i0][i1][4][K], so that lanes
+// with different cell types still read neighbouring addresses)
+__device__ __forceinline__ void order_common_gather(OrderCommon &oc, const double2 *node00,
+                                                    int stride0, int stride1, int qs, double t0,
+                                                    double t1) {
+    const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
+    const double2 *nodes[4] = {node00, node00 + stride1, node00 + stride0,
+                               node00 + stride0 + stride1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) oc.ar[q] = oc.ai[q] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double2 v = nodes[c][q * qs];
+            oc.ar[q] = fma(w[c], v.x, oc.ar[q]);
+            oc.ai[q] = fma(w[c], v.y, oc.ai[q]);
+        }
+}
+
+// one polarisation's share of the order (nearfield.py:313-327 rearranged, see the file header)
+__device__ __forceinline__ void order_apply(Acc &acc, const OrderCommon &oc, double Hw_x,
+                                            double Hw_y) {
+    // U_fy = sum_p Hw_p a_fy,p ; U_fx = sum_p Hw_p a_fx,p
+    const double ufy_r = fma(Hw_x, oc.ar[0], Hw_y * oc.ar[2]), ufy_i = fma(Hw_x, oc.ai[0], Hw_y * oc.ai[2]);
+    const double ufx_r = fma(Hw_x, oc.ar[1], Hw_y * oc.ar[3]), ufx_i = fma(Hw_x, oc.ai[1], Hw_y * oc.ai[3]);
+    // V = U * exp(i arg)
+    const double vy_r = fma(ufy_r, oc.cs, -ufy_i * oc.sn), vy_i = fma(ufy_r, oc.sn, ufy_i * oc.cs);
+    const double vx_r = fma(ufx_r, oc.cs, -ufx_i * oc.sn), vx_i = fma(ufx_r, oc.sn, ufx_i * oc.cs);
     acc.Hx.r += vy_r;
     acc.Hx.i += vy_i;
     acc.Hy.r += vx_r;
     acc.Hy.i += vx_i;
-    const double g = Z0 * inv_n * recip(k_glass) * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
-    const double cxy = kx * ky * g, cxx = fma(ky, ky, kz2) * g, cyy = -fma(kx, kx, kz2) * g;
-    acc.Ex.r += fma(cxy, vy_r, cxx * vx_r);
-    acc.Ex.i += fma(cxy, vy_i, cxx * vx_i);
-    acc.Ey.r += fma(cyy, vy_r, -cxy * vx_r);
-    acc.Ey.i += fma(cyy, vy_i, -cxy * vx_i);
+    acc.Ex.r += fma(oc.cxy, vy_r, oc.cxx * vx_r);
+    acc.Ex.i += fma(oc.cxy, vy_i, oc.cxx * vx_i);
+    acc.Ey.r += fma(oc.cyy, vy_r, -oc.cxy * vx_r);
+    acc.Ey.i += fma(oc.cyy, vy_i, -oc.cxy * vx_i);
 }
 
 // ---- kernel 1 of 2: the source-INDEPENDENT decisions of every sample ---------------------------
@@ -350,8 +352,8 @@ constexpr int NF_SLOTS = 6;                  // distinct (ring, cell) blocks sta
 constexpr int NF_CHUNK = 4;                  // orders per staging pass (64 lanes = 4 x 4 x 4)
 constexpr int NF_PITCH = NF_CHUNK * 16 + 1;  // +1: blocks start in different 16-byte bank slots
 
-template <bool RECORDS>
-__global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) {
+template <bool RECORDS, int NP>
+__global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(const NfArgs a) {
     __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];
     const int lane = threadIdx.x & 63;
     const ml_nearfield_params &p = a.p;
@@ -381,43 +383,61 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
     int key = -1, n_orders = 0, stride0 = 0, stride_o = 0;
-    double uxp = 0.0, uyp = 0.0, Hw_x = 0.0, Hw_y = 0.0, t0 = 0.0, t1 = 0.0;
+    double uxp = 0.0, uyp = 0.0, t0 = 0.0, t1 = 0.0;
+    double Hw_x[NP], Hw_y[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) Hw_x[m] = Hw_y[m] = 0.0;
     const double *ok = a.ring_ok;
     const double2 *node00 = a.ring_tab;
     bool outside = false;
     {
-        double power_here = 0.0;
-        double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 1.0, Hx_i = 0.0, Hy_i = 0.0;
+        double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 1.0;
+        double Hx_i[NP], Hy_i[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) Hx_i[m] = Hy_i[m] = 0.0;
         if (lens) {
-            // ---- incidence direction and incident field (amplitude-type arithmetic)
             x = a.x_pts[i];
             y = a.y_pts[j];
-            double Ex_i, Ey_i;
-            if (p.plane_wave) {
-                Ex_i = p.pol[0] * p.dipole_moment;
-                Ey_i = p.pol[1] * p.dipole_moment;
-                Hx_i = -p.pol[1] * p.dipole_moment / p.Z0;
-                Hy_i = p.pol[0] * p.dipole_moment / p.Z0;
-            } else {
-                const double dx = x - p.source_x, dy = y - p.source_y;
-                const double inv = rsqrt_fast(dx * dx + dy * dy + p.dz2);
-                ux = dx * inv;
-                uy = dy * inv;
-                uz = p.dz * inv;
-                const double amp = p.H_coef * sqrt(uz) * inv;
-                Hx_i = (uy * p.pol[2] - uz * p.pol[1]) * amp;
-                Hy_i = (uz * p.pol[0] - ux * p.pol[2]) * amp;
-                const double Hz_i = (ux * p.pol[1] - uy * p.pol[0]) * amp;
-                Ex_i = (Hy_i * uz - Hz_i * uy) * p.Z0;
-                Ey_i = (Hz_i * ux - Hx_i * uz) * p.Z0;
-            }
-            power_here = Ex_i * Hy_i - Ey_i * Hx_i;
         }
-        wave_power(a, power_here, by);
+        // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
+        // arithmetic)
+        double inv = 1.0;
+        if (lens && !p.plane_wave) {
+            const double dx = x - p.source_x, dy = y - p.source_y;
+            inv = rsqrt_fast(dx * dx + dy * dy + p.dz2);
+            ux = dx * inv;
+            uy = dy * inv;
+            uz = p.dz * inv;
+        }
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            double power_here = 0.0;
+            if (lens) {
+                const double *pol = a.pol[m];
+                double Ex_i, Ey_i;
+                if (p.plane_wave) {
+                    Ex_i = pol[0] * a.dmom[m];
+                    Ey_i = pol[1] * a.dmom[m];
+                    Hx_i[m] = -pol[1] * a.dmom[m] / p.Z0;
+                    Hy_i[m] = pol[0] * a.dmom[m] / p.Z0;
+                } else {
+                    const double amp = a.hcoef[m] * sqrt(uz) * inv;
+                    Hx_i[m] = (uy * pol[2] - uz * pol[1]) * amp;
+                    Hy_i[m] = (uz * pol[0] - ux * pol[2]) * amp;
+                    const double Hz_i = (ux * pol[1] - uy * pol[0]) * amp;
+                    Ex_i = (Hy_i[m] * uz - Hz_i * uy) * p.Z0;
+                    Ey_i = (Hz_i * ux - Hx_i[m] * uz) * p.Z0;
+                }
+                power_here = Ex_i * Hy_i[m] - Ey_i * Hx_i[m];
+            }
+            wave_power(a, power_here, by, m);
+        }
 
         if (lens && !peri) {
             // ================= centre: the record holds the nearest hexagonal cell =================
-            Acc acc = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            Acc acc[NP];
+#pragma unroll
+            for (int m = 0; m < NP; ++m) acc[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
             if (aux >= 0) {
                 const TableDesc &T = a.center_desc;
                 int i0, i1;
@@ -440,17 +460,21 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
                     const double kt2 = fma(kx, kx, ky * ky);
                     if (kt2 <= p.kvac2) {
                         if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                        OrderCommon oc;
+                        order_common_gather(oc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which,
+                                            st0, st1, n2, c0, c1);
+                        order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                      kx * ox_ + ky * oy_);
                         // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
-                        order_term(acc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which, st0, st1,
-                                   n2, c0, c1, Hy_i, Hx_i, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n,
-                                   p.Z0, kx * ox_ + ky * oy_);
+#pragma unroll
+                        for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
                     }
                 }
                 // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
-                c2 tilt = {1.0, 0.0};
+                c2 e = {1.0, 0.0};
                 if (a.premod) {
                     const double2 t2 = a.premod[j];
-                    tilt = {t2.x, t2.y};
+                    e = {t2.x, t2.y};
                 }
                 if (!p.plane_wave) {
                     // phase-critical: propagation from the cell centre (nearfield.py:453-461)
@@ -458,23 +482,26 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double sn, cn;
                     sincos_cw(p.kvac * air, sn, cn);
-                    c2 e = {cn, sn};
-                    if (a.premod) e = cmul(e, tilt);
-                    acc.Ex = cmul(acc.Ex, e);
-                    acc.Ey = cmul(acc.Ey, e);
-                    acc.Hx = cmul(acc.Hx, e);
-                    acc.Hy = cmul(acc.Hy, e);
-                } else if (a.premod) {
-                    acc.Ex = cmul(acc.Ex, tilt);
-                    acc.Ey = cmul(acc.Ey, tilt);
-                    acc.Hx = cmul(acc.Hx, tilt);
-                    acc.Hy = cmul(acc.Hy, tilt);
+                    const c2 prop = {cn, sn};
+                    e = a.premod ? cmul(prop, e) : prop;
+                }
+                if (!p.plane_wave || a.premod) {
+#pragma unroll
+                    for (int m = 0; m < NP; ++m) {
+                        acc[m].Ex = cmul(acc[m].Ex, e);
+                        acc[m].Ey = cmul(acc[m].Ey, e);
+                        acc[m].Hx = cmul(acc[m].Hx, e);
+                        acc[m].Hy = cmul(acc[m].Hy, e);
+                    }
                 }
             }
-            store_fields(a, i, j, acc.Ex, acc.Ey, acc.Hx, acc.Hy);
+#pragma unroll
+            for (int m = 0; m < NP; ++m)
+                store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
         } else if (inb && !lens) {
             const c2 zero = {0.0, 0.0};
-            store_fields(a, i, j, zero, zero, zero, zero);
+#pragma unroll
+            for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
         }
 
         // ================= periphery: set-up =================
@@ -492,8 +519,11 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
             const double cosr = cs.x, sinr = cs.y;
             uxp = fma(ux, cosr, uy * sinr);
             uyp = fma(uy, cosr, -ux * sinr);
-            Hw_y = fma(Hx_i, cosr, Hy_i * sinr);    // H along x' <-> y table
-            Hw_x = fma(Hy_i, cosr, -Hx_i * sinr);   // H along y' <-> x table
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                Hw_y[m] = fma(Hx_i[m], cosr, Hy_i[m] * sinr);    // H along x' <-> y table
+                Hw_x[m] = fma(Hy_i[m], cosr, -Hx_i[m] * sinr);   // H along y' <-> x table
+            }
             int i0, i1;
             locate_uv(T, uxp, uyp, i0, t0, i1, t1);
             n_orders = T.n_orders;
@@ -510,7 +540,9 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
         }
     }
     // ================= periphery: order loop over LDS-staged table blocks =================
-    Acc pr = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    Acc pr[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) pr[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
     const double xp = ga, yp = gb;
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
@@ -561,9 +593,12 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
                             const int slot = a.gc[idx - 1];
                             check_bounds(a, a.tables[slot], slot, o, uxp, uyp, a.period[idx - 1], true);
                         }
-                        order_term_lds(pr, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1, Hw_x,
-                                       Hw_y, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                       kxp * xp + kyp * yp);
+                        OrderCommon oc;
+                        order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
+                        order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                      kxp * xp + kyp * yp);
+#pragma unroll
+                        for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
                     }
                 }
             }
@@ -574,10 +609,10 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
         const double2 cs = a.rot_table[aux];
         const double cosr = cs.x, sinr = cs.y, rcen = a.rc[idx - 1];
         // input modulation of the far-field plan's stage 1, applied here for free (see NfArgs)
-        c2 tilt = {1.0, 0.0};
+        c2 e = {1.0, 0.0};
         if (a.premod) {
             const double2 t2 = a.premod[j];
-            tilt = {t2.x, t2.y};
+            e = {t2.x, t2.y};
         }
         // phase-critical: propagation from the grating centre (nearfield.py:337-341)
         if (!p.plane_wave) {
@@ -585,24 +620,25 @@ __global__ __launch_bounds__(64, 4) void nearfield_field_kernel(const NfArgs a) 
             const double air = sqrt(gx * gx + gy * gy + p.source_z2);
             double sn, cn;
             sincos_cw(p.kvac * air, sn, cn);
-            c2 e = {cn, sn};
-            if (a.premod) e = cmul(e, tilt);   // free ride: one more phasor product
-            pr.Ex = cmul(pr.Ex, e);
-            pr.Ey = cmul(pr.Ey, e);
-            pr.Hx = cmul(pr.Hx, e);
-            pr.Hy = cmul(pr.Hy, e);
-        } else if (a.premod) {
-            pr.Ex = cmul(pr.Ex, tilt);
-            pr.Ey = cmul(pr.Ey, tilt);
-            pr.Hx = cmul(pr.Hx, tilt);
-            pr.Hy = cmul(pr.Hy, tilt);
+            const c2 prop = {cn, sn};
+            e = a.premod ? cmul(prop, e) : prop;   // free ride: one more phasor product
         }
-        // back to the lab frame (nearfield.py:351-354)
-        const c2 Ex = {fma(pr.Ex.r, cosr, -pr.Ey.r * sinr), fma(pr.Ex.i, cosr, -pr.Ey.i * sinr)};
-        const c2 Ey = {fma(pr.Ex.r, sinr, pr.Ey.r * cosr), fma(pr.Ex.i, sinr, pr.Ey.i * cosr)};
-        const c2 Hx = {fma(pr.Hx.r, cosr, -pr.Hy.r * sinr), fma(pr.Hx.i, cosr, -pr.Hy.i * sinr)};
-        const c2 Hy = {fma(pr.Hx.r, sinr, pr.Hy.r * cosr), fma(pr.Hx.i, sinr, pr.Hy.i * cosr)};
-        store_fields(a, i, j, Ex, Ey, Hx, Hy);
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            Acc &q = pr[m];
+            if (!p.plane_wave || a.premod) {
+                q.Ex = cmul(q.Ex, e);
+                q.Ey = cmul(q.Ey, e);
+                q.Hx = cmul(q.Hx, e);
+                q.Hy = cmul(q.Hy, e);
+            }
+            // back to the lab frame (nearfield.py:351-354)
+            const c2 Ex = {fma(q.Ex.r, cosr, -q.Ey.r * sinr), fma(q.Ex.i, cosr, -q.Ey.i * sinr)};
+            const c2 Ey = {fma(q.Ex.r, sinr, q.Ey.r * cosr), fma(q.Ex.i, sinr, q.Ey.i * cosr)};
+            const c2 Hx = {fma(q.Hx.r, cosr, -q.Hy.r * sinr), fma(q.Hx.i, cosr, -q.Hy.i * sinr)};
+            const c2 Hy = {fma(q.Hx.r, sinr, q.Hy.r * cosr), fma(q.Hx.i, sinr, q.Hy.i * cosr)};
+            store_fields(a, m, i, j, Ex, Ey, Hx, Hy);
+        }
     }
 }
 
@@ -619,10 +655,14 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     // kernel does not have (spills) and ran 25-40 % slower.
     const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
     *n_partials = (int)(grid.x * grid.y);
-    if (a.geo_ix)
-        hipLaunchKernelGGL(nearfield_field_kernel<true>, grid, dim3(64), 0, ctx->stream, a);
+    if (!a.geo_ix)   // diagnostic build only: decisions inline, no records
+        hipLaunchKernelGGL((nearfield_field_kernel<false, 1>), grid, dim3(64), 0, ctx->stream, a);
+    else if (a.n_pol == 1)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1>), grid, dim3(64), 0, ctx->stream, a);
+    else if (a.n_pol == 2)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 2>), grid, dim3(64), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(nearfield_field_kernel<false>, grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 3>), grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

@@ -1,78 +1,167 @@
-"""Batched source sweeps.
+"""Batched source sweeps with the sums kept on the GPU.
 
 The reference's docstring describes the use (nearfield.py:69-73): an isotropic or Lambertian
-emitter is the INCOHERENT sum of x-, y- and z-polarised dipoles, possibly at several positions
-or wavelengths - i.e. many runs of near field -> far field whose POWERS are added.  A sweep
-re-uses the resident tables and layout and keeps two passes in flight on two GPU streams: the
-near-field kernel (L1/latency-bound, matrix cores idle) of one source overlaps the folded GEMMs
-(matrix-core-bound) of the previous one (measured +7 % throughput at 2048^2 -> 256^2, +11 % at
-4096^2 -> 512^2 with the end-of-round-1 kernels).
+emitter is the INCOHERENT sum of x-, y- and z-polarised dipoles, possibly at several positions -
+i.e. many runs of near field -> far field whose POWERS are added, and whose efficiency is
+``sum(total_P) / sum(power_passing_through_lens)`` (nearfield_farfield.py:74, nearfield.py:474-477).
+
+What a sweep shares:
+
+* tables, layout, far-field plan and the per-sample geometry records (ring, sector, rotated
+  coordinates, nearest cell: csrc/nearfield_fast.hip) - they depend on grid and lens only;
+* within a group of sources at ONE position that differ in polarisation (the x, y, z triple): the
+  whole per-sample evaluation except the two weights the incident H enters with - such a group
+  is ONE synthesis pass (``ml_nearfield_batch_async``) that leaves one resident field set per
+  member;
+* the sums: ``P_sum``, per-source ``total_P`` and encircled power are accumulated by a kernel
+  right after each projection (``ml_farfield_accumulate``); only ``P_sum`` and two scalars per
+  source cross PCIe, whatever the sweep's length.
 """
 import numpy as np
 
-from . import _lib
-from .pipeline import HotPath
+from . import _lib, constants, packing, ties
+from .constants import nm
+from .grating import n_glass as tabulated_n_glass
+from .nearfield import _check_axis, _raise_violation, nearfield_params
+from .pipeline import _check_source
+
+MAX_BATCH = 3          # members of a polarisation batch (csrc/nearfield_dev.h MAX_POL)
+MAX_SLOTS = 4096       # ML_MAX_SWEEP_SLOTS
 
 
 class SourceSweep:
     def __init__(self, wavelength, lens_periphery_summary, lens_center_summary, hexgridset,
-                 x_pts, y_pts, ux, uy, dipole_moment=1e-30, c0=None, Z0=None, n_streams=2,
-                 device=None):
-        self.ux = np.asarray(ux, dtype=float).ravel()
-        self.uy = np.asarray(uy, dtype=float).ravel()
-        self.lanes = []
-        for _ in range(max(1, n_streams)):
-            ctx = _lib.Context(device)
-            # the source is replaced per pass; any valid one will do for set-up
-            hp = HotPath((0.0, 0.0, -1.0, 'x'), wavelength, lens_periphery_summary,
-                         lens_center_summary, hexgridset, x_pts, y_pts, self.ux, self.uy,
-                         dipole_moment=dipole_moment, c0=c0, Z0=Z0, ctx=ctx)
-            self.lanes.append(hp)
+                 x_pts, y_pts, ux, uy, dipole_moment=1e-30, c0=None, Z0=None, ctx=None,
+                 precision=None, method=None):
+        self.ctx = ctx or _lib.default_context()
+        self.ctx.set_precision(precision or 'f64')
+        self.ctx.set_method(method or 'auto')
+        self.c0 = constants.c0 if c0 is None else c0
+        self.Z0 = constants.Z0 if Z0 is None else Z0
+        _check_axis(x_pts, wavelength)
+        _check_axis(y_pts, wavelength)
+        S = lens_periphery_summary
+        wl_nm = int(round(wavelength / nm))
+        n_glass = S['gratingcollection_list'][0].grating_list[0].n_glass
+        if n_glass == 0:
+            n_glass = tabulated_n_glass(wl_nm)
+        self.n_glass, self.wavelength = n_glass, wavelength
+        self._tables = (S['gratingcollection_list'], hexgridset, wl_nm)
+        self._layout = (S, lens_center_summary)
+        self._cells = lens_center_summary
+        self.dipole_moment = dipole_moment
+        self.x, self.y = _lib.f64(x_pts), _lib.f64(y_pts)
+        self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
+        self.dxp, self.dyp = x_pts[1] - x_pts[0], y_pts[1] - y_pts[0]
 
-    def close(self):
-        for hp in self.lanes:
-            hp.ctx.close()
+    def close(self):   # kept for callers of the earlier two-stream implementation
+        pass
 
-    def run(self, sources, keep_each=False):
-        """``sources`` = iterable of ``(source_x, source_y, source_z, source_pol)``.
+    def prepare(self):
+        """make tables, layout and the far-field plan resident (no-ops when they already are)"""
+        ctx, lib = self.ctx, self.ctx.lib
+        packing.upload_tables(ctx, *self._tables)
+        packing.upload_layout(ctx, *self._layout)
+        _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 0))
+        _lib.check(lib.ml_farfield_plan(ctx.handle, self.x.size, self.y.size, self.dxp, self.dyp,
+                                        self.wavelength, self.n_glass, _lib.dptr(self.ux),
+                                        self.ux.size, _lib.dptr(self.uy), self.uy.size, 0))
+
+    def queue(self, sources):
+        """queue the whole sweep on the GPU and return without synchronising (benchmarks);
+        tie settlement and the downloads are ``run``'s business"""
+        weights = np.ones(len(sources))
+        for g in self._group(sources):
+            self._pass(g, None, (0.0, 0.0, 0.0), weights)
+
+    def _group(self, sources):
+        """consecutive sources at one position -> batches of up to MAX_BATCH polarisations"""
+        groups = []
+        for k, src in enumerate(sources):
+            sx, sy, sz, pol = _check_source(src)
+            if groups and groups[-1]['pos'] == (sx, sy, sz) and len(groups[-1]['members']) < MAX_BATCH:
+                groups[-1]['members'].append((k, pol))
+            else:
+                groups.append({'pos': (sx, sy, sz), 'members': [(k, pol)]})
+        return groups
+
+    def _pass(self, group, slots_done, cone, weights):
+        """queue one group: batched synthesis, then per member transform -> projection -> sums"""
+        ctx, lib = self.ctx, self.ctx.lib
+        sx, sy, sz = group['pos']
+        n = len(group['members'])
+        params = (_lib.NearfieldParams * n)()
+        for m, (k, pol) in enumerate(group['members']):
+            params[m] = nearfield_params(sx, sy, sz, pol, self.wavelength, self.n_glass,
+                                         self.dipole_moment, self.c0, self.Z0)
+        _lib.check(lib.ml_nearfield_batch_async(ctx.handle, params, n, _lib.dptr(self.x), self.x.size,
+                                                _lib.dptr(self.y), self.y.size))
+        for m, (k, pol) in enumerate(group['members']):
+            _lib.check(lib.ml_fields_select(ctx.handle, m))
+            _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
+            _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
+            _lib.check(lib.ml_farfield_accumulate(ctx.handle, float(weights[k]), cone[0], cone[1],
+                                                  cone[2], k, int(k == 0)))
+        return n
+
+    def run(self, sources, weights=None, cone=None, cone_center=(0.0, 0.0), keep_each=False):
+        """``sources`` = iterable of ``(source_x, source_y, source_z, source_pol)``; sources at the
+        same position that follow each other (the x, y, z dipoles of one emitter) are synthesised
+        together.  ``weights[k]`` scales source k in ``P_sum`` (default 1); ``cone`` = sine of the
+        half-angle of the cone (about ``cone_center``) whose encircled power is wanted.
+
         Returns a dict: ``P_sum`` (incoherent sum of the far-field power maps, NaN outside the
         unit circle), ``power_in`` (incident power through the lens per source,
         nearfield.py:474-477), ``total_P`` (radiated power per source: sum of the finite
         ``P * dux * duy``, nearfield_farfield.py:74), ``efficiency`` = sum(total_P) /
-        sum(power_in), and ``P_each`` if ``keep_each``."""
+        sum(power_in), ``cone_P`` / ``cone_efficiency`` if a cone was given, ``P_each`` if
+        ``keep_each`` (downloads every map: for tests)."""
         sources = list(sources)
-        dux = self.ux[1] - self.ux[0] if self.ux.size > 1 else 1.0
-        duy = self.uy[1] - self.uy[0] if self.uy.size > 1 else 1.0
-        P_sum = None
-        power_in, total_P, each = [], [], []
-        pending = [None] * len(self.lanes)
-
-        def collect(slot):
-            nonlocal P_sum
-            hp = self.lanes[slot]
-            hp.sync()
-            res = hp.results()
-            P = res['P']
-            P_sum = P.copy() if P_sum is None else P_sum + P
-            power_in.append(res['power_local_rows'])
-            total_P.append(float((P * dux * duy)[np.isfinite(P)].sum()))
-            if keep_each:
-                each.append(P)
-            pending[slot] = None
-
-        for k, src in enumerate(sources):
-            slot = k % len(self.lanes)
-            if pending[slot] is not None:
-                collect(slot)
-            self.lanes[slot].set_source(src)
-            self.lanes[slot].step()
-            pending[slot] = k
-        # drain in issue order
-        order = sorted((k, s) for s, k in enumerate(pending) if k is not None)
-        for _, slot in order:
-            collect(slot)
-        out = {'P_sum': P_sum, 'power_in': np.array(power_in), 'total_P': np.array(total_P)}
-        out['efficiency'] = out['total_P'].sum() / out['power_in'].sum() if power_in else np.nan
+        if not 1 <= len(sources) <= MAX_SLOTS:
+            raise ValueError('a sweep takes 1 to %d sources, got %d' % (MAX_SLOTS, len(sources)))
+        weights = np.ones(len(sources)) if weights is None else np.asarray(weights, dtype=float)
+        ctx, lib = self.ctx, self.ctx.lib
+        self.prepare()
+        cone3 = (float(cone) if cone is not None else 0.0, float(cone_center[0]), float(cone_center[1]))
+        groups = self._group(sources)
+        power_in = np.zeros(len(sources))
+        each = [None] * len(sources)
+        first = True
+        for g in groups:
+            n = self._pass(g, None, cone3, weights)
+            if first:
+                # exact nearest-cell ties are a property of grid and cells: settled once, by
+                # asking cKDTree like the reference (ties.py), then the pass is repeated
+                ctx.sync()
+                if ties.settle(ctx, self._cells, self.x, self.y) is not None:
+                    n = self._pass(g, None, cone3, weights)
+                first = False
+            pw = np.zeros(n)
+            _lib.check(lib.ml_nearfield_powers(ctx.handle, _lib.dptr(pw), n))
+            viol = (_lib.BoundViolation * 8)()
+            n_viol = _lib.c_int(0)
+            _lib.check(lib.ml_nearfield_result(ctx.handle, None, viol, 8, _lib.byref(n_viol)))
+            if n_viol.value:
+                _raise_violation(viol[0], ctx)
+            for m, (k, pol) in enumerate(g['members']):
+                power_in[k] = pw[m] * self.dxp * self.dyp
+            if keep_each:   # the projections of this group's members, one at a time (tests)
+                for m, (k, pol) in enumerate(g['members']):
+                    _lib.check(lib.ml_fields_select(ctx.handle, m))
+                    _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
+                    P = np.empty((self.ux.size, self.uy.size))
+                    _lib.check(lib.ml_farfield_project(ctx.handle, self.Z0, _lib.dptr(P), None, None))
+                    each[k] = P
+        P_sum = np.empty((self.ux.size, self.uy.size))
+        total_P = np.zeros(len(sources))
+        cone_P = np.zeros(len(sources))
+        _lib.check(lib.ml_farfield_sums(ctx.handle, _lib.dptr(P_sum), _lib.dptr(total_P),
+                                        _lib.dptr(cone_P), len(sources)))
+        out = {'P_sum': P_sum, 'power_in': power_in, 'total_P': total_P}
+        out['efficiency'] = total_P.sum() / power_in.sum() if power_in.sum() else np.nan
+        if cone is not None:
+            out['cone_P'] = cone_P
+            out['cone_efficiency'] = cone_P.sum() / power_in.sum() if power_in.sum() else np.nan
         if keep_each:
             out['P_each'] = each
         return out

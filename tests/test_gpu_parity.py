@@ -345,20 +345,28 @@ def test_rgb_wavelengths_vs_oracle(ma, wl_nm, n_glass):
 
 def test_source_sweep_incoherent_sum_vs_oracle(ma):
     """x + y + z dipoles summed incoherently (the reference's isotropic-emitter recipe,
-    nearfield.py:69-73), two passes in flight on two streams"""
+    nearfield.py:69-73).  Sources at one position are ONE synthesis pass (a polarisation batch
+    of 3, then a single, then a batch of 2); P_sum, every total_P and the encircled power are
+    accumulated on the GPU and must equal the oracle's maps reduced on the host
+    (metalens_amd/postprocess.py, itself pinned on the reference's total_P)."""
+    from metalens_amd import postprocess
     from oracle import farfield_oracle, nearfield_oracle
     wl = 580e-9
     lens = _synthetic_lens(18e-6, 0.35, wl, switch_deg=9.0)
     R = lens['lens_periphery_summary']['r_max_list'][-1]
     x = np.linspace(-R, R, 150)
     u = np.linspace(-0.2, 0.2, 36)
+    du = u[1] - u[0]
     f = lens['source_distance']
     sources = [(0.2e-6, 0.1e-6, -f, 'x'), (0.2e-6, 0.1e-6, -f, 'y'), (0.2e-6, 0.1e-6, -f, 'z'),
-               (-1.0e-6, 0.5e-6, -1.05 * f, 'x')]
+               (-1.0e-6, 0.5e-6, -1.05 * f, 'x'),
+               (0.0, 0.0, -0.97 * f, 'y'), (0.0, 0.0, -0.97 * f, 'z')]
+    weights = np.array([1.0, 1.0, 1.0, 0.5, 2.0, 2.0])
+    cone, center = 0.08, (0.01, -0.005)
     sw = ma.SourceSweep(wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
                         lens['hexgridset'], x, x, u, u)
-    got = sw.run(sources, keep_each=True)
-    sw.close()
+    assert [len(g['members']) for g in sw._group(sources)] == [3, 1, 2]
+    got = sw.run(sources, weights=weights, cone=cone, cone_center=center, keep_each=True)
     P_ref, pin_ref = 0, []
     for k, (sx, sy, sz, pol) in enumerate(sources):
         nf = nearfield_oracle.build_nearfield(sx, sy, sz, pol, wl, lens['lens_periphery_summary'],
@@ -366,11 +374,51 @@ def test_source_sweep_incoherent_sum_vs_oracle(ma):
                                               x_pts=x, y_pts=x)
         ff = farfield_oracle.farfield_direct(*nf[:4], x, x, wl, nf[7], u, u)
         assert np.nanmax(np.abs(got['P_each'][k] - ff['P'])) <= 1e-11 * np.nanmax(ff['P'])
-        P_ref = P_ref + ff['P']
+        P_ref = P_ref + weights[k] * ff['P']
         pin_ref.append(nf[6])
+        want_total = postprocess.total_power(ff['P'], du, du)
+        want_cone = postprocess.encircled_power(ff['P'], u, u, du, du, sin_max=cone, center=center)
+        assert abs(got['total_P'][k] - want_total) <= 1e-11 * want_total, k
+        assert abs(got['cone_P'][k] - want_cone) <= 1e-11 * want_total, k
+        assert 0 < want_cone < want_total          # the cone really cuts the map
     assert np.nanmax(np.abs(got['P_sum'] - P_ref)) <= 1e-11 * np.nanmax(P_ref)
     np.testing.assert_allclose(got['power_in'], pin_ref, rtol=1e-12)
-    assert 0 < got['efficiency'] < 10
+    assert abs(got['efficiency'] - got['total_P'].sum() / np.sum(pin_ref)) < 1e-12
+    assert 0 < got['cone_efficiency'] < got['efficiency'] < 10
+
+
+def test_polarisation_batch_equals_single_sources(ma):
+    """the batched synthesis (one pass, three resident field sets) against three single-source
+    calls of the drop-in function, fields and incident power, dipoles and plane waves"""
+    from metalens_amd import _lib
+    from metalens_amd.nearfield import nearfield_params
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    r_c = float(lens['lens_periphery_summary']['r_min_list'][0])
+    ctx = _lib.default_context()
+    common = (wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'])
+    for (sx, sy, sz), pols, x in (((0.3e-6, -0.2e-6, -lens['source_distance']), 'xyz', np.linspace(-R, R, 384)),
+                                  ((0.0, 0.0, -float('inf')), 'xy', np.linspace(-0.6 * r_c, 0.6 * r_c, 160))):
+        singles = [ma.build_nearfield(sx, sy, sz, pol, *common, x_pts=x, y_pts=x, ctx=ctx) for pol in pols]
+        n = len(pols)
+        params = (_lib.NearfieldParams * n)()
+        for m, pol in enumerate(pols):
+            params[m] = nearfield_params(sx, sy, sz, pol, wl, singles[0][7], 1e-30,
+                                         ma.constants.c0, ma.constants.Z0)
+        xs = _lib.f64(x)
+        _lib.check(ctx.lib.ml_nearfield_batch_async(ctx.handle, params, n, _lib.dptr(xs), xs.size,
+                                                    _lib.dptr(xs), xs.size))
+        pw = np.zeros(n)
+        _lib.check(ctx.lib.ml_nearfield_powers(ctx.handle, _lib.dptr(pw), n))
+        for m in range(n):
+            _lib.check(ctx.lib.ml_fields_select(ctx.handle, m))
+            F = [np.empty((x.size, x.size), dtype=np.complex128) for _ in range(4)]
+            _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(a) for a in F]))
+            scale = max(np.abs(w).max() for w in singles[m][:4])
+            for g, w in zip(F, singles[m][:4]):
+                assert np.abs(g - w).max() <= 1e-14 * scale
+            assert abs(pw[m] * (x[1] - x[0]) ** 2 - singles[m][6]) <= 1e-13 * abs(singles[m][6])
 
 
 @pytest.mark.parametrize('reduce', ['amplitudes', 'vectors'])
