@@ -69,6 +69,8 @@ static int load_rccl() {
     } while (0)
 
 void comm_release(ml_ctx *ctx) {
+    if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+    ctx->reduce_in_flight = false;
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
 }
@@ -86,8 +88,8 @@ static std::string comm_file_name(const ml_ctx *ctx, long seq, int rank) {
     return b;
 }
 
-static int allreduce_file(ml_ctx *ctx, double *buf, size_t count, int op) {
-    ML_HIP(hipStreamSynchronize(ctx->stream));
+static int allreduce_file(ml_ctx *ctx, double *buf, size_t count, int op, hipStream_t stream) {
+    ML_HIP(hipStreamSynchronize(stream));
     std::vector<double> mine(count), other(count), acc(count);
     ML_HIP(hipMemcpy(mine.data(), buf, count * sizeof(double), hipMemcpyDeviceToHost));
     const long seq = ctx->comm_file_seq++;
@@ -121,20 +123,34 @@ static int allreduce_file(ml_ctx *ctx, double *buf, size_t count, int op) {
     return ML_OK;
 }
 
-static int allreduce_dev(ml_ctx *ctx, double *buf, size_t count, int op) {
-    if (ctx->comm_file) return allreduce_file(ctx, buf, count, op);
+static int allreduce_dev(ml_ctx *ctx, double *buf, size_t count, int op, hipStream_t stream) {
+    if (ctx->comm_file) return allreduce_file(ctx, buf, count, op, stream);
     if (ctx->n_ranks <= 1 && !ctx->comm) return ML_OK;
     if (!ctx->comm) {
         set_error("ml_comm_init has not been called");
         return ML_ESTATE;
     }
     ML_NCCL(g_rccl.AllReduce(buf, buf, count, ncclDouble, op == 1 ? ncclMax : ncclSum,
-                             (ncclComm_t)ctx->comm, ctx->stream));
+                             (ncclComm_t)ctx->comm, stream));
     return ML_OK;
 }
 
-int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count) {
-    return allreduce_dev(ctx, buf, count, 0);
+int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count, hipStream_t stream) {
+    return allreduce_dev(ctx, buf, count, 0, stream);
+}
+
+int comm_join(ml_ctx *ctx, bool host) {
+    if (!ctx->reduce_in_flight) return ML_OK;
+    // every reduction records reduce_done[slot] behind its power kernel; the latest one is
+    // plan.amp_slot's, and the comm stream runs them in order
+    hipEvent_t e = ctx->reduce_done[ctx->plan.amp_slot];
+    if (host) {
+        ML_HIP(hipEventSynchronize(e));
+        ctx->reduce_in_flight = false;
+    } else {
+        ML_HIP(hipStreamWaitEvent(ctx->stream, e, 0));
+    }
+    return ML_OK;
 }
 
 }  // namespace ml
@@ -219,17 +235,18 @@ int ml_farfield_allreduce(ml_ctx *ctx) {
     ML_TRY(flush_unfold(ctx));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     pl.amplitudes_reduced = false;
-    return allreduce_dev(ctx, pl.vectors.as<double>(), 4 * n * 2, 0);
+    return allreduce_dev(ctx, pl.vectors.as<double>(), 4 * n * 2, 0, ctx->stream);
 }
 
 int ml_comm_allreduce_host(ml_ctx *ctx, double *values, int count, int op) {
     ML_REQUIRE(ctx && values && count >= 1, "bad argument");
     if (ctx->n_ranks <= 1 && !ctx->comm && !ctx->comm_file) return ML_OK;
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(comm_join(ctx, true));   // one collective of this communicator at a time
     ML_TRY(ctx->comm_scratch.reserve(count * sizeof(double)));
     ML_HIP(hipMemcpyAsync(ctx->comm_scratch.p, values, count * sizeof(double),
                           hipMemcpyHostToDevice, ctx->stream));
-    ML_TRY(allreduce_dev(ctx, ctx->comm_scratch.as<double>(), count, op));
+    ML_TRY(allreduce_dev(ctx, ctx->comm_scratch.as<double>(), count, op, ctx->stream));
     ML_HIP(hipMemcpyAsync(values, ctx->comm_scratch.p, count * sizeof(double),
                           hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));

@@ -179,7 +179,12 @@ struct FarfieldPlan {
     DevBuf stage1;       // complex [4][nx_local][my]
     DevBuf vectors;      // complex [4][mx][my]  (Nx, Ny, Lx, Ly)  or [4][mx] for a pair list
     DevBuf power;        // double  [mx][my]
-    DevBuf amplitudes;   // complex [2][mx][my]  (a_theta, a_phi)
+    // complex [2 slots][2][mx][my]  (a_theta, a_phi).  Two slots: with a communicator the
+    // all-reduce of step k's amplitudes runs on its own stream while step k + 1 is synthesised
+    // and projects into the other slot (ml_farfield_project_reduce)
+    DevBuf amplitudes;
+    int amp_slot = 0;
+    double *amp_ptr() const { return reinterpret_cast<double *>(amplitudes.p) + (size_t)amp_slot * 4 * mx * (pair_list ? 1 : my); }
     bool have_vectors = false;
     bool tw_x_ready = false;  // complex x twiddles built for the current plan
     int stage1_splits = 1;   // split-K slabs currently held in `stage1`
@@ -294,7 +299,11 @@ struct ml_ctx {
     ml::FarfieldPlan plan;
     ml::Profile prof;
 
-    // RCCL
+    // RCCL.  comm_stream carries the all-reduce of the projected amplitudes and the power kernel
+    // behind it; amp_ready[s] / reduce_done[s] order it against the main stream per amplitude slot
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t amp_ready[2] = {nullptr, nullptr}, reduce_done[2] = {nullptr, nullptr};
+    bool reduce_in_flight = false;
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
     // ML_COMM_BACKEND=file: TEST backend, all-reduce through files in /tmp (several ranks may
@@ -372,8 +381,10 @@ void comm_release(ml_ctx *ctx);
 int fields_unmodulate(ml_ctx *ctx);
 // farfield.hip: write the radiation vectors a folded stage 2 left in split-K slabs (no-op if none)
 int flush_unfold(ml_ctx *ctx);
-// in-place sum of `count` doubles over the communicator, on the context's stream (no-op without one)
-int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count);
+// in-place sum of `count` doubles over the communicator, queued on `stream` (no-op without one)
+int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count, hipStream_t stream);
+// the main stream (and the host, if `host`) waits for a reduction still running on comm_stream
+int comm_join(ml_ctx *ctx, bool host);
 
 // nearfield.hip: synthesis of a batch of n sources that differ in polarisation only
 int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny);

@@ -37,6 +37,7 @@ static hipEvent_t take_event(ml_ctx *ctx) {
 }
 
 void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b) {
+    if (kernel < 0 || kernel >= ML_K_COUNT) return;   // launches that are not timed (other stream)
     if (!ctx->prof.on || !((ctx->prof.mask >> kernel) & 1u)) return;
     if (ctx->prof.seen[kernel]++ % ctx->prof.period != 0) return;
     *a = take_event(ctx);
@@ -407,6 +408,13 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
+    if (ctx->comm_stream) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipEventDestroy(ctx->amp_ready[k]);
+            (void)hipEventDestroy(ctx->reduce_done[k]);
+        }
+        (void)hipStreamDestroy(ctx->comm_stream);
+    }
     for (auto &s : ctx->slots) {
         s.axis0.release();
         s.axis1.release();
@@ -455,6 +463,7 @@ int ml_sync(ml_ctx *ctx) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_HIP(hipSetDevice(ctx->device));
     ML_HIP(hipStreamSynchronize(ctx->stream));
+    ML_TRY(comm_join(ctx, true));
     return ML_OK;
 }
 

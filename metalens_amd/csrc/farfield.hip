@@ -651,10 +651,11 @@ static int need_tw_x(ml_ctx *ctx) {
     return ML_OK;
 }
 
-static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id) {
-    ProfScope scope(ctx, kernel_id);
-    hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0, ctx->stream,
-                       a);
+static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id, hipStream_t stream = nullptr) {
+    // (HIP-event timing belongs to the context's own stream)
+    ProfScope scope(ctx, stream ? ML_K_COUNT : kernel_id);
+    hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0,
+                       stream ? stream : ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
@@ -707,6 +708,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
         pl.amplitudes_reduced = false;
         return ML_OK;
     }
+    ML_TRY(comm_join(ctx, true));   // a reduction of the old plan may still use its buffers
     pl.ready = false;
     ++pl.serial;
     pl.have_vectors = false;
@@ -727,7 +729,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     const size_t out_elems = pair_list ? (size_t)mx : (size_t)mx * my;
     ML_TRY(pl.vectors.reserve(4 * out_elems * 2 * sizeof(double)));
     ML_TRY(pl.power.reserve(out_elems * sizeof(double)));
-    ML_TRY(pl.amplitudes.reserve(2 * out_elems * 2 * sizeof(double)));
+    ML_TRY(pl.amplitudes.reserve(2 * 2 * out_elems * 2 * sizeof(double)));   // two slots
     // direction grids on the aperture's FFT lattice: that axis runs as an output-pruned FFT
     pl.fft_y.ok = pl.fft_x.ok = false;
     if (method == ML_METHOD_AUTO && !pair_list) {
@@ -997,7 +999,7 @@ int ml_farfield_transform_mirrored(ml_ctx *ctx, int row0, int accumulate) {
     return prof_harvest(ctx);
 }
 
-static int project_stage(ml_ctx *ctx, double Z0, int stage) {
+static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream = nullptr) {
     ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready || !pl.have_vectors) {
@@ -1023,8 +1025,8 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage) {
     a.Z = Z0 / pl.n_glass;
     a.coef = pow(2 * M_PI * pl.n_glass / pl.wavelength, 2) / (32 * pow(M_PI, 2) * a.Z);
     a.P = pl.power.as<double>();
-    a.a_theta = pl.amplitudes.as<double2>();
-    a.a_phi = pl.amplitudes.as<double2>() + n;
+    a.a_theta = reinterpret_cast<double2 *>(pl.amp_ptr());
+    a.a_phi = a.a_theta + n;
     a.stage = stage;
     if (pl.unfold_pending && stage != 2) {
         // vectors still in split-K slabs: unfold and project in one kernel, and let a spare
@@ -1048,7 +1050,7 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage) {
         return ML_OK;
     }
     ML_TRY(flush_unfold(ctx));
-    return project_launch(ctx, a, ML_K_PROJECT);
+    return project_launch(ctx, a, ML_K_PROJECT, stream);
 }
 
 int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
@@ -1060,28 +1062,56 @@ int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
 // radiation vectors need not be summed themselves: project locally, all-reduce 2 complex
 // planes instead of 4, then take the power (nearfield_farfield.py:184-189).  The radiation
 // vectors stay local partial sums (ml_farfield_allreduce sums those, if they are wanted).
+// With a communicator the all-reduce (latency-bound: 2 planes of a few MB over xGMI) and the power
+// kernel behind it run on the context's second stream: the main stream only projects the partial
+// sums into the free amplitude slot and moves on to the next step's synthesis.
 int ml_farfield_project_reduce(ml_ctx *ctx, double Z0) {
-    ML_TRY(project_stage(ctx, Z0, 1));
+    ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
+    const bool overlap = ctx->comm || ctx->comm_file;
+    if (!overlap) {
+        ML_TRY(project_stage(ctx, Z0, 1));
+        ML_TRY(project_stage(ctx, Z0, 2));
+        pl.amplitudes_reduced = true;
+        return ML_OK;
+    }
+    ML_HIP(hipSetDevice(ctx->device));
+    if (!ctx->comm_stream) {
+        ML_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            ML_HIP(hipEventCreateWithFlags(&ctx->amp_ready[k], hipEventDisableTiming));
+            ML_HIP(hipEventCreateWithFlags(&ctx->reduce_done[k], hipEventDisableTiming));
+        }
+    }
+    const int slot = pl.amp_slot ^ 1;
+    // the reduction that last used this slot (two calls ago) has to be through with it
+    if (ctx->reduce_in_flight) ML_HIP(hipStreamWaitEvent(ctx->stream, ctx->reduce_done[slot], 0));
+    pl.amp_slot = slot;
+    ML_TRY(project_stage(ctx, Z0, 1));
+    ML_HIP(hipEventRecord(ctx->amp_ready[slot], ctx->stream));
+    ML_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->amp_ready[slot], 0));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
-    ML_TRY(comm_allreduce_sum(ctx, pl.amplitudes.as<double>(), 2 * n * 2));
-    ML_TRY(project_stage(ctx, Z0, 2));
+    ML_TRY(comm_allreduce_sum(ctx, pl.amp_ptr(), 2 * n * 2, ctx->comm_stream));
+    ML_TRY(project_stage(ctx, Z0, 2, ctx->comm_stream));
+    ML_HIP(hipEventRecord(ctx->reduce_done[slot], ctx->comm_stream));
+    ctx->reduce_in_flight = true;
     pl.amplitudes_reduced = true;
     return ML_OK;
 }
 
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi) {
     ML_TRY(ml_farfield_project_async(ctx, Z0));
+    ML_TRY(comm_join(ctx, false));   // a reduction on the second stream writes what is copied here
     FarfieldPlan &pl = ctx->plan;
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     if (P)
         ML_HIP(hipMemcpyAsync(P, pl.power.p, n * sizeof(double), hipMemcpyDeviceToHost,
                               ctx->stream));
     if (a_theta)
-        ML_HIP(hipMemcpyAsync(a_theta, pl.amplitudes.p, n * 2 * sizeof(double),
+        ML_HIP(hipMemcpyAsync(a_theta, pl.amp_ptr(), n * 2 * sizeof(double),
                               hipMemcpyDeviceToHost, ctx->stream));
     if (a_phi)
-        ML_HIP(hipMemcpyAsync(a_phi, pl.amplitudes.as<double>() + 2 * n, n * 2 * sizeof(double),
+        ML_HIP(hipMemcpyAsync(a_phi, pl.amp_ptr() + 2 * n, n * 2 * sizeof(double),
                               hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return prof_harvest(ctx);
@@ -1158,6 +1188,7 @@ int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double con
     ML_REQUIRE(slot >= 0 && slot < ML_MAX_SWEEP_SLOTS, "slot %d out of range [0, %d)", slot,
                ML_MAX_SWEEP_SLOTS);
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(comm_join(ctx, false));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     const int blocks = (int)((n + 255) / 256);
     ML_TRY(ctx->acc_P.reserve(n * sizeof(double)));

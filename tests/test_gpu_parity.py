@@ -589,6 +589,41 @@ def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs):
     assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
 
 
+def test_two_gpus_real_rccl(tmp_path):
+    """bench.py --gpus 2 with REAL RCCL over xGMI, one rank per GPU: runs only where two GPUs are
+    visible (the single-GPU boxes of this pool skip it; the file-communicator test above covers
+    the same flow there).  Rendezvous through the launcher's environment, ncclCommInitRank with
+    two ranks, the all-reduce of the projected amplitudes on the second stream, max-over-ranks
+    timing - and the far field must equal the one-process result."""
+    import json
+    from metalens_amd import _lib
+    n = _lib.c_int(0)
+    _lib.check(_lib.load().ml_device_count(_lib.byref(n)))
+    if n.value < 2:
+        pytest.skip('needs two GPUs (%d visible)' % n.value)
+    one = str(tmp_path / 'one.npz')
+    p = _run_bench(['--dump', one, '--steps', '6'], {}, aperture=512)
+    out, err = p.communicate(timeout=600)
+    assert p.returncode == 0, err[-2000:]
+    for reduce in ('amplitudes', 'vectors'):
+        two = str(tmp_path / ('two_%s.npz' % reduce))
+        env = dict(WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(29571 + (reduce == 'vectors')), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs = [_run_bench(['--gpus', '2', '--dump', two, '--reduce', reduce, '--steps', '6'],
+                            dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=512) for r in range(2)]
+        outs = [q.communicate(timeout=600) for q in procs]
+        for q, (o, e) in zip(procs, outs):
+            assert q.returncode == 0, e[-2000:]
+        line = json.loads([l for l in outs[0][0].splitlines() if l.strip()][-1])
+        assert line['n_gpus'] == 2
+        a, b = np.load(one), np.load(two)
+        for key in ('a_theta', 'a_phi'):
+            assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), (reduce, key)
+        ok = ~np.isnan(a['P'])
+        assert np.array_equal(np.isnan(b['P']), ~ok)
+        assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
+
+
 def test_full_size_nearfield_rows_and_determinism(ma):
     """BASELINE config[1] (2048^2 window of the 1 mm NA 0.5 lens): 24 aperture rows spread over
     the window against the CPU oracle, two runs bit-identical (fixed-order reductions, no float
