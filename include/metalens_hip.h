@@ -50,6 +50,12 @@ void ml_ctx_destroy(ml_ctx *ctx);
 /* name[] receives the gcnArchName; cu_count / hbm_bytes may be NULL */
 int ml_device_info(ml_ctx *ctx, char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
 
+/* Page-locked host memory for arrays that cross PCIe: copies to and from it run at the link's
+ * rate (pageable memory is staged at about a fifth of it).  The Python binding gives
+ * build_nearfield's output arrays such storage and recycles it when they are garbage-collected. */
+int ml_host_alloc(uint64_t bytes, void **ptr);
+int ml_host_free(void *ptr);
+
 /* ---- tables: GratingCollection.interpolators / HexGridSet.interpolators ------------
  * Replaces the scipy RegularGridInterpolator objects built by the reference at
  * grating.py:1186-1232 and lens_center.py:188-226 and evaluated at nearfield.py:310-311

@@ -42,7 +42,7 @@ SYMBOLS = (
     'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
     'ml_farfield_plan_kernels', 'ml_farfield_set_method',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
-    'ml_farfield_accumulate', 'ml_farfield_sums',
+    'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_host_alloc', 'ml_host_free',
 )
 
 
@@ -102,6 +102,8 @@ def load():
     lib.ml_nearfield_powers.argtypes = [c_void_p, _dp, c_int]
     lib.ml_farfield_accumulate.argtypes = [c_void_p, c_double, c_double, c_double, c_double, c_int, c_int]
     lib.ml_farfield_sums.argtypes = [c_void_p, _dp, _dp, _dp, c_int]
+    lib.ml_host_alloc.argtypes = [ctypes.c_uint64, POINTER(c_void_p)]
+    lib.ml_host_free.argtypes = [c_void_p]
     lib.ml_nearfield_result.argtypes = [c_void_p, _dp, POINTER(BoundViolation), c_int,
                                         POINTER(c_int)]
     lib.ml_nearfield_ties.argtypes = [c_void_p, POINTER(c_int64), c_int, POINTER(c_int)]
@@ -166,6 +168,51 @@ def f64(a):
 
 def c128(a):
     return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+class _PinnedPool:
+    """Page-locked buffers behind the arrays the drop-in functions return.  Locking pages is slow
+    (tens of ms for a few hundred MB), copying into locked pages is fast: a buffer goes back to
+    the pool when the array built on it is garbage-collected, and the next call of the same size
+    takes it from there."""
+
+    def __init__(self, keep_bytes=8 << 30):
+        self.free = {}          # nbytes -> [pointer, ...]
+        self.kept = 0
+        self.keep_bytes = keep_bytes
+
+    def _release(self, ptr, nbytes):
+        if self.kept + nbytes <= self.keep_bytes:
+            self.free.setdefault(nbytes, []).append(ptr)
+            self.kept += nbytes
+        else:
+            try:
+                load().ml_host_free(c_void_p(ptr))
+            except Exception:   # interpreter shutdown
+                pass
+
+    def empty(self, shape, dtype):
+        import weakref
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes == 0:
+            return np.empty(shape, dtype=dtype)
+        stack = self.free.get(nbytes)
+        if stack:
+            ptr = stack.pop()
+            self.kept -= nbytes
+        else:
+            p = c_void_p()
+            check(load().ml_host_alloc(nbytes, byref(p)))
+            ptr = p.value
+        buf = (ctypes.c_char * nbytes).from_address(ptr)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        # `buf` is the base object of every view of `arr`: it dies when the last of them does
+        weakref.finalize(buf, self._release, ptr, nbytes)
+        return arr
+
+
+pinned = _PinnedPool()
 
 
 class Context:

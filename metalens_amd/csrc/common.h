@@ -280,6 +280,9 @@ struct ml_ctx {
     // fields_premod_serial = serial of the plan whose modulation the resident fields carry (-1: none)
     bool premod_enabled = false;
     long fields_premod_serial = -1;
+    // what the zeros outside the lens in `fields` were written for: (buffer, bytes, sets, nx * ny,
+    // grid_serial, layout_serial); a synthesis with the same key does not store them again
+    long zero_key[6] = {0, -1, -1, -1, -1, -1};
     ml::DevBuf x_pts, y_pts, partial_power, power, violations;
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see row_extent_kernel; valid only for synthesised fields

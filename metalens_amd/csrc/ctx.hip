@@ -459,6 +459,17 @@ int ml_device_info(ml_ctx *ctx, char *name, int name_len, int *cu_count, int64_t
     return ML_OK;
 }
 
+int ml_host_alloc(uint64_t bytes, void **ptr) {
+    ML_REQUIRE(ptr && bytes > 0, "bad argument");
+    ML_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return ML_OK;
+}
+
+int ml_host_free(void *ptr) {
+    if (ptr) ML_HIP(hipHostFree(ptr));
+    return ML_OK;
+}
+
 int ml_sync(ml_ctx *ctx) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_HIP(hipSetDevice(ctx->device));
@@ -931,7 +942,8 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
     ctx->ny = ny;
     ctx->n_sets = 1;
     ctx->field_set = 0;
-    ctx->row_first_valid = false;   // caller-supplied fields: nothing known about zeros
+    ctx->zero_key[1] = -1;          // caller-supplied fields: nothing known about zeros
+    ctx->row_first_valid = false;
     return ML_OK;
 }
 

@@ -79,6 +79,9 @@ struct NfArgs {
     double2 *geo_ab;   // [nx][ny]
     int2 *geo_ix;      // [nx][ny]
     // outputs
+    // outside_is_zero: the samples outside the lens already hold zeros in `fields` (the previous
+    // launch wrote them for the same grid, layout and buffer) and are not stored again
+    int outside_is_zero;
     double *fields;
     double *partial_power;
     int *row_first;   // per aperture row: smallest min(j, ny-1-j) over samples inside the lens
@@ -386,11 +389,13 @@ __device__ __forceinline__ void store_fields(const NfArgs &a, int member, int i,
     // 16 B per lane per plane, coalesced along y; field set `member` = 4 planes
     const size_t plane = (size_t)a.nx * a.ny;
     const size_t at = (size_t)i * a.ny + j;
-    double2 *F = reinterpret_cast<double2 *>(a.fields) + (size_t)member * 4 * plane;
-    F[at] = make_double2(Ex.r, Ex.i);
-    F[plane + at] = make_double2(Ey.r, Ey.i);
-    F[2 * plane + at] = make_double2(Hx.r, Hx.i);
-    F[3 * plane + at] = make_double2(Hy.r, Hy.i);
+    // streamed (non-temporal): 64 B per sample that this kernel never reads again
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    double2v *F = reinterpret_cast<double2v *>(a.fields) + (size_t)member * 4 * plane;
+    __builtin_nontemporal_store((double2v){Ex.r, Ex.i}, F + at);
+    __builtin_nontemporal_store((double2v){Ey.r, Ey.i}, F + plane + at);
+    __builtin_nontemporal_store((double2v){Hx.r, Hx.i}, F + 2 * plane + at);
+    __builtin_nontemporal_store((double2v){Hy.r, Hy.i}, F + 3 * plane + at);
 }
 
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a);

@@ -268,6 +268,22 @@ __device__ __forceinline__ void order_apply(Acc &acc, const OrderCommon &oc, dou
     acc.Ey.i += fma(oc.cyy, vy_i, -oc.cxy * vx_i);
 }
 
+// Diagnostic build (-DML_PHASE_TIMERS, tools/nearfield_phase_timers.py): every wave of the field
+// kernel stamps s_memtime at fixed points; `dep` is a value that must have arrived by then.
+#ifdef ML_PHASE_TIMERS
+constexpr int PHASE_SLOTS = 10, PHASE_WAVES = 1 << 18;
+__device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
+#define ML_MARK(k, dep)                                   \
+    do {                                                  \
+        asm volatile("" ::"v"(dep));                      \
+        __builtin_amdgcn_sched_barrier(0);                \
+        stamp[k] = __builtin_amdgcn_s_memtime();          \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#else
+#define ML_MARK(k, dep)
+#endif
+
 // ---- kernel 1 of 2: the source-INDEPENDENT decisions of every sample ---------------------------
 // Ring (nearfield.py:125-128), sector and rotated local coordinates (:169,200-201), nearest
 // centre cell (:363-367) depend on the sample grid and the layout only.  They are evaluated once
@@ -364,11 +380,20 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
     const size_t at = (size_t)i * a.ny + j;
     int idx = a.n_rings + 1, aux = -1;
     double ga = 0.0, gb = 0.0;
+#ifdef ML_PHASE_TIMERS
+    unsigned long long stamp[PHASE_SLOTS] = {0};
+    stamp[0] = __builtin_amdgcn_s_memtime();
+#endif
+    // the sample's coordinates do not wait for its record
+    const double x_ld = a.x_pts[min(i, a.nx - 1)], y_ld = a.y_pts[min(j, a.ny - 1)];
     if (inb) {
         if (RECORDS) {
-            // both records at once (the second does not wait for the first)
-            const int2 ix = a.geo_ix[at];
-            const double2 ab = a.geo_ab[at];
+            // both records at once (the second does not wait for the first); streamed: they are
+            // read once per launch and must not push the ring tables out of the L2
+            typedef int int2v __attribute__((ext_vector_type(2)));
+            typedef double double2v __attribute__((ext_vector_type(2)));
+            const int2v ix = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(a.geo_ix) + at);
+            const double2v ab = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a.geo_ab) + at);
             idx = ix.x;
             aux = ix.y;
             ga = ab.x;
@@ -377,6 +402,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
             sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
         }
     }
+    ML_MARK(1, idx + (int)ga);
     const bool lens = idx <= a.n_rings;
     const bool peri = lens && idx >= 1;
     const double inv_n = recip(p.n_glass);
@@ -396,8 +422,8 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
 #pragma unroll
         for (int m = 0; m < NP; ++m) Hx_i[m] = Hy_i[m] = 0.0;
         if (lens) {
-            x = a.x_pts[i];
-            y = a.y_pts[j];
+            x = x_ld;
+            y = y_ld;
         }
         // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
         // arithmetic)
@@ -432,6 +458,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
             }
             wave_power(a, power_here, by, m);
         }
+        ML_MARK(2, Hx_i[0]);
 
         if (lens && !peri) {
             // ================= centre: the record holds the nearest hexagonal cell =================
@@ -498,7 +525,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
 #pragma unroll
             for (int m = 0; m < NP; ++m)
                 store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
-        } else if (inb && !lens) {
+        } else if (inb && !lens && !a.outside_is_zero) {
             const c2 zero = {0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
@@ -539,6 +566,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
             key = (T.n0 > 64 || T.n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
         }
     }
+    ML_MARK(3, t0 + t1 + (double)key);
     // ================= periphery: order loop over LDS-staged table blocks =================
     Acc pr[NP];
 #pragma unroll
@@ -564,24 +592,33 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
         for (int o0 = 0; o0 < MAX_ORDERS; o0 += NF_CHUNK) {
             if (!__any(myslot >= 0 && o0 < n_orders)) break;
             // stage: lane e of the wave fetches (order o0 + e / 16, node (e / 4) % 4, amplitude e % 4)
-            // of the block owner's table position
+            // of the block owner's table position.  All loads first, then all LDS writes: written
+            // slot by slot the compiler waits for each load before it issues the next (one L2
+            // round trip per block instead of one for all of them).
+            double2 val[NF_SLOTS];
+            bool have[NF_SLOTS];
+            {
+                const int o = o0 + (lane >> 4), c = (lane >> 2) & 3, q = lane & 3;
 #pragma unroll
-            for (int s = 0; s < NF_SLOTS; ++s) {
-                if (lead[s] >= 0) {   // wave-uniform
+                for (int s = 0; s < NF_SLOTS; ++s) {
+                    const int l = max(lead[s], 0);   // wave-uniform
                     const unsigned long long bits = (unsigned long long)node00;
-                    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, lead[s]);
-                    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lead[s]);
-                    const int so = __builtin_amdgcn_readlane(stride_o, lead[s]);
-                    const int s0 = __builtin_amdgcn_readlane(stride0, lead[s]);
-                    const int no = __builtin_amdgcn_readlane(n_orders, lead[s]);
+                    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, l);
+                    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), l);
+                    const int so = __builtin_amdgcn_readlane(stride_o, l);
+                    const int s0 = __builtin_amdgcn_readlane(stride0, l);
+                    const int no = lead[s] >= 0 ? __builtin_amdgcn_readlane(n_orders, l) : 0;
                     const double2 *base = reinterpret_cast<const double2 *>(((unsigned long long)hi << 32) | lo);
-                    const int o = o0 + (lane >> 4), c = (lane >> 2) & 3, q = lane & 3;
-                    if (o < no)
-                        s_tab[s * NF_PITCH + lane] =
-                            base[(long long)o * so + (c >> 1) * s0 + (c & 1) * 4 + q];
+                    have[s] = o < no;
+                    val[s] = have[s] ? base[(long long)o * so + (c >> 1) * s0 + (c & 1) * 4 + q]
+                                     : make_double2(0.0, 0.0);
                 }
+#pragma unroll
+                for (int s = 0; s < NF_SLOTS; ++s)
+                    if (have[s]) s_tab[s * NF_PITCH + lane] = val[s];
             }
             __syncthreads();
+            ML_MARK(4, s_tab[lane].x);
             if (myslot >= 0) {
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
                 for (int o = o0; o < o1; ++o) {
@@ -605,6 +642,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
             __syncthreads();   // the next pass overwrites the blocks
         }
     }
+    ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
     if (peri) {
         const double2 cs = a.rot_table[aux];
         const double cosr = cs.x, sinr = cs.y, rcen = a.rc[idx - 1];
@@ -637,10 +675,31 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
             const c2 Ey = {fma(q.Ex.r, sinr, q.Ey.r * cosr), fma(q.Ex.i, sinr, q.Ey.i * cosr)};
             const c2 Hx = {fma(q.Hx.r, cosr, -q.Hy.r * sinr), fma(q.Hx.i, cosr, -q.Hy.i * sinr)};
             const c2 Hy = {fma(q.Hx.r, sinr, q.Hy.r * cosr), fma(q.Hx.i, sinr, q.Hy.i * cosr)};
+#ifdef ML_PHASE_TIMERS
+            if (m == 0) ML_MARK(6, Ex.r + Hy.i);
+#endif
             store_fields(a, m, i, j, Ex, Ey, Hx, Hy);
         }
     }
+#ifdef ML_PHASE_TIMERS
+    stamp[7] = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0);   // the stores have left the wave
+    stamp[8] = __builtin_amdgcn_s_memtime();
+    const size_t wid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (lane == 0 && wid < PHASE_WAVES) {
+        stamp[9] = (unsigned long long)__ballot(true);
+        for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = stamp[k];
+    }
+#endif
 }
+
+#ifdef ML_PHASE_TIMERS
+extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase),
+                                    n_waves * PHASE_SLOTS * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
 
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);

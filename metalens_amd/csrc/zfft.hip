@@ -57,38 +57,61 @@ __device__ __forceinline__ zf::Geo geo_of(const FftArgs &a) {
     return g;
 }
 
-// R3T > 0: residues known at compile time (the div / mod by R3 become shifts), R3T == 0: any R3
+// one row's 16 samples of thread `tid` (coalesced: lane l reads element l + NT n2)
+template <int R3T>
+__device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int row, int tid, cd *v) {
+    const int NT = 16 * g.R3;
+    const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2;
+    const int first = a.row_first ? a.row_first[row % a.rf_mod] : 0;
+#pragma unroll
+    for (int n2 = 0; n2 < 16; ++n2) {
+        const int n = tid + NT * n2;
+        int q = -1;
+        if (n >= a.a0 && n < a.a0 + a.h0) q = n - a.a0;
+        if (n >= a.a1 && n < a.a1 + a.h1) q = a.h0 + n - a.a1;
+        if (min(n, g.n_valid - 1 - n) < first) q = -1;
+        v[n2] = q >= 0 ? src[q * a.in_es] : zf::mk(0.0, 0.0);
+    }
+}
+
+// R3T > 0: residues known at compile time (the div / mod by R3 become shifts), R3T == 0: any R3.
+// The next row's loads are issued before the current row's arithmetic (its 16 values wait in a
+// second register set), so a workgroup always has a row in flight; the stage-1 twiddles live in
+// LDS ([k2][n1]: the lanes of a 16-lane group read neighbouring or equal slots) to pay for it.
 template <int R3T, int NTMAX, int MINW>
 __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
     cd *lds = reinterpret_cast<cd *>(zfft_lds_raw);
     const zf::Geo g = geo_of<R3T>(a);
     const int NT = 16 * g.R3, tid = threadIdx.x;
-
-    // per-thread constants: the stage-1 twiddles of n1 = tid / R3
-    cd tw1[16];
-    {
-        const int n1 = tid / g.R3;
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) tw1[k2] = a.tw1[n1 * 16 + k2];
+    cd *s_tw = lds + zf::lds_elems(g);   // [16][16] behind the exchange buffer
+    for (int e = tid; e < 256; e += NT) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];   // e = n1 * 16 + k2
+    const int n1 = tid / g.R3;
+    // the (up to two) bins this thread evaluates in stage 3 are the same for every row
+    const bool own0 = tid < g.M, own1 = tid + NT < g.M, few = g.M <= 2 * NT;
+    cd w0 = zf::mk(0, 0), p0 = w0, w1 = w0, p1 = w0;
+    int k0 = 0, k1 = 0;
+    if (own0) {
+        w0 = a.wk[tid];
+        p0 = a.pj[tid];
+        k0 = a.kbin[tid];
     }
-    const int xcd = blockIdx.x & 7;
-    for (int idx = blockIdx.x >> 3; idx < a.chunk; idx += gridDim.x >> 3) {
-        const int row = xcd * a.chunk + idx;   // block-uniform
-        if (row >= a.rows) break;
-        const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2;
-        const int first = a.row_first ? a.row_first[row % a.rf_mod] : 0;
-        cd v[16];
-#pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) {
-            const int n = tid + NT * n2;
-            int q = -1;
-            if (n >= a.a0 && n < a.a0 + a.h0) q = n - a.a0;
-            if (n >= a.a1 && n < a.a1 + a.h1) q = a.h0 + n - a.a1;
-            if (min(n, g.n_valid - 1 - n) < first) q = -1;
-            v[n2] = q >= 0 ? src[q * a.in_es] : zf::mk(0.0, 0.0);
-        }
-        zf::stage1(g, tid, v, tw1, lds);
+    if (own1) {
+        w1 = a.wk[tid + NT];
+        p1 = a.pj[tid + NT];
+        k1 = a.kbin[tid + NT];
+    }
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+    int idx = blockIdx.x >> 3;
+    int row = xcd * a.chunk + idx;   // block-uniform
+    cd v[16], nx[16];
+    if (idx < a.chunk && row < a.rows) load_row<R3T>(a, g, row, tid, v);
+    while (idx < a.chunk && row < a.rows) {
+        const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
+        const bool more = idx_n < a.chunk && row_n < a.rows;
+        if (more) load_row<R3T>(a, g, row_n, tid, nx);
+        zf::stage1(g, tid, v, s_tw + n1, 16, lds);
         __syncthreads();
         zf::gather2(g, tid, v, lds);
         __syncthreads();
@@ -96,16 +119,39 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
         const double al = a.alpha[row / a.alpha_rb];
-        for (int o = tid; o < g.M; o += NT) {
-            const cd w = a.wk[o], p = a.pj[o];
-            cd x = zf::cmul(zf::stage3(g, a.kbin[o], w, lds), p);
-            x.x *= al;
-            x.y *= al;
-            cd *d = dst + o * a.out_es;
-            if (a.accumulate) x = zf::cadd(x, *d);
-            *d = x;
+        if (few) {
+            if (own0) {
+                cd x = zf::cmul(zf::stage3(g, k0, w0, lds), p0);
+                x.x *= al;
+                x.y *= al;
+                cd *d = dst + tid * a.out_es;
+                if (a.accumulate) x = zf::cadd(x, *d);
+                *d = x;
+            }
+            if (own1) {
+                cd x = zf::cmul(zf::stage3(g, k1, w1, lds), p1);
+                x.x *= al;
+                x.y *= al;
+                cd *d = dst + (tid + NT) * a.out_es;
+                if (a.accumulate) x = zf::cadd(x, *d);
+                *d = x;
+            }
+        } else {
+            for (int o = tid; o < g.M; o += NT) {
+                const cd w = a.wk[o], p = a.pj[o];
+                cd x = zf::cmul(zf::stage3(g, a.kbin[o], w, lds), p);
+                x.x *= al;
+                x.y *= al;
+                cd *d = dst + o * a.out_es;
+                if (a.accumulate) x = zf::cadd(x, *d);
+                *d = x;
+            }
         }
         __syncthreads();   // the next row's stage 1 overwrites the buffer
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = nx[n2];
+        idx = idx_n;
+        row = row_n;
     }
 }
 
@@ -221,7 +267,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     a.rows = c.rows;
     a.accumulate = c.accumulate;
     a.chunk = (c.rows + 7) / 8;
-    const size_t lds_bytes = (size_t)zf::lds_elems(a.g) * sizeof(cd);
+    const size_t lds_bytes = ((size_t)zf::lds_elems(a.g) + 256) * sizeof(cd);   // exchange buffer + twiddles
     // workgroups resident per CU (LDS-limited), 256 CUs; a multiple of 8 so that a workgroup
     // stays on the rows of one XCD
     const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds_bytes));

@@ -118,13 +118,13 @@ ZF_HD int bin_of(const Geo &g, int j) {
 }
 
 // ---- the phases, one thread each -------------------------------------------------------------
-// stage 1 on the 16 samples v[n2] of thread t: butterflies, the W_256^(n1 k2) twiddles (tw1[k2],
-// per-thread constants), result to exchange 1
-ZF_HD void stage1(const Geo &g, int t, cd *v, const cd *tw1, cd *lds) {
+// stage 1 on the 16 samples v[n2] of thread t: butterflies, the W_256^(n1 k2) twiddles
+// (tw1[k2 * tw_stride]: a table of this thread's n1, read where it is used), result to exchange 1
+ZF_HD void stage1(const Geo &g, int t, cd *v, const cd *tw1, int tw_stride, cd *lds) {
     dft16(v);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
-        const cd a = k2 == 0 ? v[bin16(0)] : cmul(v[bin16(k2)], tw1[k2]);
+        const cd a = k2 == 0 ? v[bin16(0)] : cmul(v[bin16(k2)], tw1[k2 * tw_stride]);
         lds[ex1_addr(g, t, k2)] = a;
     }
 }

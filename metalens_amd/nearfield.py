@@ -158,7 +158,8 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
     power_passing_through_lens = power.value * (x_pts[1] - x_pts[0]) * (y_pts[1] - y_pts[0])
     if not download:
         return None, None, None, None, x_pts, y_pts, power_passing_through_lens, n_glass
-    out = [np.empty((xs.size, ys.size), dtype=np.complex128) for _ in range(4)]
+    # page-locked storage (recycled through _lib.pinned): the copy runs at the PCIe rate
+    out = [_lib.pinned.empty((xs.size, ys.size), np.complex128) for _ in range(4)]
     _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(a) for a in out]))
     return out[0], out[1], out[2], out[3], x_pts, y_pts, power_passing_through_lens, n_glass
 

@@ -752,6 +752,37 @@ def test_nearest_cell_on_irregular_cell_sets(ma, kind):
         assert flips == 0 and err < TOL
 
 
+def test_zeros_outside_the_lens_survive_repeated_synthesis(ma):
+    """Samples outside the lens are zero whatever the source; the synthesis stores them once per
+    (buffer, grid, layout) and skips them afterwards.  Repeated calls, another source, and a
+    buffer that somebody else has written in between (ml_fields_upload) must all still return
+    exact zeros there and the oracle's field inside."""
+    from metalens_amd import _lib
+    from oracle import nearfield_oracle
+    wl = 580e-9
+    lens = _synthetic_lens(30e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    x = np.linspace(-1.3 * R, 1.3 * R, 320)          # a window well beyond the lens
+    common = (wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'])
+    ctx = _lib.Context(0)
+    try:
+        outside = np.hypot(x[:, None], x[None, :]) > R
+        assert outside.sum() > 0.3 * outside.size
+        srcs = [(0.0, 0.0, -lens['source_distance'], 'x')] * 2 + [(0.4e-6, -0.3e-6, -0.98 * lens['source_distance'], 'y')]
+        for k, src in enumerate(srcs + srcs[:1]):
+            if k == 3:   # garbage into the resident buffer: the next synthesis must not trust it
+                junk = [np.full((x.size, x.size), 7.0 + 1j, dtype=np.complex128) for _ in range(4)]
+                _lib.check(ctx.lib.ml_fields_upload(ctx.handle, x.size, x.size, *[_lib.dptr(a) for a in junk]))
+            got = ma.build_nearfield(*src, *common, x_pts=x, y_pts=x, ctx=ctx)
+            want = nearfield_oracle.build_nearfield(*src, *common, x_pts=x, y_pts=x)
+            for g, w in zip(got[:4], want[:4]):
+                assert not g[outside].any()
+                err, flips = field_errors(g, w)
+                assert flips == 0 and err < TOL, (k, err, flips)
+    finally:
+        ctx.close()
+
+
 def test_reordered_cells_on_one_context_are_a_new_layout(ma):
     """The resident layout is keyed by a content hash of every packed array.  The same cells in
     another ORDER are another layout - tie answers (cKDTree row indices) and the bin-sorted cell

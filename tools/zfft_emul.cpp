@@ -29,7 +29,7 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose) {
             tw1[k2] = zf::mk((double)cosl(a), (double)sinl(a));
         }
         for (int n2 = 0; n2 < 16; ++n2) v[t][n2] = in[t + NT * n2];
-        zf::stage1(g, t, v[t].data(), tw1, lds.data());
+        zf::stage1(g, t, v[t].data(), tw1, 1, lds.data());
     }
     for (int u = 0; u < NT; ++u) zf::gather2(g, u, v[u].data(), lds.data());
     for (int u = 0; u < NT; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
