@@ -270,8 +270,9 @@ struct ml_ctx {
     long ovr_serial = 0;                    // bumped whenever the override list changes
     // per-sample geometry records (nearfield_fast.hip) and what they were built for:
     // (grid_serial, layout_serial, ovr_serial, samples)
-    ml::DevBuf geo_ab, geo_ix;
+    ml::DevBuf geo_ab, geo_ix, active_list, active_count;
     long geo_key[4] = {-1, -1, -1, -1};
+    int n_active = -1;   // patches with lens samples; -1: not read back yet
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores

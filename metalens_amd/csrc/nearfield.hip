@@ -154,6 +154,11 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.ring_ok_off = ctx->ring_ok_off.as<int>();
     a.geo_ab = ctx->geo_ab.as<double2>();
     a.geo_ix = ctx->geo_ix.as<int2>();
+    a.active_list = ctx->active_list.as<int2>();
+    a.active_count = ctx->active_count.as<int>();
+    a.use_active = 0;
+    a.n_active = 0;
+    a.patches_x = (ny + 7) / 8;
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
     a.row_first = ctx->row_first.as<int>();
@@ -191,8 +196,11 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     } else if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
         ProfScope scope(ctx, ML_K_TWIDDLE);
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
+        ML_HIP(hipMemsetAsync(ctx->active_count.p, 0, sizeof(int), ctx->stream));
         ML_TRY(nearfield_geometry_launch(ctx, a));
         memcpy(ctx->geo_key, geo_key, sizeof geo_key);
+        ctx->n_active = -1;
+        ctx->zero_key[1] = -1;   // every patch is visited (and its zeros stored) once more
     }
     // samples outside the lens are zero whatever the source: stored by the first synthesis into
     // this buffer for this geometry, skipped afterwards (27 % of the stores of a 4096^2 window
@@ -200,6 +208,21 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     const long zero_key[6] = {(long)(intptr_t)ctx->fields.p, (long)ctx->fields.bytes, n, (long)nx * ny,
                               ctx->grid_serial, ctx->layout_serial};
     a.outside_is_zero = !plan_cache_disabled() && memcmp(zero_key, ctx->zero_key, sizeof zero_key) == 0;
+    if (a.outside_is_zero && nf_mode != 1) {
+        // ... and then only the patches that hold lens samples are launched at all.  Their
+        // number comes back from the GPU once per geometry (a 4-byte copy, one synchronisation);
+        // the power partials of the others stay at the zeros written here.
+        if (ctx->n_active < 0) {
+            ML_HIP(hipMemcpyAsync(&ctx->n_active, ctx->active_count.p, sizeof(int), hipMemcpyDeviceToHost,
+                                  ctx->stream));
+            ML_HIP(hipMemsetAsync(ctx->partial_power.p, 0, ctx->partial_power.bytes, ctx->stream));
+            ML_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        if (ctx->n_active > 0) {
+            a.use_active = 1;
+            a.n_active = ctx->n_active;
+        }
+    }
     {
         ProfScope scope(ctx, ML_K_NEARFIELD);
         ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));

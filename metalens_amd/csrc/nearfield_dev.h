@@ -78,6 +78,11 @@ struct NfArgs {
     // per-sample geometry records (nearfield_fast.hip, kernel 1 writes, kernel 2 reads)
     double2 *geo_ab;   // [nx][ny]
     int2 *geo_ix;      // [nx][ny]
+    // 8 x 8 patches that hold at least one lens sample (written by kernel 1); use_active: the
+    // field kernel's grid is that list (n_active entries) instead of all patches
+    int2 *active_list;
+    int *active_count;
+    int use_active, n_active, patches_x;
     // outputs
     // outside_is_zero: the samples outside the lens already hold zeros in `fields` (the previous
     // launch wrote them for the same grid, layout and buffer) and are not stored again
@@ -376,11 +381,12 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
 }
 
 // incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream
-__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int by, int member) {
+__device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int bx, int by, int member) {
     for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
     if (threadIdx.x == 0)
-        a.partial_power[(size_t)member * a.n_partials + (size_t)by * gridDim.x + blockIdx.x] = power_here;
-    if (blockIdx.x == 0 && by == 0 && member == 0)
+        a.partial_power[(size_t)member * a.n_partials + (size_t)by * a.patches_x + bx] = power_here;
+    // (workgroup 0 exists in the full and in the listed grid alike)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && member == 0)
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
 }
 

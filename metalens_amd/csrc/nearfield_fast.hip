@@ -346,13 +346,19 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.y * 8 + (lane >> 3);
     const int j = blockIdx.x * 8 + (lane & 7);
-    if (j >= a.ny || i >= a.nx) return;
-    const size_t at = (size_t)i * a.ny + j;
-    int idx, aux;
-    double ga, gb;
-    sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
-    a.geo_ab[at] = make_double2(ga, gb);
-    a.geo_ix[at] = make_int2(idx, aux);
+    int idx = a.n_rings + 1, aux = -1;
+    if (j < a.ny && i < a.nx) {
+        const size_t at = (size_t)i * a.ny + j;
+        double ga, gb;
+        sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
+        a.geo_ab[at] = make_double2(ga, gb);
+        a.geo_ix[at] = make_int2(idx, aux);
+    }
+    // patches with at least one sample inside the lens: the field kernel visits only these once
+    // the zeros of the others are in place (their order in the list does not matter: every
+    // result is indexed by the patch itself)
+    if (__any(idx <= a.n_rings) && lane == 0)
+        a.active_list[atomicAdd(a.active_count, 1)] = make_int2(blockIdx.x, blockIdx.y);
 }
 
 // ---- kernel 2 of 2: fields from the records ----------------------------------------------------
@@ -373,9 +379,16 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
     __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];
     const int lane = threadIdx.x & 63;
     const ml_nearfield_params &p = a.p;
-    const int by = blockIdx.y;
+    // patch of this wave: the whole grid, or (once the zeros outside the lens are in place) the
+    // list of patches that hold lens samples
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.use_active) {
+        const int2 pb = a.active_list[blockIdx.x];
+        bx = pb.x;
+        by = pb.y;
+    }
     const int i = by * 8 + (lane >> 3);                       // x index
-    const int j = blockIdx.x * 8 + (lane & 7);                // y index (fastest in memory)
+    const int j = bx * 8 + (lane & 7);                        // y index (fastest in memory)
     const bool inb = j < a.ny && i < a.nx;
     const size_t at = (size_t)i * a.ny + j;
     int idx = a.n_rings + 1, aux = -1;
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
                 }
                 power_here = Ex_i * Hy_i[m] - Ey_i * Hx_i[m];
             }
-            wave_power(a, power_here, by, m);
+            wave_power(a, power_here, bx, by, m);
         }
         ML_MARK(2, Hx_i[0]);
 
@@ -712,8 +725,9 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     // one wave (= one workgroup) per 8 x 8 patch.  A wave that walks several patches so that its
     // stores drain under the next patch's arithmetic was tried: the loop costs registers the
     // kernel does not have (spills) and ran 25-40 % slower.
-    const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
-    *n_partials = (int)(grid.x * grid.y);
+    const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
+    *n_partials = (int)(full.x * full.y);
+    const dim3 grid = a.use_active ? dim3(a.n_active) : full;
     if (!a.geo_ix)   // diagnostic build only: decisions inline, no records
         hipLaunchKernelGGL((nearfield_field_kernel<false, 1>), grid, dim3(64), 0, ctx->stream, a);
     else if (a.n_pol == 1)
