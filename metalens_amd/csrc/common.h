@@ -110,6 +110,13 @@ struct TableDesc {
     double ax0[PACKED_AXIS], inv0[PACKED_AXIS], ax1[PACKED_AXIS], inv1[PACKED_AXIS];
 };
 
+// Everything the field kernel needs to know about a periphery sample's RING, in one 160-byte
+// record (one round trip instead of ring -> collection -> table descriptor):
+//   [0] r_center  [1] period  [2..7] table bounds  [8..13] uniform (ux, uy) axes: first, step,
+//   1/step per axis  [14] (n0, n1)  [15] (n_orders, flags: bit 0 = axes uniform)
+//   [16] offset of the ring's table in ring_tab  [17] (offset in ring_ok, collection)  [18..19] -
+constexpr int RING_HDR = 20;
+
 struct TableSlot {
     bool present = false;
     int n0 = 0, n1 = 0, n2 = 0, n_orders = 0;
@@ -228,10 +235,12 @@ struct ml_ctx {
     // layout
     bool have_layout = false;
     int n_rings = 0, n_cells = 0;
-    std::vector<double> h_ring_period, h_ring_lateral;
+    std::vector<double> h_ring_period, h_ring_lateral, h_ring_rc;
     std::vector<int32_t> h_ring_gc;
     ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
     ml::DevBuf rot_table, tie_table, ring_rot_center, ring_rot_half;
+    ml::DevBuf ring_hdr;                                       // RING_HDR doubles per ring, see ctx.hip
+    std::vector<ml::TableDesc> h_table_desc;                   // host copy of table_desc
     ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables
     ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary

@@ -123,6 +123,7 @@ static int refresh_table_desc(ml_ctx *ctx) {
     }
     ML_TRY(h2d(ctx, ctx->table_desc, h.data(), h.size() * sizeof(TableDesc)));
     ctx->h_center_desc = h[MAX_SLOTS];
+    ctx->h_table_desc = h;
     ML_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
     ctx->tables_dirty = false;
     return ML_OK;
@@ -179,6 +180,25 @@ static int refresh_ring_locations(ml_ctx *ctx) {
             ok[ok_off[r] + 2 * o + 1] = t.h_order_k[2 * o + 1] / ctx->h_ring_lateral[r];
         }
     }
+    // per-ring headers (common.h RING_HDR)
+    std::vector<double> hdr((size_t)ctx->n_rings * RING_HDR, 0.0);
+    for (int r = 0; r < ctx->n_rings; ++r) {
+        const int slot = ctx->h_ring_gc[r];
+        const TableSlot &t = ctx->slots[slot];
+        const TableDesc &d = ctx->h_table_desc[slot];
+        double *q = hdr.data() + (size_t)r * RING_HDR;
+        q[0] = ctx->h_ring_rc[r];
+        q[1] = ctx->h_ring_period[r];
+        for (int k = 0; k < 6; ++k) q[2 + k] = t.bounds[k];
+        for (int k = 0; k < 6; ++k) q[8 + k] = d.uni_ax[k];
+        const int32_t i14[2] = {t.n0, t.n1}, i15[2] = {t.n_orders, d.uniform ? 1 : 0};
+        const int32_t i17[2] = {ok_off[r], slot};
+        memcpy(q + 14, i14, 8);
+        memcpy(q + 15, i15, 8);
+        memcpy(q + 16, &tab_off[r], 8);
+        memcpy(q + 17, i17, 8);
+    }
+    ML_TRY(h2d(ctx, ctx->ring_hdr, hdr.data(), hdr.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_tab, tab.data(), tab.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_tab_off, tab_off.data(), tab_off.size() * sizeof(long long)));
     ML_TRY(h2d(ctx, ctx->ring_ok, ok.data(), ok.size() * sizeof(double)));
@@ -427,7 +447,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     ctx->center.order_k.release();
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
-                      &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
+                      &ctx->ring_hdr, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
@@ -548,6 +568,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     ML_TRY(h2d(ctx, ctx->ring_rot_center, ring_rot_center, n_rings * sizeof(int32_t)));
     ML_TRY(h2d(ctx, ctx->ring_rot_half, ring_rot_half, n_rings * sizeof(int32_t)));
     ctx->h_ring_period.assign(period, period + n_rings);
+    ctx->h_ring_rc.assign(r_center, r_center + n_rings);
     ctx->h_ring_lateral.assign(lateral, lateral + n_rings);
     ctx->h_ring_gc.assign(ring_gc, ring_gc + n_rings);
 

@@ -148,6 +148,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.lat_nb = ctx->lat_nb;
     a.tables = ctx->table_desc.as<TableDesc>();
     a.center_desc = ctx->h_center_desc;
+    a.ring_hdr = ctx->ring_hdr.as<double2>();
     a.ring_tab = ctx->ring_tab.as<double2>();
     a.ring_tab_off = ctx->ring_tab_off.as<long long>();
     a.ring_ok = ctx->ring_ok.as<double>();

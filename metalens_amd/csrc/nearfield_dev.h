@@ -71,6 +71,7 @@ struct NfArgs {
     // per-ring tables for the fast kernel: period axis already interpolated, complex
     // [order][n0][n1][4] per ring at ring_tab + ring_tab_off[ring]; per-ring order
     // wavenumbers (ox*2*pi/period, oy*2*pi/lateral) at ring_ok + ring_ok_off[ring]
+    const double2 *ring_hdr;   // [n_rings][RING_HDR / 2], common.h
     const double2 *ring_tab;
     const long long *ring_tab_off;
     const double *ring_ok;

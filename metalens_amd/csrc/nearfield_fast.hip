@@ -547,15 +547,19 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
         // ================= periphery: set-up =================
         if (peri) {
             const int ring = idx - 1;
-            // everything that depends on the ring alone, in one batch
-            const int slot = a.gc[ring];
-            const double period = a.period[ring];
-            ok = a.ring_ok + a.ring_ok_off[ring];
-            const double2 *tab = a.ring_tab + a.ring_tab_off[ring];
+            // everything that depends on the ring alone comes from ONE record (common.h RING_HDR):
+            // nine independent 16-byte loads, one round trip
+            const double2 *h = a.ring_hdr + (size_t)ring * (RING_HDR / 2);
+            const double2 h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6],
+                          h7 = h[7], h8 = h[8];
             const double2 cs = a.rot_table[aux];
-            const TableDesc &T = a.tables[slot];
-            const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3],
-                         b4 = T.bounds[4], b5 = T.bounds[5];
+            const double period = h0.y;
+            const int n0 = (int)(__double_as_longlong(h7.x) & 0xffffffffll), n1 = (int)(__double_as_longlong(h7.x) >> 32);
+            const int flags = (int)(__double_as_longlong(h7.y) >> 32);
+            const long long tab_off = __double_as_longlong(h8.x);
+            const int ok_off = (int)(__double_as_longlong(h8.y) & 0xffffffffll);
+            n_orders = (int)(__double_as_longlong(h7.y) & 0xffffffffll);
+            ok = a.ring_ok + ok_off;
             const double cosr = cs.x, sinr = cs.y;
             uxp = fma(ux, cosr, uy * sinr);
             uyp = fma(uy, cosr, -ux * sinr);
@@ -565,21 +569,32 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
                 Hw_x[m] = fma(Hy_i[m], cosr, -Hx_i[m] * sinr);   // H along y' <-> x table
             }
             int i0, i1;
-            locate_uv(T, uxp, uyp, i0, t0, i1, t1);
-            n_orders = T.n_orders;
-            stride0 = T.n1 * 4;
-            stride_o = T.n0 * T.n1 * 4;
-            node00 = tab + i0 * stride0 + i1 * 4;
+            if (flags & 1) {
+                // uniformly spaced axes (what characterize() produces): the cell by arithmetic, as
+                // locate_uv does; header = first0, step0, 1/step0, first1, step1, 1/step1
+                const double a0 = (uxp - h4.x) * h5.x, a1 = (uyp - h5.y) * h6.y;
+                const double f0 = fmin(fmax(floor(a0), 0.0), (double)(n0 - 2));
+                const double f1 = fmin(fmax(floor(a1), 0.0), (double)(n1 - 2));
+                i0 = (int)f0;
+                i1 = (int)f1;
+                t0 = (uxp - fma(f0, h4.y, h4.x)) * h5.x;
+                t1 = (uyp - fma(f1, h6.x, h5.y)) * h6.y;
+            } else {
+                const int slot = (int)(__double_as_longlong(h8.y) >> 32);
+                locate_uv(a.tables[slot], uxp, uyp, i0, t0, i1, t1);
+            }
+            stride0 = n1 * 4;
+            stride_o = n0 * n1 * 4;
+            node00 = a.ring_tab + tab_off + i0 * stride0 + i1 * 4;
             // the table-bound tests do not depend on the order: evaluate them once, and only take
             // the reporting path (per order, in the reference's check order) on failure
-            outside = (int)(uxp < b0) | (int)(uxp > b1) | (int)(uyp < b2) | (int)(uyp > b3) |
-                      (int)(period < b4) | (int)(period > b5);
+            outside = (int)(uxp < h1.x) | (int)(uxp > h1.y) | (int)(uyp < h2.x) | (int)(uyp > h2.y) |
+                      (int)(period < h3.x) | (int)(period > h3.y);
             // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
             // block per lane (still correct, just not shared)
-            key = (T.n0 > 64 || T.n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
+            key = (n0 > 64 || n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
         }
     }
-    ML_MARK(3, t0 + t1 + (double)key);
     // ================= periphery: order loop over LDS-staged table blocks =================
     Acc pr[NP];
 #pragma unroll
