@@ -429,6 +429,19 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
     const double *ok = a.ring_ok;
     const double2 *node00 = a.ring_tab;
     bool outside = false;
+    // the ring's header and rotation, requested as soon as the record is there: they travel
+    // while the incident field is worked out
+    // (its first and last 16 bytes: the 160-byte record spans two cache lines, which are then in
+    // the L1 when the rest is read; holding all of it across the incident field costs registers
+    // the kernel does not have)
+    double2 h0 = {0, 0}, h8 = h0, cs = {1.0, 0.0};
+    if (peri) {
+        const double2 *h = a.ring_hdr + (size_t)(idx - 1) * (RING_HDR / 2);
+        h0 = h[0];
+        h8 = h[8];
+        cs = a.rot_table[aux];
+    }
+    c2 prop = {1.0, 0.0};   // exp(i k |grating centre - source|) x the plan's column phasor
     {
         double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 1.0;
         double Hx_i[NP], Hy_i[NP];
@@ -547,12 +560,10 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
         // ================= periphery: set-up =================
         if (peri) {
             const int ring = idx - 1;
-            // everything that depends on the ring alone comes from ONE record (common.h RING_HDR):
-            // nine independent 16-byte loads, one round trip
+            // everything that depends on the ring alone comes from ONE record (common.h RING_HDR),
+            // whose two cache lines were requested above
             const double2 *h = a.ring_hdr + (size_t)ring * (RING_HDR / 2);
-            const double2 h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6],
-                          h7 = h[7], h8 = h[8];
-            const double2 cs = a.rot_table[aux];
+            const double2 h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
             const double period = h0.y;
             const int n0 = (int)(__double_as_longlong(h7.x) & 0xffffffffll), n1 = (int)(__double_as_longlong(h7.x) >> 32);
             const int flags = (int)(__double_as_longlong(h7.y) >> 32);
@@ -593,6 +604,22 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
             // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
             // block per lane (still correct, just not shared)
             key = (n0 > 64 || n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
+            // input modulation of the far-field plan's stage 1, applied for free (see NfArgs), and
+            // the phase-critical propagation from the grating centre (nearfield.py:337-341);
+            // evaluated HERE so that its arithmetic runs while the table blocks are on their way
+            if (a.premod) {
+                const double2 t2 = a.premod[j];
+                prop = {t2.x, t2.y};
+            }
+            if (!p.plane_wave) {
+                const double rcen = h0.x;
+                const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
+                const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                double sn, cn;
+                sincos_cw(p.kvac * air, sn, cn);
+                const c2 e = {cn, sn};
+                prop = a.premod ? cmul(e, prop) : e;   // free ride: one more phasor product
+            }
         }
     }
     // ================= periphery: order loop over LDS-staged table blocks =================
@@ -672,23 +699,9 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(co
     }
     ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
     if (peri) {
-        const double2 cs = a.rot_table[aux];
-        const double cosr = cs.x, sinr = cs.y, rcen = a.rc[idx - 1];
-        // input modulation of the far-field plan's stage 1, applied here for free (see NfArgs)
-        c2 e = {1.0, 0.0};
-        if (a.premod) {
-            const double2 t2 = a.premod[j];
-            e = {t2.x, t2.y};
-        }
-        // phase-critical: propagation from the grating centre (nearfield.py:337-341)
-        if (!p.plane_wave) {
-            const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
-            const double air = sqrt(gx * gx + gy * gy + p.source_z2);
-            double sn, cn;
-            sincos_cw(p.kvac * air, sn, cn);
-            const c2 prop = {cn, sn};
-            e = a.premod ? cmul(prop, e) : prop;   // free ride: one more phasor product
-        }
+        const double2 cs2 = a.rot_table[aux];   // (an L1 hit by now; cheaper than two live registers)
+        const double cosr = cs2.x, sinr = cs2.y;
+        const c2 e = prop;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             Acc &q = pr[m];
