@@ -15,6 +15,9 @@
 // cache lines between neighbouring columns).
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <tuple>
+#include <utility>
 
 #include "common.h"
 #include "zfft_core.h"
@@ -283,10 +286,18 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
 }
 
 void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2) {
-    zf::Geo g{N_eff / 256, N_eff, M, j0, 0, 0};
-    zf::choose_pads(g);
-    *pad1 = g.pad1;
-    *pad2 = g.pad2;
+    // a few milliseconds of host time per new (lattice, window): remembered
+    static std::map<std::tuple<int, int, int>, std::pair<int, int>> memo;
+    const auto key = std::make_tuple(N_eff, M, j0);
+    auto hit = memo.find(key);
+    if (hit == memo.end()) {
+        zf::Geo g{N_eff / 256, N_eff, M, j0, 0, 0};
+        zf::choose_pads(g);
+        if (memo.size() > 4096) memo.clear();
+        hit = memo.emplace(key, std::make_pair(g.pad1, g.pad2)).first;
+    }
+    *pad1 = hit->second.first;
+    *pad2 = hit->second.second;
 }
 
 }  // namespace ml

@@ -227,24 +227,34 @@ inline LdsCost lds_cost(const Geo &g) {
     return c;
 }
 
-// paddings with the fewest conflict cycles (exchange 1 is read strided, exchange 2 written strided)
+// paddings with the fewest conflict cycles (exchange 1 is read strided, exchange 2 written
+// strided).  The two exchanges do not interact, so each padding is searched on its own.
 inline void choose_pads(Geo &g) {
     long best = -1;
     int b1 = 0, b2 = 0;
-    for (int p1 = 0; p1 <= 16; ++p1)
-        for (int p2 = 0; p2 <= 16; ++p2) {
-            Geo t = g;
-            t.pad1 = p1;
-            t.pad2 = p2;
-            const LdsCost c = lds_cost(t);
-            // smaller paddings win ties (LDS footprint)
-            const long cost = (c.ex1_write + c.ex1_read + c.ex2_write + c.ex2_read) * 64 + p1 + p2;
-            if (best < 0 || cost < best) {
-                best = cost;
-                b1 = p1;
-                b2 = p2;
-            }
+    for (int p1 = 0; p1 <= 16; ++p1) {   // smaller paddings win ties (LDS footprint)
+        Geo t = g;
+        t.pad1 = p1;
+        t.pad2 = 0;
+        const LdsCost c = lds_cost(t);
+        const long cost = (c.ex1_write + c.ex1_read) * 64 + p1;
+        if (best < 0 || cost < best) {
+            best = cost;
+            b1 = p1;
         }
+    }
+    best = -1;
+    for (int p2 = 0; p2 <= 16; ++p2) {
+        Geo t = g;
+        t.pad1 = b1;
+        t.pad2 = p2;
+        const LdsCost c = lds_cost(t);
+        const long cost = (c.ex2_write + c.ex2_read) * 64 + p2;
+        if (best < 0 || cost < best) {
+            best = cost;
+            b2 = p2;
+        }
+    }
     g.pad1 = b1;
     g.pad2 = b2;
 }

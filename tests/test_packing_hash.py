@@ -1,0 +1,87 @@
+"""Host logic that decides whether resident tables / layouts can be re-used: the content hashes
+taken from the caller's own arrays before anything is packed (metalens_amd/packing.py), and the
+grouping of a source list into polarisation batches (metalens_amd/sweep.py).  No GPU."""
+import math
+
+import numpy as np
+
+import metalens_amd as ma
+from metalens_amd import layout, packing, synthetic
+
+
+def _lens():
+    return synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design,
+                               radius=15e-6, numerical_aperture=0.3, wavelength=580e-9,
+                               switch_angle=8 * math.pi / 180, num_gratings=6, num_entries=6)
+
+
+def test_tables_fingerprint_follows_content_not_identity():
+    lens = _lens()
+    objs = list(lens['lens_periphery_summary']['gratingcollection_list']) + [lens['hexgridset']]
+    a = packing._tables_fingerprint(objs, 580)
+    assert a == packing._tables_fingerprint(objs, 580)                 # deterministic
+    assert a != packing._tables_fingerprint(objs[:-1] + [None], 580)   # centre set missing
+    # one value of one table edited IN PLACE: same objects, another fingerprint
+    key = sorted(objs[0].interpolators, key=repr)[3]
+    vals = objs[0].interpolators[key].values
+    old = vals.flat[17]
+    vals.flat[17] = old * (1 + 1e-15) + 1e-30
+    b = packing._tables_fingerprint(objs, 580)
+    vals.flat[17] = old
+    assert b != a and packing._tables_fingerprint(objs, 580) == a
+    # another wavelength has no tables at all
+    assert packing._tables_fingerprint(objs, 450) != a
+
+
+class _FakeCtx:
+    """records what upload_layout would send, without a GPU"""
+    def __init__(self):
+        self.layout_token = None
+        self.uploads = 0
+
+        class Lib:
+            def ml_upload_layout(_self, *args):
+                self.uploads += 1
+                return 0
+        self.lib = Lib()
+        self.handle = None
+
+
+def test_layout_token_sees_reordered_cells_and_skips_identical_calls():
+    lens = _lens()
+    S, cells = lens['lens_periphery_summary'], np.array(lens['lens_center_summary'], dtype=float)
+    ctx = _FakeCtx()
+    packing.upload_layout(ctx, S, cells)
+    first = ctx.layout_token
+    packing.upload_layout(ctx, S, cells.copy())            # equal content, other object: no upload
+    assert ctx.uploads == 1 and ctx.layout_token == first
+    perm = np.random.default_rng(0).permutation(len(cells))
+    packing.upload_layout(ctx, S, cells[perm])             # same cells, another order: a new layout
+    assert ctx.uploads == 2 and ctx.layout_token != first
+    swapped = cells.copy()
+    swapped[[0, 1], 2] = swapped[[1, 0], 2]                # two cell types exchanged (sums unchanged)
+    if swapped[0, 2] != cells[0, 2]:
+        packing.upload_layout(ctx, S, swapped)
+        assert ctx.uploads == 3
+    S2 = dict(S)
+    S2['r_center_list'] = np.array(S['r_center_list'], dtype=float) * (1 + 1e-12)
+    packing.upload_layout(ctx, S2, cells)                  # r_center feeds xp and the lateral period
+    assert ctx.layout_token not in (first,)
+
+
+def test_sweep_groups_consecutive_polarisations_of_one_position():
+    from metalens_amd.sweep import MAX_BATCH, SourceSweep
+    sw = SourceSweep.__new__(SourceSweep)                  # the grouping needs no GPU state
+    f = -1e-4
+    srcs = [(0, 0, f, 'x'), (0, 0, f, 'y'), (0, 0, f, 'z'), (0, 0, f, 'x'),      # 3 + 1 (batch is full)
+            (1e-6, 0, f, 'x'), (0, 0, f, 'y'), (0, 0, f, 'z'),                      # position changes
+            (0, 0, -float('inf'), 'x'), (0, 0, -float('inf'), 'y')]                # plane waves
+    groups = sw._group(srcs)
+    assert [len(g['members']) for g in groups] == [3, 1, 1, 2, 2]
+    assert all(len(g['members']) <= MAX_BATCH for g in groups)
+    assert [k for g in groups for k, _ in g['members']] == list(range(len(srcs)))
+    import pytest
+    with pytest.raises(AssertionError):
+        sw._group([(0, 0, -float('inf'), 'z')])            # no z-polarised plane wave (nearfield.py:224)
+    with pytest.raises(AssertionError):
+        sw._group([(0, 0, +1.0, 'x')])                     # the source sits below the lens
