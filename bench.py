@@ -50,7 +50,13 @@ RGB = ((450e-9, 1.4656), (532e-9, 1.4607), (635e-9, 1.4570))   # configs[3]; n_g
 # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 # passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads), measured
 # for the default N = 1 command: profiles/r02*_summary.txt.  None until measured for a config.
-PMC_TRAFFIC = {}
+PMC_TRAFFIC = {
+    # (gpus, aperture, farfield, precision, method, zoom): bytes per launch, profiles/r02_summary.txt
+    #   near field: FETCH x2 392 MB (records) + WRITE 729 MB (zeros outside the lens are not re-stored)
+    #   stage 1:    FETCH x2 725 MB (rows outside the lens circle are not read) + WRITE 134 MB
+    #   step:       + stage 2 (135 + 17 MB) + projection (17 + 10 MB)
+    (1, 4096, 512, 'f64', 'auto', 1.0): {'nearfield': 1121e6, 'stage1': 859e6, 'step': 2158e6},
+}
 
 
 def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0):
@@ -440,6 +446,7 @@ def main():
         step_bytes = (64.0 * side * side + 64.0 * n_dir) * (world if replicas else 1)
         line['roofline']['step_hbm_frac'] = step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
         line['roofline']['step_bytes'] = step_bytes
+        line['roofline']['step_traffic'] = PMC_TRAFFIC.get(cfg_key, {}).get('step')
     if rel_err is not None:
         line['rel_err'] = rel_err
     if rank == 0 and world == 1:

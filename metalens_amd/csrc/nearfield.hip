@@ -157,6 +157,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.geo_ix = ctx->geo_ix.as<int2>();
     a.active_list = ctx->active_list.as<int2>();
     a.active_count = ctx->active_count.as<int>();
+    a.active_flag = ctx->active_flag.as<int>();
     a.use_active = 0;
     a.n_active = 0;
     a.patches_x = (ny + 7) / 8;
@@ -197,7 +198,6 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     } else if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
         ProfScope scope(ctx, ML_K_TWIDDLE);
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
-        ML_HIP(hipMemsetAsync(ctx->active_count.p, 0, sizeof(int), ctx->stream));
         ML_TRY(nearfield_geometry_launch(ctx, a));
         memcpy(ctx->geo_key, geo_key, sizeof geo_key);
         ctx->n_active = -1;

@@ -82,7 +82,7 @@ struct NfArgs {
     // 8 x 8 patches that hold at least one lens sample (written by kernel 1); use_active: the
     // field kernel's grid is that list (n_active entries) instead of all patches
     int2 *active_list;
-    int *active_count;
+    int *active_count, *active_flag;
     int use_active, n_active, patches_x;
     // outputs
     // outside_is_zero: the samples outside the lens already hold zeros in `fields` (the previous

@@ -355,10 +355,34 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
         a.geo_ix[at] = make_int2(idx, aux);
     }
     // patches with at least one sample inside the lens: the field kernel visits only these once
-    // the zeros of the others are in place (their order in the list does not matter: every
-    // result is indexed by the patch itself)
-    if (__any(idx <= a.n_rings) && lane == 0)
-        a.active_list[atomicAdd(a.active_count, 1)] = make_int2(blockIdx.x, blockIdx.y);
+    // the zeros of the others are in place.  A flag per patch here, compacted into the list by
+    // active_compact_kernel (190 k waves adding to ONE counter took 2 ms)
+    const int any_lens = __any(idx <= a.n_rings);   // all lanes vote
+    if (lane == 0) a.active_flag[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = any_lens ? 1 : 0;
+}
+
+// flags -> list of (bx, by), in patch order; one workgroup of 1024 threads, each owning a
+// contiguous run of patches (count, block scan, write)
+__global__ __launch_bounds__(1024) void active_compact_kernel(const int *flag, int n_patches, int patches_x,
+                                                              int2 *list, int *count) {
+    __shared__ int s_sum[1024];
+    const int t = threadIdx.x;
+    const int per = (n_patches + 1023) / 1024;
+    const int lo = min(t * per, n_patches), hi = min(lo + per, n_patches);
+    int mine = 0;
+    for (int k = lo; k < hi; ++k) mine += flag[k];
+    s_sum[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
+        const int v = t >= off ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int at = s_sum[t] - mine;
+    for (int k = lo; k < hi; ++k)
+        if (flag[k]) list[at++] = make_int2(k % patches_x, k / patches_x);
+    if (t == 1023) *count = s_sum[1023];
 }
 
 // ---- kernel 2 of 2: fields from the records ----------------------------------------------------
@@ -375,7 +399,7 @@ constexpr int NF_CHUNK = 4;                  // orders per staging pass (64 lane
 constexpr int NF_PITCH = NF_CHUNK * 16 + 1;  // +1: blocks start in different 16-byte bank slots
 
 template <bool RECORDS, int NP>
-__global__ __launch_bounds__(64, NP == 1 ? 4 : 2) void nearfield_field_kernel(const NfArgs a) {
+__global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(const NfArgs a) {
     __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];
     const int lane = threadIdx.x & 63;
     const ml_nearfield_params &p = a.p;
@@ -745,6 +769,9 @@ extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
     hipLaunchKernelGGL(nearfield_geometry_kernel, grid, dim3(64), 0, ctx->stream, a);
+    ML_HIP(hipGetLastError());
+    hipLaunchKernelGGL(active_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.active_flag,
+                       (int)(grid.x * grid.y), (int)grid.x, a.active_list, a.active_count);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

@@ -81,7 +81,9 @@ __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int
 // The next row's loads are issued before the current row's arithmetic (its 16 values wait in a
 // second register set), so a workgroup always has a row in flight; the stage-1 twiddles live in
 // LDS ([k2][n1]: the lanes of a 16-lane group read neighbouring or equal slots) to pay for it.
-template <int R3T, int NTMAX, int MINW>
+// PASS (1: rows of the aperture, 2: columns of stage 1's result) only names the instantiation, so
+// that a profile lists the two passes separately.
+template <int R3T, int NTMAX, int MINW, int PASS>
 __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
     cd *lds = reinterpret_cast<cd *>(zfft_lds_raw);
@@ -223,9 +225,9 @@ int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, i
     return ML_OK;
 }
 
-template <int R3T, int NTMAX, int MINW>
+template <int R3T, int NTMAX, int MINW, int PASS>
 static int launch_one(hipStream_t stream, const FftArgs &a, int grid, size_t lds_bytes) {
-    auto kern = zfft_kernel<R3T, NTMAX, MINW>;
+    auto kern = zfft_kernel<R3T, NTMAX, MINW, PASS>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         ML_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -276,12 +278,19 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds_bytes));
     int grid = std::min(256 * per_cu, a.chunk * 8);
     grid = (grid + 7) / 8 * 8;
-    switch (a.g.R3) {
-        case 4: return launch_one<4, 64, 2>(stream, a, grid, lds_bytes);
-        case 8: return launch_one<8, 128, 2>(stream, a, grid, lds_bytes);
-        case 16: return launch_one<16, 256, 2>(stream, a, grid, lds_bytes);
-        case 32: return launch_one<32, 512, 2>(stream, a, grid, lds_bytes);
-        default: return launch_one<0, 512, 1>(stream, a, grid, lds_bytes);
+    if (c.in_es == 1) switch (a.g.R3) {   // pass 1: contiguous rows
+            case 4: return launch_one<4, 64, 2, 1>(stream, a, grid, lds_bytes);
+            case 8: return launch_one<8, 128, 2, 1>(stream, a, grid, lds_bytes);
+            case 16: return launch_one<16, 256, 2, 1>(stream, a, grid, lds_bytes);
+            case 32: return launch_one<32, 512, 2, 1>(stream, a, grid, lds_bytes);
+            default: return launch_one<0, 512, 1, 1>(stream, a, grid, lds_bytes);
+        }
+    switch (a.g.R3) {                     // pass 2: strided columns
+        case 4: return launch_one<4, 64, 2, 2>(stream, a, grid, lds_bytes);
+        case 8: return launch_one<8, 128, 2, 2>(stream, a, grid, lds_bytes);
+        case 16: return launch_one<16, 256, 2, 2>(stream, a, grid, lds_bytes);
+        case 32: return launch_one<32, 512, 2, 2>(stream, a, grid, lds_bytes);
+        default: return launch_one<0, 512, 1, 2>(stream, a, grid, lds_bytes);
     }
 }
 
