@@ -774,7 +774,7 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
     ML_TRY(ctx->geo_ab.reserve(plane * 2 * sizeof(double)));
     ML_TRY(ctx->geo_ix.reserve(plane * 2 * sizeof(int)));
     ML_TRY(ctx->active_list.reserve((size_t)blocks * 2 * sizeof(int)));
-    ML_TRY(ctx->active_count.reserve(16));
+    ML_TRY(ctx->active_count.reserve(((size_t)blocks / 1024 + 4) * sizeof(int)));   // total + one per chunk of 1024 patches
     ML_TRY(ctx->active_flag.reserve((size_t)blocks * sizeof(int)));
     return nearfield_launch(ctx, p, n, nx, ny);
 }

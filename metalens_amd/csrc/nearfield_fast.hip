@@ -361,28 +361,55 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
     if (lane == 0) a.active_flag[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = any_lens ? 1 : 0;
 }
 
-// flags -> list of (bx, by), in patch order; one workgroup of 1024 threads, each owning a
-// contiguous run of patches (count, block scan, write)
-__global__ __launch_bounds__(1024) void active_compact_kernel(const int *flag, int n_patches, int patches_x,
-                                                              int2 *list, int *count) {
-    __shared__ int s_sum[1024];
-    const int t = threadIdx.x;
-    const int per = (n_patches + 1023) / 1024;
-    const int lo = min(t * per, n_patches), hi = min(lo + per, n_patches);
-    int mine = 0;
-    for (int k = lo; k < hi; ++k) mine += flag[k];
-    s_sum[t] = mine;
+// flags -> list of (bx, by), in patch order.  Two small kernels over chunks of 1024 patches:
+// lens patches per chunk, then (per chunk) the sum of the chunks before it + a scan of its own
+// flags + the writes.  count[0] = total, count[1 + c] = chunk c.
+constexpr int COMPACT_CHUNK = 1024;
+
+__device__ __forceinline__ int chunk_scan(int mine, int *s_wave, int &total) {
+    // exclusive prefix of `mine` (0 / 1) over the 1024 threads of the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long votes = __ballot(mine);
+    const int before = __popcll(votes & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wave] = __popcll(votes);
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {   // inclusive scan
-        const int v = t >= off ? s_sum[t - off] : 0;
-        __syncthreads();
-        s_sum[t] += v;
-        __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < COMPACT_CHUNK / 64; ++w) {
+        const int v = s_wave[w];
+        base += w < wave ? v : 0;
+        total += v;
     }
-    int at = s_sum[t] - mine;
-    for (int k = lo; k < hi; ++k)
-        if (flag[k]) list[at++] = make_int2(k % patches_x, k / patches_x);
-    if (t == 1023) *count = s_sum[1023];
+    return base + before;
+}
+
+__global__ __launch_bounds__(COMPACT_CHUNK) void active_count_kernel(const int *flag, int n_patches, int *count) {
+    __shared__ int s_wave[COMPACT_CHUNK / 64];
+    const int k = blockIdx.x * COMPACT_CHUNK + threadIdx.x;
+    int total;
+    chunk_scan(k < n_patches ? flag[k] : 0, s_wave, total);
+    if (threadIdx.x == 0) count[1 + blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int *flag, int n_patches, int patches_x,
+                                                                       int2 *list, int *count) {
+    __shared__ int s_wave[COMPACT_CHUNK / 64];
+    __shared__ int s_before[COMPACT_CHUNK / 64];
+    // lens patches in the chunks before this one (a few hundred chunks at most)
+    int part = 0;
+    for (int c = threadIdx.x; c < (int)blockIdx.x; c += COMPACT_CHUNK) part += count[1 + c];
+    for (int off = 32; off; off >>= 1) part += __shfl_down(part, off);
+    if ((threadIdx.x & 63) == 0) s_before[threadIdx.x >> 6] = part;
+    const int k = blockIdx.x * COMPACT_CHUNK + threadIdx.x;
+    const int mine = k < n_patches ? flag[k] : 0;
+    int total;
+    const int at = chunk_scan(mine, s_wave, total);   // (its barrier also covers s_before)
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < COMPACT_CHUNK / 64; ++w) before += s_before[w];
+    if (mine) list[before + at] = make_int2(k % patches_x, k / patches_x);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) count[0] = before + total;
 }
 
 // ---- kernel 2 of 2: fields from the records ----------------------------------------------------
@@ -770,8 +797,12 @@ int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
     hipLaunchKernelGGL(nearfield_geometry_kernel, grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
-    hipLaunchKernelGGL(active_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.active_flag,
-                       (int)(grid.x * grid.y), (int)grid.x, a.active_list, a.active_count);
+    const int n_patches = (int)(grid.x * grid.y), chunks = (n_patches + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
+    hipLaunchKernelGGL(active_count_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
+                       n_patches, a.active_count);
+    ML_HIP(hipGetLastError());
+    hipLaunchKernelGGL(active_compact_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
+                       n_patches, (int)grid.x, a.active_list, a.active_count);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

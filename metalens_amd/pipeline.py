@@ -131,8 +131,8 @@ class HotPath:
             else:
                 _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
 
-    def step(self):
-        """queue one pass of the hot path on the context's stream (asynchronous)"""
+    def queue_synthesis(self):
+        """first half of a step: near field of this rank's rows into the resident field set"""
         ctx, lib = self.ctx, self.ctx.lib
         _lib.check(lib.ml_nearfield_premodulate(ctx.handle, int(self.fuse_modulation)))
         _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
@@ -143,6 +143,11 @@ class HotPath:
             _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(self.params),
                                               _lib.dptr(self.x_local), self.x_local.size,
                                               _lib.dptr(self.y), self.y.size))
+
+    def queue_transform(self):
+        """second half: both transform stages, the reduction over ranks, the projection"""
+        ctx, lib = self.ctx, self.ctx.lib
+        if self.x_local.size:
             if self.mirrored:
                 _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
             else:
@@ -153,6 +158,11 @@ class HotPath:
             if self.world > 1 or dist.force_rccl():
                 _lib.check(lib.ml_farfield_allreduce(ctx.handle))
             _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
+
+    def step(self):
+        """queue one pass of the hot path on the context's stream (asynchronous)"""
+        self.queue_synthesis()
+        self.queue_transform()
 
     def sync(self):
         self.ctx.sync()
@@ -196,3 +206,4 @@ class HotPath:
         local_power = power.value * self.dxp * self.dyp
         return {'P': P, 'a_theta': a_theta, 'a_phi': a_phi, 'Nx': vec[0], 'Ny': vec[1],
                 'Lx': vec[2], 'Ly': vec[3], 'power_local_rows': local_power}
+
