@@ -272,7 +272,9 @@ def main():
     t0 = time.perf_counter()
     hp.step()
     hp.sync()
-    prime = max(1, min(200, int(0.05 / max(time.perf_counter() - t0, 1e-5))))
+    # (the same count on every rank - each step carries a collective: agree on the slowest rank's time)
+    t_one = float(dist.allreduce_host(ctx, [time.perf_counter() - t0], 'max')[0])
+    prime = max(1, min(200, int(0.05 / max(t_one, 1e-5))))
     for _ in range(prime):
         hp.step()
     hp.sync()
