@@ -279,7 +279,7 @@ struct ml_ctx {
     long ovr_serial = 0;                    // bumped whenever the override list changes
     // per-sample geometry records (nearfield_fast.hip) and what they were built for:
     // (grid_serial, layout_serial, ovr_serial, samples)
-    ml::DevBuf geo_ab, geo_ix, active_list, active_count, active_flag;
+    ml::DevBuf geo_ix, active_list, active_count, active_flag;
     long geo_key[4] = {-1, -1, -1, -1};
     int n_active = -1;   // patches with lens samples; -1: not read back yet
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to

@@ -452,7 +452,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
                       &ctx->cell_lattice_map, &ctx->cell_lattice_rec, &ctx->tie_count, &ctx->tie_list,
-                      &ctx->ovr_key, &ctx->ovr_slot, &ctx->geo_ab, &ctx->geo_ix, &ctx->active_list, &ctx->active_count, &ctx->active_flag, &ctx->fields,
+                      &ctx->ovr_key, &ctx->ovr_slot, &ctx->geo_ix, &ctx->active_list, &ctx->active_count, &ctx->active_flag, &ctx->fields,
                       &ctx->x_pts, &ctx->y_pts, &ctx->partial_power, &ctx->power,
                       &ctx->violations, &ctx->row_first, &ctx->acc_P, &ctx->acc_partials, &ctx->acc_sums, &ctx->plan.ux, &ctx->plan.uy, &ctx->plan.tw_x,
                       &ctx->plan.tw_y, &ctx->plan.stage1, &ctx->plan.vectors, &ctx->plan.power,
@@ -771,8 +771,7 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
         ctx->n_ovr = 0;
         ++ctx->ovr_serial;
     }
-    ML_TRY(ctx->geo_ab.reserve(plane * 2 * sizeof(double)));
-    ML_TRY(ctx->geo_ix.reserve(plane * 2 * sizeof(int)));
+    ML_TRY(ctx->geo_ix.reserve((size_t)blocks * 64 * 2 * sizeof(int)));   // patch-major, 64 per patch
     ML_TRY(ctx->active_list.reserve((size_t)blocks * 2 * sizeof(int)));
     ML_TRY(ctx->active_count.reserve(((size_t)blocks / 1024 + 4) * sizeof(int)));   // total + one per chunk of 1024 patches
     ML_TRY(ctx->active_flag.reserve((size_t)blocks * sizeof(int)));

@@ -153,7 +153,6 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.ring_tab_off = ctx->ring_tab_off.as<long long>();
     a.ring_ok = ctx->ring_ok.as<double>();
     a.ring_ok_off = ctx->ring_ok_off.as<int>();
-    a.geo_ab = ctx->geo_ab.as<double2>();
     a.geo_ix = ctx->geo_ix.as<int2>();
     a.active_list = ctx->active_list.as<int2>();
     a.active_count = ctx->active_count.as<int>();

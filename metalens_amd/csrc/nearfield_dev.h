@@ -77,8 +77,7 @@ struct NfArgs {
     const double *ring_ok;
     const int *ring_ok_off;
     // per-sample geometry records (nearfield_fast.hip, kernel 1 writes, kernel 2 reads)
-    double2 *geo_ab;   // [nx][ny]
-    int2 *geo_ix;      // [nx][ny]
+    int2 *geo_ix;      // [patch][64]: patch = by * patches_x + bx, 8 x 8 samples each
     // 8 x 8 patches that hold at least one lens sample (written by kernel 1); use_active: the
     // field kernel's grid is that list (n_active entries) instead of all patches
     int2 *active_list;

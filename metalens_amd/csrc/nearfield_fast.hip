@@ -287,34 +287,31 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 // ---- kernel 1 of 2: the source-INDEPENDENT decisions of every sample ---------------------------
 // Ring (nearfield.py:125-128), sector and rotated local coordinates (:169,200-201), nearest
 // centre cell (:363-367) depend on the sample grid and the layout only.  They are evaluated once
-// per (grid, layout, tie answers) into a 24-byte record per sample,
-//     geo_ab = (xp, yp)        periphery       geo_ix = (idx, index into the rotation table)
-//              (cell x, cell y) centre                   (0, cell type; -1: no cells)
-//                                                        (n_rings + 1, -) outside the lens
+// per (grid, layout, tie answers) into an 8-byte record per sample (stored patch by patch),
+//     geo_ix = (idx, index into the rotation table)     periphery, idx = ring + 1
+//              (0, slot of the nearest cell; -1: no cells) centre
+//              (n_rings + 1, -)                           outside the lens
+// (the rotated coordinates and the cell centre follow from these with one table load each: a
+// 24-byte record that carried them cost 10 % more per extra 16 bytes - the kernel is sensitive
+// to the bytes it streams from HBM, not to arithmetic in the shadow of its loads)
 // and every synthesis on that geometry - a sweep over sources, the steps of a benchmark - starts
 // from the records (kernel 2).  Same thread -> sample map as kernel 2 (8 x 8 patch per wave).
-// the decisions of one sample (see the geometry kernel below): idx, aux, (ga, gb)
+// the decisions of one sample (see the geometry kernel below): idx, aux
 __device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, double y, long long sample_id,
-                                                int &idx, int &aux, double &ga, double &gb) {
+                                                int &idx, int &aux) {
     const double r = sqrt(x * x + y * y);
     idx = boundaries_below_fast(a, r);
-    ga = 0.0;
-    gb = 0.0;
     aux = -1;
     if (idx >= 1 && idx <= a.n_rings) {
         const int ring = idx - 1;
-        const double dphi = a.dphi[ring], rcen = a.rc[ring];
+        const double dphi = a.dphi[ring];
         const int rot_half = a.rot_half[ring], rot_center = a.rot_center[ring];
         // sector decision: exact (nearfield.py:169)
         const int sector = sector_of_fast(a, rot_half, rot_center, x, y, dphi, recip(dphi));
         aux = rot_center + sector;
-        const double2 cs = a.rot_table[aux];
-        // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
-        ga = x * cs.x + y * cs.y - rcen;
-        gb = -x * cs.y + y * cs.x;
     } else if (idx == 0 && a.n_cells > 0) {
-        // nearest cell: the lattice shortcut returns the cell itself from the node map (one
-        // load); anything it cannot settle goes through nearest_cell_fast
+        // nearest cell: the lattice shortcut settles almost every sample from the node map (two
+        // loads); anything it cannot settle goes through nearest_cell_fast
         bool have_cell = false;
         if (a.lat_rec) {
             int ia, ib;
@@ -324,21 +321,13 @@ __device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, doubl
                 const rec_t q = *reinterpret_cast<const rec_t *>(a.lat_rec + node);
                 const double ex = x - q.x, ey = y - q.y;
                 if (ex * ex + ey * ey <= a.lat_accept_r2) {   // false for a NaN (empty) node
-                    ga = q.x;
-                    gb = q.y;
-                    aux = (int)(__double_as_longlong(q.z) & 0xffffffffll);
+                    aux = a.lat_map[node];
                     have_cell = true;
                 }
             }
         }
-        if (!have_cell) {
-            const int s = nearest_cell_fast(a, x, y, sample_id);
-            const double2 cc = a.cxy[s];
-            ga = cc.x;
-            gb = cc.y;
-            aux = a.cwhich[s];
-        }
-        aux = max(aux, 0);   // a (never produced) negative cell type would read as "no cells"
+        if (!have_cell) aux = nearest_cell_fast(a, x, y, sample_id);
+        aux = max(aux, 0);   // a (never produced) negative slot would read as "no cells"
     }
 }
 
@@ -349,10 +338,10 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
     int idx = a.n_rings + 1, aux = -1;
     if (j < a.ny && i < a.nx) {
         const size_t at = (size_t)i * a.ny + j;
-        double ga, gb;
-        sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
-        a.geo_ab[at] = make_double2(ga, gb);
-        a.geo_ix[at] = make_int2(idx, aux);
+        sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
+        // patch-major: the 64 records of a wave are 512 contiguous bytes
+        const size_t rec = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
+        a.geo_ix[rec] = make_int2(idx, aux);
     }
     // patches with at least one sample inside the lens: the field kernel visits only these once
     // the zeros of the others are in place.  A flag per patch here, compacted into the list by
@@ -443,7 +432,6 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     const bool inb = j < a.ny && i < a.nx;
     const size_t at = (size_t)i * a.ny + j;
     int idx = a.n_rings + 1, aux = -1;
-    double ga = 0.0, gb = 0.0;
 #ifdef ML_PHASE_TIMERS
     unsigned long long stamp[PHASE_SLOTS] = {0};
     stamp[0] = __builtin_amdgcn_s_memtime();
@@ -452,28 +440,24 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     const double x_ld = a.x_pts[min(i, a.nx - 1)], y_ld = a.y_pts[min(j, a.ny - 1)];
     if (inb) {
         if (RECORDS) {
-            // both records at once (the second does not wait for the first); streamed: they are
-            // read once per launch and must not push the ring tables out of the L2
+            // streamed: read once per launch, must not push the ring tables out of the L2
             typedef int int2v __attribute__((ext_vector_type(2)));
-            typedef double double2v __attribute__((ext_vector_type(2)));
-            const int2v ix = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(a.geo_ix) + at);
-            const double2v ab = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(a.geo_ab) + at);
+            const size_t rec = ((size_t)by * a.patches_x + bx) * 64 + lane;   // patch-major
+            const int2v ix = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(a.geo_ix) + rec);
             idx = ix.x;
             aux = ix.y;
-            ga = ab.x;
-            gb = ab.y;
         } else {
-            sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux, ga, gb);
+            sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
         }
     }
-    ML_MARK(1, idx + (int)ga);
+    ML_MARK(1, idx + aux);
     const bool lens = idx <= a.n_rings;
     const bool peri = lens && idx >= 1;
     const double inv_n = recip(p.n_glass);
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
     int key = -1, n_orders = 0, stride0 = 0, stride_o = 0;
-    double uxp = 0.0, uyp = 0.0, t0 = 0.0, t1 = 0.0;
+    double uxp = 0.0, uyp = 0.0, t0 = 0.0, t1 = 0.0, xp = 0.0, yp = 0.0;
     double Hw_x[NP], Hw_y[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) Hw_x[m] = Hw_y[m] = 0.0;
@@ -552,8 +536,10 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
                 const int n2 = T.n2;
                 const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
                 const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
-                const double ccx = ga, ccy = gb;
-                const int which = min(aux, n2 - 1);
+                // the record holds the cell's slot in the bin-sorted arrays
+                const double2 cc = a.cxy[aux];
+                const double ccx = cc.x, ccy = cc.y;
+                const int which = min(a.cwhich[aux], n2 - 1);
                 // centre table, amplitude-major: [order][i0][i1][4][K]
                 const double2 *tab = a.center_tab;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
@@ -623,6 +609,9 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
             n_orders = (int)(__double_as_longlong(h7.y) & 0xffffffffll);
             ok = a.ring_ok + ok_off;
             const double cosr = cs.x, sinr = cs.y;
+            // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
+            xp = x * cosr + y * sinr - h0.x;
+            yp = -x * sinr + y * cosr;
             uxp = fma(ux, cosr, uy * sinr);
             uyp = fma(uy, cosr, -ux * sinr);
 #pragma unroll
@@ -677,7 +666,6 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     Acc pr[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    const double xp = ga, yp = gb;
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
         int myslot = -1, lead[NF_SLOTS];
