@@ -61,7 +61,10 @@ __device__ __forceinline__ zf::Geo geo_of(const FftArgs &a) {
 }
 
 // one row's 16 samples of thread `tid` (coalesced: lane l reads element l + NT n2)
-template <int R3T>
+// STREAM: the rows of the aperture are read once per transform (non-temporal: they must not push
+// the next synthesis' tables and records out of the caches); the column pass re-uses every line
+// it touches across neighbouring workgroups and reads normally
+template <int R3T, bool STREAM>
 __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int row, int tid, cd *v) {
     const int NT = 16 * g.R3;
     const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2;
@@ -73,7 +76,13 @@ __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int
         if (n >= a.a0 && n < a.a0 + a.h0) q = n - a.a0;
         if (n >= a.a1 && n < a.a1 + a.h1) q = a.h0 + n - a.a1;
         if (min(n, g.n_valid - 1 - n) < first) q = -1;
-        v[n2] = q >= 0 ? src[q * a.in_es] : zf::mk(0.0, 0.0);
+        if (STREAM && q >= 0) {
+            typedef double double2v __attribute__((ext_vector_type(2)));
+            const double2v t = __builtin_nontemporal_load(reinterpret_cast<const double2v *>(src + q * a.in_es));
+            v[n2] = zf::mk(t.x, t.y);
+        } else {
+            v[n2] = q >= 0 ? src[q * a.in_es] : zf::mk(0.0, 0.0);
+        }
     }
 }
 
@@ -111,11 +120,11 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     int idx = blockIdx.x >> 3;
     int row = xcd * a.chunk + idx;   // block-uniform
     cd v[16], nx[16];
-    if (idx < a.chunk && row < a.rows) load_row<R3T>(a, g, row, tid, v);
+    if (idx < a.chunk && row < a.rows) load_row<R3T, PASS == 1>(a, g, row, tid, v);
     while (idx < a.chunk && row < a.rows) {
         const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
         const bool more = idx_n < a.chunk && row_n < a.rows;
-        if (more) load_row<R3T>(a, g, row_n, tid, nx);
+        if (more) load_row<R3T, PASS == 1>(a, g, row_n, tid, nx);
         zf::stage1(g, tid, v, s_tw + n1, 16, lds);
         __syncthreads();
         zf::gather2(g, tid, v, lds);
