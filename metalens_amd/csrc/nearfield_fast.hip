@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
             // streamed: read once per launch, must not push the ring tables out of the L2
             typedef int int2v __attribute__((ext_vector_type(2)));
             const size_t rec = ((size_t)by * a.patches_x + bx) * 64 + lane;   // patch-major
-            const int2v ix = __builtin_nontemporal_load(reinterpret_cast<const int2v *>(a.geo_ix) + rec);
+            const int2v ix = reinterpret_cast<const int2v *>(a.geo_ix)[rec];
             idx = ix.x;
             aux = ix.y;
         } else {
