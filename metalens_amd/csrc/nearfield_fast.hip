@@ -738,7 +738,8 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     }
     ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
     if (peri) {
-        const double2 cs2 = a.rot_table[aux];   // (an L1 hit by now; cheaper than two live registers)
+        // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
+        const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
         const double cosr = cs2.x, sinr = cs2.y;
         const c2 e = prop;
 #pragma unroll
