@@ -102,19 +102,23 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     for (int e = tid; e < 256; e += NT) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];   // e = n1 * 16 + k2
     const int n1 = tid / g.R3;
     // the (up to two) bins this thread evaluates in stage 3 are the same for every row
-    const bool own0 = tid < g.M, own1 = tid + NT < g.M, few = g.M <= 2 * NT;
+    const int bin0 = tid, bin1 = tid + NT;
+    const bool own0 = bin0 < g.M, own1 = bin1 < g.M, few = g.M <= 2 * NT;
     cd w0 = zf::mk(0, 0), p0 = w0, w1 = w0, p1 = w0;
     int k0 = 0, k1 = 0;
     if (own0) {
-        w0 = a.wk[tid];
-        p0 = a.pj[tid];
-        k0 = a.kbin[tid];
+        w0 = a.wk[bin0];
+        p0 = a.pj[bin0];
+        k0 = a.kbin[bin0];
     }
     if (own1) {
-        w1 = a.wk[tid + NT];
-        p1 = a.pj[tid + NT];
-        k1 = a.kbin[tid + NT];
+        w1 = a.wk[bin1];
+        p1 = a.pj[bin1];
+        k1 = a.kbin[bin1];
     }
+    // bins 256 apart differ in k0 only and sum the same LDS values: one pass for both
+    // (stage3_pair).  True for every thread with two bins when NT is a multiple of 256.
+    const bool pair = own0 && own1 && ((k1 - k0) & 255) == 0;
     __syncthreads();
     const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
     int idx = blockIdx.x >> 3;
@@ -133,12 +137,29 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
         const double al = a.alpha[row / a.alpha_rb];
-        if (few) {
+        if (few && pair) {
+            // the two bins share their LDS operands
+            cd xa, xb;
+            zf::stage3_pair(g, k0, w0, w1, lds, xa, xb);
+            xa = zf::cmul(xa, p0);
+            xb = zf::cmul(xb, p1);
+            xa.x *= al;
+            xa.y *= al;
+            xb.x *= al;
+            xb.y *= al;
+            cd *da = dst + bin0 * a.out_es, *db = dst + bin1 * a.out_es;
+            if (a.accumulate) {
+                xa = zf::cadd(xa, *da);
+                xb = zf::cadd(xb, *db);
+            }
+            *da = xa;
+            *db = xb;
+        } else if (few) {
             if (own0) {
                 cd x = zf::cmul(zf::stage3(g, k0, w0, lds), p0);
                 x.x *= al;
                 x.y *= al;
-                cd *d = dst + tid * a.out_es;
+                cd *d = dst + bin0 * a.out_es;
                 if (a.accumulate) x = zf::cadd(x, *d);
                 *d = x;
             }
@@ -146,7 +167,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
                 cd x = zf::cmul(zf::stage3(g, k1, w1, lds), p1);
                 x.x *= al;
                 x.y *= al;
-                cd *d = dst + (tid + NT) * a.out_es;
+                cd *d = dst + bin1 * a.out_es;
                 if (a.accumulate) x = zf::cadd(x, *d);
                 *d = x;
             }

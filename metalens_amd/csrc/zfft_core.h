@@ -149,6 +149,18 @@ ZF_HD cd stage3(const Geo &g, int k, cd w, const cd *lds) {
     return x;
 }
 
+// ... for TWO wanted bins k and kb with kb = k (mod 256): they differ in k0 only and sum the same
+// R3 values with different ratios, so each value is read from LDS once
+ZF_HD void stage3_pair(const Geo &g, int k, cd wa, cd wb, const cd *lds, cd &xa, cd &xb) {
+    const int k2 = k & 15, k1 = (k >> 4) & 15;
+    xa = xb = lds[ex2_addr(g, g.R3 - 1, k1, k2)];
+    for (int n0 = g.R3 - 2; n0 >= 0; --n0) {
+        const cd t = lds[ex2_addr(g, n0, k1, k2)];
+        xa = cmac(xa, wa, t);
+        xb = cmac(xb, wb, t);
+    }
+}
+
 }  // namespace zf
 
 // ---- host side: LDS bank-conflict model and the choice of the two paddings ---------------------

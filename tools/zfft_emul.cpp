@@ -35,10 +35,22 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose) {
     for (int u = 0; u < NT; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
     double worst = 0, scale = 0;
     std::vector<cd> out(M);
-    for (int j = 0; j < M; ++j) {
-        const int k = zf::bin_of(g, j);
+    auto ratio = [&](int k) {
         const long double a = -2 * M_PIl * k / N;
-        out[j] = zf::stage3(g, k, zf::mk((double)cosl(a), (double)sinl(a)), lds.data());
+        return zf::mk((double)cosl(a), (double)sinl(a));
+    };
+    for (int j = 0; j < M; ++j) out[j] = zf::stage3(g, zf::bin_of(g, j), ratio(zf::bin_of(g, j)), lds.data());
+    // bins 256 apart share their operands: the paired form (the kernel's path for 256-thread
+    // workgroups) must give exactly the same values
+    for (int j = 0; j + 256 < M; ++j) {
+        const int ka = zf::bin_of(g, j), kb = zf::bin_of(g, j + 256);
+        if (((kb - ka) & 255) != 0) continue;
+        cd xa, xb;
+        zf::stage3_pair(g, ka, ratio(ka), ratio(kb), lds.data(), xa, xb);
+        if (xa.x != out[j].x || xa.y != out[j].y || xb.x != out[j + 256].x || xb.y != out[j + 256].y) {
+            printf("stage3_pair differs from stage3 at bin %d\n", j);
+            return 1.0;
+        }
     }
     for (int j = 0; j < M; ++j) {
         long double re = 0, im = 0;
