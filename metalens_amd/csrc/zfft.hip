@@ -101,6 +101,12 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     cd *s_tw = lds + zf::lds_elems(g);   // [16][16] behind the exchange buffer
     for (int e = tid; e < 256; e += NT) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];   // e = n1 * 16 + k2
     const int n1 = tid / g.R3;
+    // W^1..3 of this thread's stage-1 twiddle W = W_256^(n1) stay in registers; W^4, 8, 12 are read
+    // from LDS per row (W^(4 a + b) is one product): 3 LDS reads per row instead of 15
+    cd tb[4];
+    tb[0] = zf::mk(1.0, 0.0);
+#pragma unroll
+    for (int b = 1; b < 4; ++b) tb[b] = a.tw1[n1 * 16 + b];
     // the (up to two) bins this thread evaluates in stage 3 are the same for every row
     const int bin0 = tid, bin1 = tid + NT;
     const bool own0 = bin0 < g.M, own1 = bin1 < g.M, few = g.M <= 2 * NT;
@@ -129,7 +135,13 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
         const bool more = idx_n < a.chunk && row_n < a.rows;
         if (more) load_row<R3T, PASS == 1>(a, g, row_n, tid, nx);
-        zf::stage1(g, tid, v, s_tw + n1, 16, lds);
+        {
+            cd ta[4];
+            ta[0] = tb[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) ta[q] = s_tw[(4 * q) * 16 + n1];
+            zf::stage1_regs(g, tid, v, ta, tb, lds);
+        }
         __syncthreads();
         zf::gather2(g, tid, v, lds);
         __syncthreads();

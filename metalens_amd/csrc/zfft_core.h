@@ -118,13 +118,23 @@ ZF_HD int bin_of(const Geo &g, int j) {
 }
 
 // ---- the phases, one thread each -------------------------------------------------------------
-// stage 1 on the 16 samples v[n2] of thread t: butterflies, the W_256^(n1 k2) twiddles
-// (tw1[k2 * tw_stride]: a table of this thread's n1, read where it is used), result to exchange 1
-ZF_HD void stage1(const Geo &g, int t, cd *v, const cd *tw1, int tw_stride, cd *lds) {
+// stage 1 on the 16 samples v[n2] of thread t: butterflies, the W_256^(n1 k2) twiddles, result to
+// exchange 1.  The twiddles W^(k2), W = W_256^(n1), are built from six tabulated powers of the
+// thread's W (tb[b] = W^b, ta[a] = W^(4 a), a, b = 1..3; k2 = 4 a + b needs one product): the LDS
+// pipe is what bounds the transform and the vector pipe has room, so the kernel keeps tb in
+// registers and reads only ta from LDS (3 reads per row instead of 15)
+ZF_HD void stage1_regs(const Geo &g, int t, cd *v, const cd *ta, const cd *tb, cd *lds) {
     dft16(v);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
-        const cd a = k2 == 0 ? v[bin16(0)] : cmul(v[bin16(k2)], tw1[k2 * tw_stride]);
+        const int hi = k2 >> 2, lo = k2 & 3;
+        cd a = v[bin16(k2)];
+        if (hi && lo)
+            a = cmul(a, cmul(ta[hi], tb[lo]));
+        else if (hi)
+            a = cmul(a, ta[hi]);
+        else if (lo)
+            a = cmul(a, tb[lo]);
         lds[ex1_addr(g, t, k2)] = a;
     }
 }

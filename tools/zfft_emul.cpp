@@ -22,14 +22,16 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose) {
     std::vector<std::vector<cd>> v(NT, std::vector<cd>(16));
     // stage 1
     for (int t = 0; t < NT; ++t) {
-        cd tw1[16];
+        // the six tabulated powers of W = W_256^(n1) the kernel keeps per thread
+        cd ta[4], tb[4];
         const int n1 = t / R3;
-        for (int k2 = 0; k2 < 16; ++k2) {
-            const long double a = -2 * M_PIl * ((n1 * k2) % 256) / 256;
-            tw1[k2] = zf::mk((double)cosl(a), (double)sinl(a));
+        for (int q = 0; q < 4; ++q) {
+            const long double b = -2 * M_PIl * ((n1 * q) % 256) / 256, a = -2 * M_PIl * ((n1 * 4 * q) % 256) / 256;
+            tb[q] = zf::mk((double)cosl(b), (double)sinl(b));
+            ta[q] = zf::mk((double)cosl(a), (double)sinl(a));
         }
         for (int n2 = 0; n2 < 16; ++n2) v[t][n2] = in[t + NT * n2];
-        zf::stage1(g, t, v[t].data(), tw1, 1, lds.data());
+        zf::stage1_regs(g, t, v[t].data(), ta, tb, lds.data());
     }
     for (int u = 0; u < NT; ++u) zf::gather2(g, u, v[u].data(), lds.data());
     for (int u = 0; u < NT; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
