@@ -52,10 +52,12 @@ RGB = ((450e-9, 1.4656), (532e-9, 1.4607), (635e-9, 1.4570))   # configs[3]; n_g
 # for the default N = 1 command: profiles/r02*_summary.txt.  None until measured for a config.
 PMC_TRAFFIC = {
     # (gpus, aperture, farfield, precision, method, zoom): bytes per launch, profiles/r02_summary.txt
-    #   near field: FETCH x2 392 MB (records) + WRITE 729 MB (zeros outside the lens are not re-stored)
+    #   near field: FETCH x2 183 MB (8-byte records of the active patches, tables) + WRITE 729 MB
+    #               (zeros outside the lens are not re-stored)
     #   stage 1:    FETCH x2 725 MB (rows outside the lens circle are not read) + WRITE 134 MB
     #   step:       + stage 2 (135 + 17 MB) + projection (17 + 10 MB)
-    (1, 4096, 512, 'f64', 'auto', 1.0): {'nearfield': 1121e6, 'stage1': 859e6, 'step': 2158e6},
+    # (counted where the L2s meet the fabric: reads the Infinity Cache serves are included)
+    (1, 4096, 512, 'f64', 'auto', 1.0): {'nearfield': 912e6, 'stage1': 859e6, 'step': 1950e6},
 }
 
 
