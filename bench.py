@@ -433,13 +433,13 @@ def main():
         avg_ms = nf['total_ms'] / nf['launches']
         achieved = nf_bytes / (avg_ms * 1e-3) / 1e9
         roofs['nearfield'] = {
-            'bound': 'hbm', 'kernel': 'nearfield_fast_kernel', 'achieved': achieved,
+            'bound': 'hbm', 'kernel': 'nearfield_field_kernel', 'achieved': achieved,
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('nearfield'),
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-            'note': 'compulsory traffic is the 64 B/sample of stores; the kernel is bound by its '
-                    'per-sample table gathers through the L1 and by fp64 issue, not by HBM '
-                    '(DESIGN.md 4.1)'}
+            'note': 'compulsory traffic is the 64 B/sample of stores; what bounds the kernel is the '
+                    'chain of dependent loads per wave (record -> ring header / rotation -> table '
+                    'blocks) at four waves per SIMD and fp64 issue, not HBM bandwidth (DESIGN.md 4.1)'}
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
