@@ -715,9 +715,16 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
             ML_MARK(4, s_tab[lane].x);
             if (myslot >= 0) {
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
+                // the order's grating vector one iteration ahead: its load (an L1 hit) is in
+                // flight during the previous order's arithmetic instead of in front of its own
+                typedef double double2v __attribute__((ext_vector_type(2)));
+                const double2v *ok2 = reinterpret_cast<const double2v *>(ok);
+                double2v k_next = NP == 1 ? ok2[o0] : (double2v){0.0, 0.0};
                 for (int o = o0; o < o1; ++o) {
-                    const double kxp = fma(p.kvac, uxp, ok[2 * o]);
-                    const double kyp = fma(p.kvac, uyp, ok[2 * o + 1]);
+                    const double2v k_here = NP == 1 ? k_next : ok2[o];
+                    if (NP == 1) k_next = ok2[min(o + 1, o1 - 1)];
+                    const double kxp = fma(p.kvac, uxp, k_here.x);
+                    const double kyp = fma(p.kvac, uyp, k_here.y);
                     const double kt2 = fma(kxp, kxp, kyp * kyp);
                     if (kt2 <= p.kvac2) {
                         if (outside) {
