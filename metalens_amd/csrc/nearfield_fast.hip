@@ -469,12 +469,18 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     // (its first and last 16 bytes: the 160-byte record spans two cache lines, which are then in
     // the L1 when the rest is read; holding all of it across the incident field costs registers
     // the kernel does not have)
-    double2 h0 = {0, 0}, h8 = h0, cs = {1.0, 0.0};
+    double2 h0 = {0, 0}, h8 = h0, cs = {1.0, 0.0}, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
     if (peri) {
         const double2 *h = a.ring_hdr + (size_t)(idx - 1) * (RING_HDR / 2);
         h0 = h[0];
         h8 = h[8];
         cs = a.rot_table[aux];
+        if (NP == 1) {   // what the table cell and the staging address need: also on its way now
+            h4 = h[4];
+            h5 = h[5];
+            h6 = h[6];
+            h7 = h[7];
+        }
     }
     c2 prop = {1.0, 0.0};   // exp(i k |grating centre - source|) x the plan's column phasor
     {
@@ -600,7 +606,13 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
             // everything that depends on the ring alone comes from ONE record (common.h RING_HDR),
             // whose two cache lines were requested above
             const double2 *h = a.ring_hdr + (size_t)ring * (RING_HDR / 2);
-            const double2 h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6], h7 = h[7];
+            const double2 h1 = h[1], h2 = h[2], h3 = h[3];
+            if (NP > 1) {
+                h4 = h[4];
+                h5 = h[5];
+                h6 = h[6];
+                h7 = h[7];
+            }
             const double period = h0.y;
             const int n0 = (int)(__double_as_longlong(h7.x) & 0xffffffffll), n1 = (int)(__double_as_longlong(h7.x) >> 32);
             const int flags = (int)(__double_as_longlong(h7.y) >> 32);
@@ -773,7 +785,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     stamp[7] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0);   // the stores have left the wave
     stamp[8] = __builtin_amdgcn_s_memtime();
-    const size_t wid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const size_t wid = (size_t)by * a.patches_x + bx;   // patch id, whichever launch form
     if (lane == 0 && wid < PHASE_WAVES) {
         stamp[9] = (unsigned long long)__ballot(true);
         for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = stamp[k];
