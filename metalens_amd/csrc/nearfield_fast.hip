@@ -450,6 +450,40 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
             sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
         }
     }
+    // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
+    // arithmetic).  They need the sample's coordinates and the source only, so they are worked
+    // out for every lane while the record is on its way and masked by it afterwards.
+    double ux = 0.0, uy = 0.0, uz = 1.0;
+    double Hx_i[NP], Hy_i[NP], power_in[NP];
+    {
+        double inv = 1.0;
+        if (!p.plane_wave) {
+            const double dx = x_ld - p.source_x, dy = y_ld - p.source_y;
+            inv = rsqrt_fast(dx * dx + dy * dy + p.dz2);
+            ux = dx * inv;
+            uy = dy * inv;
+            uz = p.dz * inv;
+        }
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const double *pol = a.pol[m];
+            double Ex_i, Ey_i;
+            if (p.plane_wave) {
+                Ex_i = pol[0] * a.dmom[m];
+                Ey_i = pol[1] * a.dmom[m];
+                Hx_i[m] = -pol[1] * a.dmom[m] / p.Z0;
+                Hy_i[m] = pol[0] * a.dmom[m] / p.Z0;
+            } else {
+                const double amp = a.hcoef[m] * sqrt(uz) * inv;
+                Hx_i[m] = (uy * pol[2] - uz * pol[1]) * amp;
+                Hy_i[m] = (uz * pol[0] - ux * pol[2]) * amp;
+                const double Hz_i = (ux * pol[1] - uy * pol[0]) * amp;
+                Ex_i = (Hy_i[m] * uz - Hz_i * uy) * p.Z0;
+                Ey_i = (Hz_i * ux - Hx_i[m] * uz) * p.Z0;
+            }
+            power_in[m] = Ex_i * Hy_i[m] - Ey_i * Hx_i[m];
+        }
+    }
     ML_MARK(1, idx + aux);
     const bool lens = idx <= a.n_rings;
     const bool peri = lens && idx >= 1;
@@ -484,47 +518,9 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     }
     c2 prop = {1.0, 0.0};   // exp(i k |grating centre - source|) x the plan's column phasor
     {
-        double x = 0.0, y = 0.0, ux = 0.0, uy = 0.0, uz = 1.0;
-        double Hx_i[NP], Hy_i[NP];
+        const double x = x_ld, y = y_ld;
 #pragma unroll
-        for (int m = 0; m < NP; ++m) Hx_i[m] = Hy_i[m] = 0.0;
-        if (lens) {
-            x = x_ld;
-            y = y_ld;
-        }
-        // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
-        // arithmetic)
-        double inv = 1.0;
-        if (lens && !p.plane_wave) {
-            const double dx = x - p.source_x, dy = y - p.source_y;
-            inv = rsqrt_fast(dx * dx + dy * dy + p.dz2);
-            ux = dx * inv;
-            uy = dy * inv;
-            uz = p.dz * inv;
-        }
-#pragma unroll
-        for (int m = 0; m < NP; ++m) {
-            double power_here = 0.0;
-            if (lens) {
-                const double *pol = a.pol[m];
-                double Ex_i, Ey_i;
-                if (p.plane_wave) {
-                    Ex_i = pol[0] * a.dmom[m];
-                    Ey_i = pol[1] * a.dmom[m];
-                    Hx_i[m] = -pol[1] * a.dmom[m] / p.Z0;
-                    Hy_i[m] = pol[0] * a.dmom[m] / p.Z0;
-                } else {
-                    const double amp = a.hcoef[m] * sqrt(uz) * inv;
-                    Hx_i[m] = (uy * pol[2] - uz * pol[1]) * amp;
-                    Hy_i[m] = (uz * pol[0] - ux * pol[2]) * amp;
-                    const double Hz_i = (ux * pol[1] - uy * pol[0]) * amp;
-                    Ex_i = (Hy_i[m] * uz - Hz_i * uy) * p.Z0;
-                    Ey_i = (Hz_i * ux - Hx_i[m] * uz) * p.Z0;
-                }
-                power_here = Ex_i * Hy_i[m] - Ey_i * Hx_i[m];
-            }
-            wave_power(a, power_here, bx, by, m);
-        }
+        for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
         ML_MARK(2, Hx_i[0]);
 
         if (lens && !peri) {
