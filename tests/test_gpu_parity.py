@@ -589,6 +589,38 @@ def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs):
     assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
 
 
+def test_bench_line_contract():
+    """bench.py at N = 1 prints exactly one JSON line with the fields the driver reads: the
+    metric, K timed steps, a roofline object with a fraction <= 1 and the per-launch duration it
+    came from, the CPU baseline timed beside it, and the self-check against the oracle."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', '512', '--farfield', '64',
+           '--diameter', '1.2e-4', '--steps', '3', '--warmup', '1', '--blocks', '2', '--cpu-rows', '32',
+           '--cpu-fft-side', '128']
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d['metric'] == 'aperture x far-field pair-evals/sec' and d['unit'] == 'pair-evals/s'
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
+    assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert abs(d['value'] - 512.0 ** 2 * 64 ** 2 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
+    assert len(d['ms_per_step_blocks']) == 2 and 'workload' in d['config']
+    for key in ('roofline', 'roofline_other'):
+        r = d[key]
+        assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] <= 1 and r['peak'] > 0
+        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['avg_launch_ms'] > 0
+    assert 0 < d['roofline']['step_hbm_frac'] <= 1
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c
+    assert d['cpu_baseline_reference_route']['value'] > 0
+    assert d['rel_err']['nearfield_vs_oracle'] < 1e-12 and d['rel_err']['farfield_E_vs_oracle'] < 1e-12
+
+
 def test_two_gpus_real_rccl(tmp_path):
     """bench.py --gpus 2 with REAL RCCL over xGMI, one rank per GPU: runs only where two GPUs are
     visible (the single-GPU boxes of this pool skip it; the file-communicator test above covers
