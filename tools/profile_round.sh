@@ -29,5 +29,6 @@ timeout 300 $B --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --profil
 timeout 300 $B --pols xyz --profile all 2>/dev/null | tail -1 > $O/bench_pols_xyz.json
 timeout 300 $B --precision f32 --profile all 2>/dev/null | tail -1 > $O/bench_f32.json
 timeout 300 $B --zoom 0.5 --profile all 2>/dev/null | tail -1 > $O/bench_zoom05.json
+timeout 300 $B --zoom 0.7 --profile all 2>/dev/null | tail -1 > $O/bench_zoom07.json
 timeout 300 $B --pair-list 4096 --profile all 2>/dev/null | tail -1 > $O/bench_pairlist4096.json
 ls -la $O
