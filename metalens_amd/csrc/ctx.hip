@@ -186,6 +186,9 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         const int slot = ctx->h_ring_gc[r];
         const TableSlot &t = ctx->slots[slot];
         const TableDesc &d = ctx->h_table_desc[slot];
+        // the field kernel addresses a ring's table with 24-bit products (nearfield_fast.hip)
+        ML_REQUIRE((long long)t.n0 * t.n1 * 4 < (1ll << 24), "table of collection %d is too large (%d x %d nodes)",
+                   slot, t.n0, t.n1);
         double *q = hdr.data() + (size_t)r * RING_HDR;
         q[0] = ctx->h_ring_rc[r];
         q[1] = ctx->h_ring_period[r];

@@ -684,7 +684,9 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
             if (rest) {   // wave-uniform
                 const int l = __ffsll((long long)rest) - 1;
                 const int kl = __builtin_amdgcn_readlane(key, l);
-                const bool mine = key == kl && ((rest >> lane) & 1ull);
+                // every lane with this key is served now (so no served lane can match a later
+                // lead, whose key differs) and kl >= 0 excludes the lanes without a block
+                const bool mine = key == kl;
                 if (mine) myslot = s;
                 rest &= ~__ballot(mine);
                 lead[s] = l;
@@ -712,7 +714,12 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
                     const int no = lead[s] >= 0 ? __builtin_amdgcn_readlane(n_orders, l) : 0;
                     const double2 *base = reinterpret_cast<const double2 *>(((unsigned long long)hi << 32) | lo);
                     have[s] = o < no;
-                    val[s] = have[s] ? base[(long long)o * so + (c >> 1) * s0 + (c & 1) * 4 + q]
+                    // 32-bit element offset from the wave-uniform block address (scalar base +
+                    // lane offset; 24-bit products: o < 16, strides < 2^24 - refresh_ring_locations
+                    // refuses larger tables), instead of 64-bit products per lane and slot
+                    const unsigned off = __umul24((unsigned)o, (unsigned)so) + __umul24((unsigned)(c >> 1), (unsigned)s0) +
+                                         (unsigned)((c & 1) * 4 + q);
+                    val[s] = have[s] ? *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(base) + ((size_t)off << 4))
                                      : make_double2(0.0, 0.0);
                 }
 #pragma unroll
