@@ -498,11 +498,11 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
     const double *ok = a.ring_ok;
     const double2 *node00 = a.ring_tab;
     bool outside = false;
-    // the ring's header and rotation, requested as soon as the record is there: they travel
-    // while the incident field is worked out
-    // (its first and last 16 bytes: the 160-byte record spans two cache lines, which are then in
-    // the L1 when the rest is read; holding all of it across the incident field costs registers
-    // the kernel does not have)
+    // the ring's header and rotation, requested as soon as the record is there.  Of the 160-byte
+    // header: its first and last 16 bytes (it spans two cache lines, both then on their way) and,
+    // in the single-source kernel, the four entries behind the table cell and the staging
+    // address; the table bounds are read where they are used (batches have no registers to hold
+    // more than the two ends until then)
     double2 h0 = {0, 0}, h8 = h0, cs = {1.0, 0.0}, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
     if (peri) {
         const double2 *h = a.ring_hdr + (size_t)(idx - 1) * (RING_HDR / 2);
