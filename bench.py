@@ -437,9 +437,9 @@ def main():
             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('nearfield'),
             'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-            'note': 'compulsory traffic is the 64 B/sample of stores; what bounds the kernel is the '
-                    'chain of dependent loads per wave (record -> ring header / rotation -> table '
-                    'blocks) at four waves per SIMD and fp64 issue, not HBM bandwidth (DESIGN.md 4.1)'}
+            'note': 'compulsory traffic is the 64 B/sample of stores; what bounds the kernel is fp64 '
+                    'issue (vector pipe 73 % busy at four waves per SIMD, ~1000 instructions per '
+                    'wave), not HBM bandwidth (DESIGN.md 4.1)'}
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
