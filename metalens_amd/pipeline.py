@@ -194,8 +194,16 @@ class HotPath:
         n_viol = _lib.c_int(0)
         _lib.check(lib.ml_nearfield_result(ctx.handle, _lib.byref(power), viol, 8,
                                            _lib.byref(n_viol)))
+        # a sample outside the characterisation tables is an error on EVERY rank: the ranks that
+        # did not see it must not walk into the next collective alone
+        left = float(bool(n_viol.value))
+        if self.world > 1 or dist.force_rccl():
+            left = float(dist.allreduce_host(ctx, [left], 'max')[0])
         if n_viol.value:
             _raise_violation(viol[0], ctx)
+        if left:
+            raise ValueError('a sample on another rank fell outside the characterisation tables '
+                             '(that rank reports the value and the bound)')
         P = np.empty(self.shape)
         a_theta = np.empty(self.shape, dtype=np.complex128)
         a_phi = np.empty(self.shape, dtype=np.complex128)
