@@ -40,7 +40,7 @@ SYMBOLS = (
     'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_transform_mirrored',
     'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
     'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
-    'ml_farfield_plan_kernels', 'ml_farfield_set_method',
+    'ml_farfield_plan_kernels', 'ml_farfield_set_method', 'ml_step_overlap',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_host_alloc', 'ml_host_free',
 )
@@ -127,6 +127,7 @@ def load():
     lib.ml_farfield_set_precision.argtypes = [c_void_p, c_int]
     lib.ml_farfield_plan_kernels.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.ml_farfield_set_method.argtypes = [c_void_p, c_int]
+    lib.ml_step_overlap.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
     lib.ml_profile_select.argtypes = [c_void_p, ctypes.c_uint]
     lib.ml_profile_sample.argtypes = [c_void_p, c_int]
@@ -272,6 +273,12 @@ class Context:
         output-pruned FFTs, the others as GEMMs; 'gemm': GEMMs everywhere.  Applies to the
         next plan."""
         check(self.lib.ml_farfield_set_method(self.handle, {'auto': 0, 'gemm': 1}[method]))
+
+    def set_overlap(self, bands=0, nf_waves_per_block=4, fft_lean=True, fft_per_cu=1):
+        """the banded step (metalens_hip.h ml_step_overlap): ``bands`` > 1 runs the synthesis of band
+        b + 1 beside the row transform of band b; 0 switches it off"""
+        check(self.lib.ml_step_overlap(self.handle, int(bands), int(nf_waves_per_block),
+                                       int(bool(fft_lean)), int(fft_per_cu)))
 
     def plan_kernels(self):
         """(stage 1, stage 2) of the active plan: 'gemm', 'folded' or 'fft'"""

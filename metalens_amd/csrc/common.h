@@ -216,6 +216,24 @@ struct FarfieldPlan {
     double unfold_alpha[4] = {0, 0, 0, 0};
 };
 
+// The banded step (ml_step_overlap, nearfield.hip / farfield.hip): the aperture rows are cut
+// into `bands` bands of whole patch rows; the synthesis of band b + 1 (bound by fp64 issue) runs
+// beside the row transform of band b (bound by the LDS pipe and its barriers) on a second stream.
+struct Overlap {
+    int bands = 0;          // 0 / 1: off
+    int wpb = 4;            // waves per synthesis workgroup (1 or 4, nearfield_fast.hip)
+    int lean = 1;           // row transform: the <= 128-VGPR kernel
+    int fft_per_cu = 1;     // ... and its workgroups per CU
+    hipStream_t aux = nullptr;
+    std::vector<hipEvent_t> band_done;     // synthesis of band b is queued up to here
+    hipEvent_t s1_done = nullptr;
+    // band b = listed patches [first[b], first[b + 1]) = aperture rows [row[b], row[b + 1])
+    std::vector<int> first, row;
+    long key[6] = {-1, -1, -1, -1, -1, -1};   // geo_key + (bands, n_active) the table was built for
+    bool live = false;      // the resident fields were synthesised in bands (events valid)
+    int live_rows = 0;
+};
+
 }  // namespace ml
 
 struct ml_ctx {
@@ -311,6 +329,7 @@ struct ml_ctx {
 
     ml::FarfieldPlan plan;
     ml::Profile prof;
+    ml::Overlap ov;
 
     // RCCL.  comm_stream carries the all-reduce of the projected amplitudes and the power kernel
     // behind it; amp_ready[s] / reduce_done[s] order it against the main stream per amplitude slot
@@ -381,6 +400,7 @@ struct ZfftCall {
     const int *kbin;
     double alpha[4];
     int alpha_rb, rows, accumulate;
+    int lean = 0, lean_per_cu = 1;   // pass 1 only: the <= 128-VGPR kernel, workgroups per CU
 };
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
                        long double tol, int *N_eff, int *j0);

@@ -438,6 +438,12 @@ void ml_ctx_destroy(ml_ctx *ctx) {
         }
         (void)hipStreamDestroy(ctx->comm_stream);
     }
+    if (ctx->ov.aux) {
+        (void)hipStreamSynchronize(ctx->ov.aux);
+        for (auto e : ctx->ov.band_done) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(ctx->ov.s1_done);
+        (void)hipStreamDestroy(ctx->ov.aux);
+    }
     for (auto &s : ctx->slots) {
         s.axis0.release();
         s.axis1.release();
@@ -969,6 +975,7 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
     ctx->n_sets = 1;
     ctx->field_set = 0;
     ctx->zero_key[1] = -1;          // caller-supplied fields: nothing known about zeros
+    ctx->ov.live = false;           // ... nor are they a banded synthesis
     ctx->row_first_valid = false;
     return ML_OK;
 }

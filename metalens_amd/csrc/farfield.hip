@@ -869,7 +869,36 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
             for (int k = 0; k < 4; ++k) c.alpha[k] = 1.0;
             c.alpha_rb = c.rows;
             c.accumulate = 0;
-            ML_TRY(zfft_run(ctx->stream, c));
+            Overlap &ov = ctx->ov;
+            if (ov.live && ov.live_rows == nxl && ov.bands > 1 && (int)ov.row.size() == ov.bands + 1) {
+                // the banded step: band b's rows as soon as its synthesis is through, on the second
+                // stream, beside the synthesis of the bands behind it (nearfield.hip banded_launch)
+                for (int b = 0; b < ov.bands; ++b) {
+                    const int r0 = ov.row[b], nb = ov.row[b + 1] - r0;
+                    if (nb <= 0) continue;
+                    ML_HIP(hipStreamWaitEvent(ov.aux, ov.band_done[b], 0));
+                    ZfftCall cb = c;
+                    cb.in = ctx->set_ptr() + (size_t)r0 * ny * 2;
+                    cb.rows = 4 * nb;
+                    cb.in_rb = nb;
+                    cb.in_s1 = (int64_t)nxl * ny;
+                    cb.in_s2 = ny;
+                    cb.row_first = c.row_first ? c.row_first + r0 : nullptr;
+                    cb.rf_mod = nb;
+                    cb.out = pl.stage1.as<double>() + (size_t)r0 * my * 2;
+                    cb.out_rb = nb;
+                    cb.out_s1 = (int64_t)nxl * my;
+                    cb.out_s2 = my;
+                    cb.alpha_rb = cb.rows;
+                    cb.lean = ov.lean;
+                    cb.lean_per_cu = ov.fft_per_cu;
+                    ML_TRY(zfft_run(ov.aux, cb));
+                }
+                ML_HIP(hipEventRecord(ov.s1_done, ov.aux));
+                ML_HIP(hipStreamWaitEvent(ctx->stream, ov.s1_done, 0));
+            } else {
+                ML_TRY(zfft_run(ctx->stream, c));
+            }
         } else if (pl.fold)
             ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->set_ptr(), ny,
                                 pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
@@ -1260,6 +1289,23 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
     ML_TRY(ml_farfield_plan_info(ctx, stage1_kernel));
     const FarfieldPlan &pl = ctx->plan;
     *stage2_kernel = (pl.fft_x.ok && !pl.pair_list) ? 2 : pl.fold2 ? 1 : 0;
+    return ML_OK;
+}
+
+int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(bands >= 0 && bands <= 256, "bands = %d (0 / 1 = off, at most 256)", bands);
+    ML_REQUIRE(nf_waves_per_block == 1 || nf_waves_per_block == 4, "synthesis workgroups have 1 or 4 waves");
+    ML_REQUIRE(fft_per_cu >= 1 && fft_per_cu <= 4, "1 to 4 transform workgroups per CU");
+    ML_HIP(hipSetDevice(ctx->device));
+    // a banded step in flight keeps using the old table: wait for it
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ov.aux) ML_HIP(hipStreamSynchronize(ctx->ov.aux));
+    ctx->ov.bands = bands;
+    ctx->ov.wpb = nf_waves_per_block;
+    ctx->ov.lean = fft_lean ? 1 : 0;
+    ctx->ov.fft_per_cu = fft_per_cu;
+    ctx->ov.live = false;
     return ML_OK;
 }
 

@@ -174,6 +174,48 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     ctx->fields_premod_serial = premod ? pl.serial : -1;
 }
 
+// The synthesis half of the banded step (common.h Overlap): one launch per band of patch rows on
+// the main stream, an event behind each; farfield.hip's stage 1 picks the events up on the second
+// stream.  The band table (where each band starts in the list of active patches) is read back
+// once per (geometry, band count): the list is in patch order.
+static int banded_launch(ml_ctx *ctx, const NfArgs &a, int nx, int ny, const long *geo_key) {
+    Overlap &ov = ctx->ov;
+    const int B = ov.bands, P = (nx + 7) / 8;
+    if (!ov.aux) {
+        ML_HIP(hipStreamCreateWithFlags(&ov.aux, hipStreamNonBlocking));
+        ML_HIP(hipEventCreateWithFlags(&ov.s1_done, hipEventDisableTiming));
+    }
+    while ((int)ov.band_done.size() < B) {
+        hipEvent_t e;
+        ML_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ov.band_done.push_back(e);
+    }
+    const long key[6] = {geo_key[0], geo_key[1], geo_key[2], geo_key[3], B, a.n_active};
+    if (memcmp(key, ov.key, sizeof key) != 0) {
+        std::vector<int2> list((size_t)a.n_active);
+        ML_HIP(hipMemcpyAsync(list.data(), a.active_list, list.size() * sizeof(int2), hipMemcpyDeviceToHost,
+                              ctx->stream));
+        ML_HIP(hipStreamSynchronize(ctx->stream));
+        ov.first.assign(B + 1, 0);
+        ov.row.assign(B + 1, 0);
+        size_t at = 0;
+        for (int b = 0; b <= B; ++b) {
+            const int pr = (int)((long long)P * b / B);   // first patch row of band b
+            while (at < list.size() && list[at].y < pr) ++at;
+            ov.first[b] = b == B ? a.n_active : (int)at;
+            ov.row[b] = std::min(8 * pr, nx);
+        }
+        memcpy(ov.key, key, sizeof key);
+    }
+    for (int b = 0; b < B; ++b) {
+        ML_TRY(nearfield_band_launch(ctx->stream, a, ov.first[b], ov.first[b + 1] - ov.first[b], ov.wpb));
+        ML_HIP(hipEventRecord(ov.band_done[b], ctx->stream));
+    }
+    ov.live = true;
+    ov.live_rows = nx;
+    return ML_OK;
+}
+
 int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny) {
     NfArgs a;
     // this launch reports into the half the previous launch cleared
@@ -225,7 +267,13 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     }
     {
         ProfScope scope(ctx, ML_K_NEARFIELD);
-        ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
+        if (a.use_active && n == 1 && ctx->ov.bands > 1 && nf_mode != 1) {
+            ML_TRY(banded_launch(ctx, a, nx, ny, geo_key));
+            n_partials = a.n_partials;
+        } else {
+            ctx->ov.live = false;
+            ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
+        }
     }
     memcpy(ctx->zero_key, zero_key, sizeof zero_key);
     ML_HIP(hipGetLastError());

@@ -383,10 +383,12 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
 // incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream
 __device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int bx, int by, int member) {
     for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
-    if (threadIdx.x == 0)
+    if ((threadIdx.x & 63) == 0)
         a.partial_power[(size_t)member * a.n_partials + (size_t)by * a.patches_x + bx] = power_here;
-    // (workgroup 0 exists in the full and in the listed grid alike)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && member == 0)
+    // (workgroup 0 exists in the full and in the listed grid alike; wave 0 of it clears the keys.
+    // The bands of a banded synthesis each clear them again, which is harmless: nobody writes
+    // the other half during this launch)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && member == 0 && threadIdx.x < 64)
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
 }
 
@@ -407,6 +409,8 @@ __device__ __forceinline__ void store_fields(const NfArgs &a, int member, int i,
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a);
 // writes the number of per-block power partials it produces to *n_partials
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
+// one band of the banded step (hotpath.hip): listed patches [first, first + count)
+int nearfield_band_launch(hipStream_t stream, const NfArgs &a, int first, int count, int wpb);
 // the source-independent records of the current (grid, layout, tie answers)
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a);
 

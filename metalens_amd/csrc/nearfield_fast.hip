@@ -414,15 +414,39 @@ constexpr int NF_SLOTS = 6;                  // distinct (ring, cell) blocks sta
 constexpr int NF_CHUNK = 4;                  // orders per staging pass (64 lanes = 4 x 4 x 4)
 constexpr int NF_PITCH = NF_CHUNK * 16 + 1;  // +1: blocks start in different 16-byte bank slots
 
-template <bool RECORDS, int NP>
-__global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(const NfArgs a) {
-    __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];
+// WPB = waves (patches) per workgroup.  1: one wave per workgroup (the stand-alone synthesis).
+// 4: the banded step (hotpath.hip), where the transform of the previous band of rows runs beside
+// this kernel: a four-wave workgroup gives back one wave slot on EVERY SIMD when it retires, which
+// is what a four-wave transform workgroup needs to be admitted - single-wave workgroups refill
+// each slot the moment it frees and starve it.  The waves of a workgroup never meet: each has
+// its own LDS blocks and synchronises with itself only (wave_lds_sync).
+template <int WPB>
+__device__ __forceinline__ void wave_lds_sync() {
+    if (WPB == 1) {
+        __syncthreads();
+    } else {
+        // one wave's LDS accesses are served in order; this only stops the compiler moving them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <bool RECORDS, int NP, int WPB>
+__global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_kernel(const NfArgs a) {
+    __shared__ double2 s_tab_all[WPB * NF_SLOTS * NF_PITCH];
+    double2 *s_tab = s_tab_all + (WPB == 1 ? 0 : (threadIdx.x >> 6) * (NF_SLOTS * NF_PITCH));
     const int lane = threadIdx.x & 63;
     const ml_nearfield_params &p = a.p;
     // patch of this wave: the whole grid, or (once the zeros outside the lens are in place) the
     // list of patches that hold lens samples
     int bx = blockIdx.x, by = blockIdx.y;
-    if (a.use_active) {
+    if (WPB > 1) {   // always a listed launch
+        const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
+        if (pi >= a.n_active) return;   // (no workgroup barriers in this form)
+        const int2 pb = a.active_list[pi];
+        bx = pb.x;
+        by = pb.y;
+    } else if (a.use_active) {
         const int2 pb = a.active_list[blockIdx.x];
         bx = pb.x;
         by = pb.y;
@@ -726,7 +750,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
                 for (int s = 0; s < NF_SLOTS; ++s)
                     if (have[s]) s_tab[s * NF_PITCH + lane] = val[s];
             }
-            __syncthreads();
+            wave_lds_sync<WPB>();
             ML_MARK(4, s_tab[lane].x);
             if (myslot >= 0) {
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
@@ -755,7 +779,7 @@ __global__ __launch_bounds__(64, NP == 1 ? 4 : 3) void nearfield_field_kernel(co
                     }
                 }
             }
-            __syncthreads();   // the next pass overwrites the blocks
+            wave_lds_sync<WPB>();   // the next pass overwrites the blocks
         }
     }
     ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
@@ -825,14 +849,35 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
     *n_partials = (int)(full.x * full.y);
     const dim3 grid = a.use_active ? dim3(a.n_active) : full;
-    if (!a.geo_ix)   // diagnostic build only: decisions inline, no records
-        hipLaunchKernelGGL((nearfield_field_kernel<false, 1>), grid, dim3(64), 0, ctx->stream, a);
-    else if (a.n_pol == 1)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1>), grid, dim3(64), 0, ctx->stream, a);
+#ifdef ML_DIAG
+    if (!a.geo_ix) {   // diagnostic build only: decisions inline, no records
+        hipLaunchKernelGGL((nearfield_field_kernel<false, 1, 1>), grid, dim3(64), 0, ctx->stream, a);
+        ML_HIP(hipGetLastError());
+        return ML_OK;
+    }
+#endif
+    if (a.n_pol == 1)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1>), grid, dim3(64), 0, ctx->stream, a);
     else if (a.n_pol == 2)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 2>), grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 2, 1>), grid, dim3(64), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 3>), grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 3, 1>), grid, dim3(64), 0, ctx->stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+// The banded step's synthesis of one band: the listed patches [first, first + count) as
+// workgroups of `wpb` waves (1 or 4), single source, queued on `stream`.
+int nearfield_band_launch(hipStream_t stream, const NfArgs &a0, int first, int count, int wpb) {
+    if (count <= 0) return ML_OK;
+    NfArgs a = a0;
+    a.use_active = 1;
+    a.active_list = a0.active_list + first;
+    a.n_active = count;
+    if (wpb == 4)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 4>), dim3((count + 3) / 4), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1>), dim3(count), dim3(64), 0, stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

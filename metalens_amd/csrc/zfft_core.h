@@ -138,6 +138,27 @@ ZF_HD void stage1_regs(const Geo &g, int t, cd *v, const cd *ta, const cd *tb, c
         lds[ex1_addr(g, t, k2)] = a;
     }
 }
+// the same with the twiddles applied IN PLACE in two steps, W^(4a) then W^b (two products per
+// element instead of one product of two tabulated values and one per element - the same 24
+// complex multiplications per thread, no temporaries): the form of the lean kernel, whose
+// register budget has no room for the nine products.  tw = the [k2][n1] twiddle table in LDS.
+ZF_HD void stage1_inplace(const Geo &g, int t, cd *v, const cd *tw, int n1, cd *lds) {
+    dft16(v);
+#pragma unroll
+    for (int lo = 1; lo < 4; ++lo) {
+        const cd w = tw[lo * 16 + n1];
+#pragma unroll
+        for (int hi = 0; hi < 4; ++hi) v[bin16(4 * hi + lo)] = cmul(v[bin16(4 * hi + lo)], w);
+    }
+#pragma unroll
+    for (int hi = 1; hi < 4; ++hi) {
+        const cd w = tw[(4 * hi) * 16 + n1];
+#pragma unroll
+        for (int lo = 0; lo < 4; ++lo) v[bin16(4 * hi + lo)] = cmul(v[bin16(4 * hi + lo)], w);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) lds[ex1_addr(g, t, k2)] = v[bin16(k2)];
+}
 // stage 2 for thread u = n0 + R3 k2: gather n1 = 0..15, butterflies, result to exchange 2.
 // The caller puts a barrier between gather2() and scatter2() (the two exchanges share the buffer).
 ZF_HD void gather2(const Geo &g, int u, cd *v, const cd *lds) {
