@@ -210,7 +210,7 @@ def main():
                     help='auto: output-pruned FFT on axes whose direction grid sits on the FFT '
                          'lattice (zoom 1), GEMMs elsewhere; gemm: the folded matrix-core GEMMs')
     ap.add_argument('--overlap', default='0',
-                    help="the banded step (metalens_hip.h ml_step_overlap): 'B' or 'B,wpb,lean,per_cu' - "
+                    help="the banded step (metalens_hip.h ml_step_overlap): 'B' or 'B,wpb,lean,per_cu,same_stream' - "
                          'B > 1 bands of aperture rows, the synthesis of band b + 1 runs beside the row '
                          'transform of band b; wpb = waves per synthesis workgroup (1 | 4), lean = the '
                          '<= 128-register row transform (0 | 1), per_cu = its workgroups per CU')
@@ -257,8 +257,8 @@ def main():
                  fuse_modulation=bool(args.fuse_modulation), method=args.method)
 
     ov = [int(v) for v in args.overlap.split(',')]
-    ov = ov + [4, 1, 1][len(ov) - 1:]
-    ctx.set_overlap(ov[0], ov[1], bool(ov[2]), ov[3])
+    ov = ov + [4, 1, 1, 0][len(ov) - 1:]
+    ctx.set_overlap(ov[0], ov[1], bool(ov[2]), ov[3], bool(ov[4]))
     n_pols = len(args.pols)
     if n_pols > 1:
         assert world == 1 and not args.pair_list, '--pols batches are a single-GPU tensor-grid mode'

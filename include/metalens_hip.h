@@ -226,8 +226,11 @@ int ml_farfield_set_method(ml_ctx *ctx, int method);
  * other case runs unbanded.  nf_waves_per_block: 1 or 4 waves per synthesis workgroup (4 lets a
  * four-wave transform workgroup in whenever one retires); fft_lean: the <= 128-register row
  * transform (fits beside three synthesis waves per SIMD); fft_per_cu: its workgroups per CU (1..4).
+ * same_stream = 1 (a measurement aid) queues the banded launches back to back on the one stream,
+ * so that the cost of the banding itself can be told from the effect of running side by side.
  * bands = 0 or 1 switches the banding off (default).                                            */
-int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu);
+int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu,
+                    int same_stream);
 /* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",
  * configs[4] "fp32 GEMM-cast MFMA path").  ML_PRECISION_F64 (default): fp64 matrix cores.
  * ML_PRECISION_F32_GEMM: the folded GEMMs of both stages round their operands to fp32 and

@@ -127,7 +127,7 @@ def load():
     lib.ml_farfield_set_precision.argtypes = [c_void_p, c_int]
     lib.ml_farfield_plan_kernels.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.ml_farfield_set_method.argtypes = [c_void_p, c_int]
-    lib.ml_step_overlap.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
+    lib.ml_step_overlap.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int]
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
     lib.ml_profile_select.argtypes = [c_void_p, ctypes.c_uint]
     lib.ml_profile_sample.argtypes = [c_void_p, c_int]
@@ -177,10 +177,21 @@ class _PinnedPool:
     the pool when the array built on it is garbage-collected, and the next call of the same size
     takes it from there."""
 
-    def __init__(self, keep_bytes=8 << 30):
+    def __init__(self, keep_bytes=None):
         self.free = {}          # nbytes -> [pointer, ...]
         self.kept = 0
+        # page-locked memory kept for re-use (METALENS_PINNED_KEEP_BYTES overrides; 0 = keep none)
+        if keep_bytes is None:
+            keep_bytes = int(os.environ.get('METALENS_PINNED_KEEP_BYTES', 2 << 30))
         self.keep_bytes = keep_bytes
+
+    def drain(self):
+        """give every recycled page-locked buffer back to the system"""
+        for stack in self.free.values():
+            for ptr in stack:
+                load().ml_host_free(c_void_p(ptr))
+        self.free = {}
+        self.kept = 0
 
     def _release(self, ptr, nbytes):
         if self.kept + nbytes <= self.keep_bytes:
@@ -204,7 +215,12 @@ class _PinnedPool:
             self.kept -= nbytes
         else:
             p = c_void_p()
-            check(load().ml_host_alloc(nbytes, byref(p)))
+            if load().ml_host_alloc(nbytes, byref(p)) != 0 or not p.value:
+                # the host cannot pin that much (more): first hand the recycled buffers back,
+                # then fall back to pageable memory (slower copies, same results)
+                self.drain()
+                if load().ml_host_alloc(nbytes, byref(p)) != 0 or not p.value:
+                    return np.empty(shape, dtype=dtype)
             ptr = p.value
         buf = (ctypes.c_char * nbytes).from_address(ptr)
         arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
@@ -274,11 +290,11 @@ class Context:
         next plan."""
         check(self.lib.ml_farfield_set_method(self.handle, {'auto': 0, 'gemm': 1}[method]))
 
-    def set_overlap(self, bands=0, nf_waves_per_block=4, fft_lean=True, fft_per_cu=1):
+    def set_overlap(self, bands=0, nf_waves_per_block=4, fft_lean=True, fft_per_cu=1, same_stream=False):
         """the banded step (metalens_hip.h ml_step_overlap): ``bands`` > 1 runs the synthesis of band
         b + 1 beside the row transform of band b; 0 switches it off"""
         check(self.lib.ml_step_overlap(self.handle, int(bands), int(nf_waves_per_block),
-                                       int(bool(fft_lean)), int(fft_per_cu)))
+                                       int(bool(fft_lean)), int(fft_per_cu), int(bool(same_stream))))
 
     def plan_kernels(self):
         """(stage 1, stage 2) of the active plan: 'gemm', 'folded' or 'fft'"""

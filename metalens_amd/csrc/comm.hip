@@ -233,6 +233,10 @@ int ml_farfield_allreduce(ml_ctx *ctx) {
     }
     ML_HIP(hipSetDevice(ctx->device));
     ML_TRY(flush_unfold(ctx));
+    // an amplitude reduction of an earlier step may still run on comm_stream: two collectives of
+    // one communicator must not be in flight on two streams (the ranks could enqueue them in
+    // different orders)
+    ML_TRY(comm_join(ctx, false));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     pl.amplitudes_reduced = false;
     return allreduce_dev(ctx, pl.vectors.as<double>(), 4 * n * 2, 0, ctx->stream);

@@ -224,6 +224,7 @@ struct Overlap {
     int wpb = 4;            // waves per synthesis workgroup (1 or 4, nearfield_fast.hip)
     int lean = 1;           // row transform: the <= 128-VGPR kernel
     int fft_per_cu = 1;     // ... and its workgroups per CU
+    int same_stream = 0;    // measurement aid: the banded launches back to back on ONE stream
     hipStream_t aux = nullptr;
     std::vector<hipEvent_t> band_done;     // synthesis of band b is queued up to here
     hipEvent_t s1_done = nullptr;

@@ -556,6 +556,8 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
                "ring arrays missing (n_rings=%d)", n_rings);
     ML_REQUIRE(rot_table && tie_table && rot_len >= 1 && ring_rot_center && ring_rot_half,
                "rotation table missing");
+    // the field kernel's block-sharing key packs (ring, i0, i1) into 31 bits (nearfield_fast.hip)
+    ML_REQUIRE(n_rings < (1 << 19), "%d rings: at most %d are supported", n_rings, (1 << 19) - 1);
     for (int r = 0; r < n_rings; ++r)
         ML_REQUIRE(ring_rot_half[r] >= 0 && ring_rot_center[r] - ring_rot_half[r] - 1 >= 0 &&
                        ring_rot_center[r] + ring_rot_half[r] < rot_len,

@@ -876,7 +876,8 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                 for (int b = 0; b < ov.bands; ++b) {
                     const int r0 = ov.row[b], nb = ov.row[b + 1] - r0;
                     if (nb <= 0) continue;
-                    ML_HIP(hipStreamWaitEvent(ov.aux, ov.band_done[b], 0));
+                    hipStream_t s1 = ov.same_stream ? ctx->stream : ov.aux;
+                    if (!ov.same_stream) ML_HIP(hipStreamWaitEvent(ov.aux, ov.band_done[b], 0));
                     ZfftCall cb = c;
                     cb.in = ctx->set_ptr() + (size_t)r0 * ny * 2;
                     cb.rows = 4 * nb;
@@ -892,10 +893,12 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
                     cb.alpha_rb = cb.rows;
                     cb.lean = ov.lean;
                     cb.lean_per_cu = ov.fft_per_cu;
-                    ML_TRY(zfft_run(ov.aux, cb));
+                    ML_TRY(zfft_run(s1, cb));
                 }
-                ML_HIP(hipEventRecord(ov.s1_done, ov.aux));
-                ML_HIP(hipStreamWaitEvent(ctx->stream, ov.s1_done, 0));
+                if (!ov.same_stream) {
+                    ML_HIP(hipEventRecord(ov.s1_done, ov.aux));
+                    ML_HIP(hipStreamWaitEvent(ctx->stream, ov.s1_done, 0));
+                }
             } else {
                 ML_TRY(zfft_run(ctx->stream, c));
             }
@@ -1238,9 +1241,12 @@ int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double con
     a.reset = reset;
     a.weight = weight;
     // dux * duy as the reference takes them (nearfield_farfield.py:71-74); a pair list has no cell
+    // (per axis: an axis of one direction contributes a factor 1)
     a.cell = 1.0;
-    if (!pl.pair_list && pl.mx > 1 && pl.my > 1)
-        a.cell = (pl.h_ux[1] - pl.h_ux[0]) * (pl.h_uy[1] - pl.h_uy[0]);
+    if (!pl.pair_list) {
+        if (pl.mx > 1) a.cell *= pl.h_ux[1] - pl.h_ux[0];
+        if (pl.my > 1) a.cell *= pl.h_uy[1] - pl.h_uy[0];
+    }
     a.cone_u2 = cone_u * cone_u;
     a.cone_ux0 = cone_ux0;
     a.cone_uy0 = cone_uy0;
@@ -1292,7 +1298,8 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
     return ML_OK;
 }
 
-int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu) {
+int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu,
+                    int same_stream) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_REQUIRE(bands >= 0 && bands <= 256, "bands = %d (0 / 1 = off, at most 256)", bands);
     ML_REQUIRE(nf_waves_per_block == 1 || nf_waves_per_block == 4, "synthesis workgroups have 1 or 4 waves");
@@ -1305,6 +1312,7 @@ int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean
     ctx->ov.wpb = nf_waves_per_block;
     ctx->ov.lean = fft_lean ? 1 : 0;
     ctx->ov.fft_per_cu = fft_per_cu;
+    ctx->ov.same_stream = same_stream ? 1 : 0;
     ctx->ov.live = false;
     return ML_OK;
 }

@@ -4,8 +4,9 @@ Drop-in for the reference's ``nearfield.py``: ``build_nearfield``,
 ``build_nearfield_big`` and ``good_fft_number`` keep the reference's signatures,
 argument meaning, return tuples, assertions and ``ValueError`` messages
 (reference nearfield.py:30-36,66-68,84-85,106-109,294-305,412-419,480,482-516).
-The arithmetic runs in the hand-written HIP kernel ``nearfield_kernel``
-(csrc/nearfield.hip) through the C ABI of include/metalens_hip.h; this module
+The arithmetic runs in the hand-written HIP kernels ``nearfield_geometry_kernel``
+(once per grid and layout) and ``nearfield_field_kernel`` (csrc/nearfield_fast.hip;
+csrc/nearfield.hip is their launch code) through the C ABI of include/metalens_hip.h; this module
 only evaluates the scalar set-up with the reference's own expressions, flattens
 the inputs (packing.py) and converts the kernel's bound-check report back into
 the reference's exceptions.  There is no CPU path.

@@ -72,6 +72,60 @@ def farfield_from_nearfield(fftEx, fftEy, fftHx, fftHy, xp_list, yp_list, wavele
     return P, total_P, ux, uy, dux, duy
 
 
+def farfield_from_resident_nearfield(xp_list, yp_list, wavelength, n_glass, *, Z0=None, ctx=None):
+    """The reference's whole far-field flow (README.md:27) from the near field that
+    ``build_nearfield(..., download=False)`` left on the GPU, without the host round trip:
+
+        Ex, Ey, Hx, Hy, x, y, power, n_glass = reference.build_nearfield(...)
+        P, total_P, ux, uy, dux, duy = reference.farfield_from_nearfield(
+            fft2(fftshift(Ex)), fft2(fftshift(Ey)), fft2(fftshift(Hx)), fft2(fftshift(Hy)),
+            x, y, wavelength, n_glass)
+
+    becomes
+
+        _, _, _, _, x, y, power, n_glass = build_nearfield(..., download=False)
+        P, total_P, ux, uy, dux, duy = farfield_from_resident_nearfield(x, y, wavelength, n_glass)
+
+    Same return tuple as the reference (nearfield_farfield.py:75): ``P`` on the WHOLE FFT lattice
+    of the aperture, fft-shifted, NaN outside the unit circle (:153-155), ``total_P`` the sum of the
+    finite ``P * dux * duy`` (:74), ``ux [N,1]``, ``uy [1,N']`` the shifted direction cosines
+    (:35-39,68-70).  The four ``fft2(fftshift(F))`` (:18-20) run on the GPU as the aperture ->
+    direction transform over all lattice bins (the pruned FFT of csrc/zfft.hip with nothing pruned
+    when the axis length is a multiple of 256 up to 8192, the folded GEMMs otherwise), the
+    projection is the same kernel the drop-in ``farfield_from_nearfield`` uses, the finite sum is
+    taken on the GPU (fixed-order tree); only ``P`` crosses PCIe."""
+    Z0 = constants.Z0 if Z0 is None else Z0
+    ctx = ctx or _lib.default_context()
+    dxp = xp_list[1] - xp_list[0]
+    dyp = yp_list[1] - yp_list[0]
+    num_x, num_y = len(xp_list), len(yp_list)
+    _check_axis(xp_list, wavelength)
+    _check_axis(yp_list, wavelength)
+    nx, ny = _lib.c_int(0), _lib.c_int(0)
+    _lib.check(ctx.lib.ml_fields_shape(ctx.handle, _lib.byref(nx), _lib.byref(ny)))
+    if (nx.value, ny.value) != (num_x, num_y):
+        raise ValueError('the resident near field is %d x %d but the axes given have %d and %d '
+                         'points' % (nx.value, ny.value, num_x, num_y))
+    # the reference's lattice, in the reference's own expressions, shifted as it returns it
+    ux_list = np.fft.fftshift(fft_direction_cosines(num_x, dxp, wavelength, n_glass))
+    uy_list = np.fft.fftshift(fft_direction_cosines(num_y, dyp, wavelength, n_glass))
+    t = FarfieldTransform(num_x, num_y, dxp, dyp, wavelength, n_glass, ux_list, uy_list, ctx=ctx)
+    lib = ctx.lib
+    _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
+    _lib.check(lib.ml_farfield_project_async(ctx.handle, Z0))
+    # total_P = sum of the finite P * dux * duy (slot 0 of the sweep sums, reset)
+    _lib.check(lib.ml_farfield_accumulate(ctx.handle, 1.0, 0.0, 0.0, 0.0, 0, 1))
+    P = _lib.pinned.empty((num_x, num_y), np.float64)
+    _lib.check(lib.ml_farfield_project(ctx.handle, Z0, _lib.dptr(P), None, None))
+    total = np.zeros(1)
+    _lib.check(lib.ml_farfield_sums(ctx.handle, None, _lib.dptr(total), None, 1))
+    dux = ux_list[1] - ux_list[0]
+    duy = uy_list[1] - uy_list[0]
+    ux, uy = np.meshgrid(ux_list, uy_list, indexing='ij', sparse=True)
+    del t
+    return P, float(total[0]), ux, uy, dux, duy
+
+
 class FarfieldTransform:
     """Direct aperture -> direction transform for one aperture geometry and one set
     of directions.
@@ -87,8 +141,10 @@ class FarfieldTransform:
     def __init__(self, num_x_total, num_y, dxp, dyp, wavelength, n_glass, ux, uy,
                  pair_list=False, ctx=None, precision=None):
         self.ctx = ctx or _lib.default_context()
-        if precision is not None:   # 'f64' | 'f32' (GEMM arithmetic; a property of the context)
-            self.ctx.set_precision(precision)
+        # 'f64' | 'f32': arithmetic of the GEMMs.  A property of the CONTEXT that plans inherit, so
+        # it is set on every construction: an earlier HotPath(precision='f32') on the same context
+        # must not leak into a transform that documents 1e-12
+        self.ctx.set_precision(precision or 'f64')
         self.ux = _lib.f64(np.ravel(ux))
         self.uy = _lib.f64(np.ravel(uy))
         self.pair_list = bool(pair_list)
@@ -128,10 +184,12 @@ class FarfieldTransform:
 
 
 def farfield_direct(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, uy,
-                    *, pair_list=False, Z0=None, ctx=None):
+                    *, pair_list=False, Z0=None, ctx=None, precision=None):
     """One-shot convenience: far field of host arrays ``Ex..Hy`` (or of the field set
     already resident on the GPU if ``Ex is None``) at the given directions.  Returns a
-    dict with ``Nx, Ny, Lx, Ly, P, a_theta, a_phi``."""
+    dict with ``Nx, Ny, Lx, Ly, P, a_theta, a_phi``.  ``precision``: 'f64' (default, 1e-12)
+    or 'f32' (the fp32 matrix-core GEMMs, 1e-4); whatever an earlier user of the context chose
+    does not carry over."""
     ctx = ctx or _lib.default_context()
     dxp = xp_list[1] - xp_list[0]
     dyp = yp_list[1] - yp_list[0]
@@ -143,7 +201,7 @@ def farfield_direct(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, u
         _lib.check(ctx.lib.ml_fields_upload(ctx.handle, len(xp_list), len(yp_list),
                                             *[_lib.dptr(a) for a in arrs]))
     t = FarfieldTransform(len(xp_list), len(yp_list), dxp, dyp, wavelength, n_glass, ux, uy,
-                          pair_list=pair_list, ctx=ctx)
+                          pair_list=pair_list, ctx=ctx, precision=precision)
     t.transform()
     out = t.radiation_vectors()
     out['P'], out['a_theta'], out['a_phi'] = t.project(Z0)

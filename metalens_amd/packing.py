@@ -123,10 +123,14 @@ def upload_tables(ctx, gratingcollection_list, hexgridset, wavelength_in_nm):
     token = ('tables', wavelength_in_nm, tuple(_digest(t) for t in packed),
              _digest(center) if center is not None else None,
              periods.tobytes() if periods is not None else None)
-    ctx.tables_fingerprint = fp
     if ctx.tables_token == token:
+        ctx.tables_fingerprint = fp
         return
     lib = ctx.lib
+    # nothing is known about the GPU's tables until every upload below has succeeded: a failure
+    # part-way must not leave a fingerprint / token that a later call would take for "resident"
+    ctx.tables_fingerprint = None
+    ctx.tables_token = None
     for slot, t in enumerate(packed):
         a0, a1, a2 = t['axes']
         _lib.check(lib.ml_upload_table(
@@ -141,6 +145,7 @@ def upload_tables(ctx, gratingcollection_list, hexgridset, wavelength_in_nm):
             _lib.iptr(t['orders']), _lib.dptr(t['order_k']), len(t['orders']),
             _lib.dptr(t['values']), _lib.dptr(t['bounds']), _lib.dptr(periods)))
     ctx.tables_token = token
+    ctx.tables_fingerprint = fp
     ctx.table_orders = [p['orders'] for p in packed] + ([center['orders']] if center is not None else [])
 
 

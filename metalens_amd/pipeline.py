@@ -179,12 +179,23 @@ class HotPath:
     def results(self):
         """fetch what the last step left on the GPU; raises the reference's ValueError if a
         sample fell outside the characterisation tables"""
-        redo = 1.0 if self.settle_ties() else 0.0
-        if self.world > 1 or dist.force_rccl():   # every rank repeats the pass or none does
-            redo = float(dist.allreduce_host(self.ctx, [redo], 'max')[0])
-        if redo:
+        # as build_nearfield does: up to three rounds (a settled tie can uncover another), the
+        # answers so far carried along; anything still open after that is an error
+        known = None
+        for _ in range(3):
+            now = (ties.settle(self.ctx, self._cells, self.x_local, self.y, known=known)
+                   if self.x_local.size else None)
+            redo = 0.0 if now is None else 1.0
+            if self.world > 1 or dist.force_rccl():   # every rank repeats the pass or none does
+                redo = float(dist.allreduce_host(self.ctx, [redo], 'max')[0])
+            if not redo:
+                break
+            known = now if now is not None else known
             self.step()
             self.sync()
+        else:
+            if self.x_local.size and ties.pending(self.ctx).size:
+                raise RuntimeError('nearest-cell ties still open after three rounds')
         return self._fetch()
 
     def _fetch(self):

@@ -54,9 +54,6 @@ class SourceSweep:
         self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
         self.dxp, self.dyp = x_pts[1] - x_pts[0], y_pts[1] - y_pts[0]
 
-    def close(self):   # kept for callers of the earlier two-stream implementation
-        pass
-
     def prepare(self):
         """make tables, layout and the far-field plan resident (no-ops when they already are)"""
         ctx, lib = self.ctx, self.ctx.lib
@@ -70,6 +67,7 @@ class SourceSweep:
     def queue(self, sources):
         """queue the whole sweep on the GPU and return without synchronising (benchmarks);
         tie settlement and the downloads are ``run``'s business"""
+        self.prepare()
         weights = np.ones(len(sources))
         for g in self._group(sources):
             self._pass(g, None, (0.0, 0.0, 0.0), weights)
@@ -120,6 +118,9 @@ class SourceSweep:
         if not 1 <= len(sources) <= MAX_SLOTS:
             raise ValueError('a sweep takes 1 to %d sources, got %d' % (MAX_SLOTS, len(sources)))
         weights = np.ones(len(sources)) if weights is None else np.asarray(weights, dtype=float)
+        if weights.shape != (len(sources),):
+            raise ValueError('weights must have one entry per source: got shape %s for %d sources'
+                             % (weights.shape, len(sources)))
         ctx, lib = self.ctx, self.ctx.lib
         self.prepare()
         cone3 = (float(cone) if cone is not None else 0.0, float(cone_center[0]), float(cone_center[1]))
@@ -132,9 +133,19 @@ class SourceSweep:
             if first:
                 # exact nearest-cell ties are a property of grid and cells: settled once, by
                 # asking cKDTree like the reference (ties.py), then the pass is repeated
+                # (as build_nearfield does: up to three rounds - a settled tie can uncover another -
+                # with the answers so far carried along; anything left after that is an error)
                 ctx.sync()
-                if ties.settle(ctx, self._cells, self.x, self.y) is not None:
+                known = None
+                for _ in range(3):
+                    known = ties.settle(ctx, self._cells, self.x, self.y, known=known)
+                    if known is None:
+                        break
                     n = self._pass(g, None, cone3, weights)
+                    ctx.sync()
+                else:
+                    if ties.pending(ctx).size:
+                        raise RuntimeError('nearest-cell ties still open after three rounds')
                 first = False
             pw = np.zeros(n)
             _lib.check(lib.ml_nearfield_powers(ctx.handle, _lib.dptr(pw), n))

@@ -34,7 +34,10 @@ def _hotpath(ctx, side, M, diameter, na, world=1, rank=0):
     import bench
     from metalens_amd.pipeline import HotPath
     wl = 580e-9
-    lens, x, u = bench.build_workload(side, M, diameter, na, wl, 1.0)
+    # directions = bins of the lattice of the next multiple of 256 samples (zero-padded when the
+    # aperture has fewer): the grids the pruned FFT takes
+    n_eff = -(-side // 256) * 256
+    lens, x, u = bench.build_workload(side, M, diameter, na, wl, side / n_eff)
     src = (0.3e-6, -0.2e-6, -lens['source_distance'], 'x')
     hp = HotPath(src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
                  lens['hexgridset'], x, x, u, u, ctx=ctx, rank=rank, world=world)

@@ -502,7 +502,7 @@ def test_f32_gemm_vs_oracle(ma, f32_gemm, shape):
     y = (np.arange(ny) + 11.1) * (wl / 2.3)
     ux = np.linspace(-0.61, 0.55, mx)
     uy = np.linspace(-0.3, 0.72, my)
-    got = ma.farfield_direct(*F, x, y, wl, n, ux, uy)
+    got = ma.farfield_direct(*F, x, y, wl, n, ux, uy, precision='f32')
     want = farfield_oracle.farfield_direct(*F, x, y, wl, n, ux, uy)
     worst = 0.0
     for key in ('Nx', 'Ny', 'Lx', 'Ly', 'a_theta', 'a_phi'):
@@ -513,6 +513,41 @@ def test_f32_gemm_vs_oracle(ma, f32_gemm, shape):
     ok = ~np.isnan(want['P'])
     assert np.array_equal(np.isnan(got['P']), ~ok)
     assert np.abs(got['P'][ok] - want['P'][ok]).max() <= 4 * TOL_F32 * want['P'][ok].max()
+
+
+def test_f32_mode_does_not_leak_into_the_drop_in_transform(ma):
+    """HotPath(precision='f32') and a bare ``set_precision('f32')`` on the default context, then
+    ``farfield_direct()`` / ``FarfieldTransform`` without a precision argument on the same
+    context: they document 1e-12 and must deliver it (precision is set on every construction)"""
+    from metalens_amd import _lib
+    from metalens_amd.pipeline import HotPath
+    from oracle import farfield_oracle
+    ctx = _lib.default_context()
+    wl, n = 580e-9, 1.459
+    try:
+        lens = _synthetic_lens(30e-6, 0.4, wl, switch_deg=9.0)
+        R = lens['lens_periphery_summary']['r_max_list'][-1]
+        xg = np.linspace(-R, R, 256)
+        ug = np.linspace(-0.2, 0.2, 64)
+        hp = HotPath((0.0, 0.0, -lens['source_distance'], 'x'), wl, lens['lens_periphery_summary'],
+                     lens['lens_center_summary'], lens['hexgridset'], xg, xg, ug, ug, ctx=ctx,
+                     precision='f32')
+        hp.step()
+        hp.sync()
+        ctx.set_precision('f32')
+        rng = np.random.default_rng(3)
+        nx, ny = 96, 80
+        F = [rng.standard_normal((nx, ny)) + 1j * rng.standard_normal((nx, ny)) for _ in range(4)]
+        x = (np.arange(nx) - 3.3) * (wl / 2.2)
+        y = (np.arange(ny) + 11.1) * (wl / 2.3)
+        ux = np.linspace(-0.5, 0.5, 40)
+        uy = np.linspace(-0.4, 0.4, 36)
+        got = ma.farfield_direct(*F, x, y, wl, n, ux, uy)
+        want = farfield_oracle.farfield_direct(*F, x, y, wl, n, ux, uy)
+        for key in ('Nx', 'Ny', 'Lx', 'Ly', 'a_theta', 'a_phi'):
+            assert np.abs(got[key] - want[key]).max() <= TOL * np.abs(want[key]).max(), key
+    finally:
+        ctx.set_precision('f64')
 
 
 def test_f32_gemm_hot_path_vs_f64(ma, f32_gemm):

@@ -1,0 +1,115 @@
+"""``farfield_from_resident_nearfield``: the reference's README flow
+``build_nearfield -> fft2(fftshift) x 4 -> farfield_from_nearfield`` (README.md:27,
+nearfield_farfield.py:14-75) with the near field staying on the GPU.  Pinned on the reference's
+own outputs (tests/golden/farfield_*.npz) and on the oracle's restatement of the same flow.
+Needs an MI355X."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_io
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _upload(ctx, fields):
+    from metalens_amd import _lib
+    arrs = [_lib.c128(a) for a in fields]
+    _lib.check(ctx.lib.ml_fields_upload(ctx.handle, arrs[0].shape[0], arrs[0].shape[1],
+                                        *[_lib.dptr(a) for a in arrs]))
+
+
+def test_reference_lattice_golden_window():
+    """the reference's (P, total_P, ux, uy, dux, duy) for a 40 x 48 window, from the window's near
+    field resident on the GPU (the GEMM route: 40 and 48 are not multiples of 256)"""
+    import metalens_amd as ma
+    from metalens_amd import _lib
+    z = np.load(golden_io.golden_path('farfield_B_periphery_window.npz'))
+    nf = np.load(golden_io.golden_path(str(z['nearfield'])))
+    ctx = _lib.default_context()
+    _upload(ctx, [nf[k] for k in ('Ex', 'Ey', 'Hx', 'Hy')])
+    P, total_P, ux, uy, dux, duy = ma.farfield_from_resident_nearfield(
+        nf['x_pts'], nf['y_pts'], float(z['wavelength']), float(z['n_glass']), Z0=float(z['Z0']), ctx=ctx)
+    assert np.array_equal(np.isnan(P), np.isnan(z['P'])) and np.isnan(P).any()
+    ok = ~np.isnan(P)
+    assert np.abs(P[ok] - z['P'][ok]).max() <= 1e-13 * np.nanmax(z['P'])
+    assert abs(total_P - z['total_P']) <= 1e-13 * abs(z['total_P'])
+    assert np.array_equal(ux, z['ux']) and np.array_equal(uy, z['uy'])
+    assert dux == z['dux'] and duy == z['duy']
+
+
+def test_reference_flow_on_the_default_grid_golden():
+    """lens A on the reference's default 400 x 400 grid: build_nearfield(download=False) ->
+    farfield_from_resident_nearfield against what the reference's flow returned (strided sample
+    of P, NaN count, arg-max, total_P, axes)"""
+    import metalens_amd as ma
+    from metalens_amd import _lib
+    z = np.load(golden_io.golden_path('farfield_A_lattice.npz'))
+    case = np.load(golden_io.golden_path(str(z['nearfield'])))
+    lens = golden_io.load_lens(golden_io.golden_path(str(z['lens'])))
+    ctx = _lib.default_context()
+    out = ma.build_nearfield(float(case['source_x']), float(case['source_y']), float(case['source_z']),
+                             str(case['source_pol']), float(case['wavelength']), lens[0], lens[1], lens[2],
+                             dipole_moment=float(case['dipole_moment']), c0=float(case['c0']),
+                             Z0=float(case['Z0']), ctx=ctx, download=False)
+    assert out[0] is None and len(out[4]) == 400
+    P, total_P, ux, uy, dux, duy = ma.farfield_from_resident_nearfield(
+        out[4], out[5], float(z['wavelength']), out[7], Z0=float(z['Z0']), ctx=ctx)
+    s = int(z['stride'])
+    sub = P[3::s, 2::s]
+    ok = ~np.isnan(z['P'])
+    assert np.array_equal(np.isnan(sub), ~ok)
+    assert np.abs(sub[ok] - z['P'][ok]).max() <= 1e-13 * z['P_max']
+    assert np.isnan(P).sum() == z['P_nan_count']
+    assert abs(total_P - z['total_P']) <= 1e-13 * abs(z['total_P'])
+    assert tuple(np.unravel_index(np.nanargmax(P), P.shape)) == tuple(z['P_argmax'])
+    assert np.array_equal(ux, z['ux']) and np.array_equal(uy, z['uy'])
+    assert dux == z['dux'] and duy == z['duy']
+
+
+@pytest.mark.parametrize('N', [512, 768, 500])
+def test_whole_lattice_vs_oracle_flow(N):
+    """a lens window of N x N samples (512, 768: multiples of 256 -> both axes run as the pruned FFT
+    with nothing pruned; 500: the folded GEMMs): every lattice direction against the oracle's
+    restatement of the reference flow (numpy.fft on the host) - ALL N^2 directions, not a sample"""
+    import metalens_amd as ma
+    from metalens_amd import _lib
+    from oracle import farfield_oracle
+    from test_gpu_parity import _synthetic_lens
+    wl = 580e-9
+    lens = _synthetic_lens(60e-6, 0.4, wl, switch_deg=9.0)
+    x = (np.arange(N) - (N - 1) / 2) * (wl / 2.2)
+    args = dict(source_x=0.2e-6, source_y=-0.1e-6, source_z=-lens['source_distance'], source_pol='y',
+                wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'],
+                x_pts=x, y_pts=x)
+    ctx = _lib.default_context()
+    fields = ma.build_nearfield(ctx=ctx, **args)          # host copies for the oracle flow
+    ma.build_nearfield(ctx=ctx, download=False, **args)   # and the resident set
+    P, total_P, ux, uy, dux, duy = ma.farfield_from_resident_nearfield(x, x, wl, fields[7], ctx=ctx)
+    assert ctx.plan_kernels() == (('fft', 'fft') if N % 256 == 0 else ('folded', 'folded'))
+    ffts = [np.fft.fft2(np.fft.fftshift(F)) for F in fields[:4]]
+    want = farfield_oracle.farfield_from_nearfield(*ffts, x, x, wl, fields[7])
+    assert np.array_equal(np.isnan(P), np.isnan(want[0]))
+    ok = ~np.isnan(P)
+    assert np.abs(P[ok] - want[0][ok]).max() <= 1e-12 * np.nanmax(want[0])
+    assert abs(total_P - want[1]) <= 1e-12 * abs(want[1])
+    assert np.array_equal(ux, want[2]) and np.array_equal(uy, want[3])
+    assert dux == want[4] and duy == want[5]
+
+
+def test_shape_mismatch_is_refused():
+    import metalens_amd as ma
+    from metalens_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(0)
+    _upload(ctx, [rng.standard_normal((16, 24)) + 0j for _ in range(4)])
+    x = np.arange(20) * 2e-7
+    with pytest.raises(ValueError):
+        ma.farfield_from_resident_nearfield(x, x, 580e-9, 1.459, ctx=ctx)
