@@ -11,4 +11,5 @@ from .nearfield import build_nearfield, build_nearfield_big, good_fft_number  # 
 from .pipeline import HotPath  # noqa: F401
 from .sweep import SourceSweep  # noqa: F401
 from .nearfield_farfield import (FarfieldTransform, farfield_direct,  # noqa: F401
-                                 farfield_from_nearfield, fft_direction_cosines)
+                                 farfield_from_nearfield, farfield_from_resident_nearfield,
+                                 fft_direction_cosines)

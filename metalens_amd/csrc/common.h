@@ -98,6 +98,10 @@ struct TableDesc {
     double bounds[6];
     double center_kx[MAX_ORDERS];  // centre only: ox*2*pi/x_period, per order
     double center_ky[MAX_ORDERS];
+    // ... the orders themselves and the two reciprocal-lattice steps 2*pi/x_period, 2*pi/y_period:
+    // the field kernel builds an order's phasor as E0 * Ex^ox (* exp(i oy Gy y') when oy != 0)
+    int center_ox[MAX_ORDERS], center_oy[MAX_ORDERS];
+    double center_g[2];
     // (ux, uy) axes inline for the fast kernel when both have <= PACKED_AXIS nodes: node a for
     // a <= n-2 (+inf beyond, so a running compare never selects a padded node) and
     // 1 / (node[a+1] - node[a]); one round of independent loads instead of a pointer chase
@@ -114,7 +118,9 @@ struct TableDesc {
 // record (one round trip instead of ring -> collection -> table descriptor):
 //   [0] r_center  [1] period  [2..7] table bounds  [8..13] uniform (ux, uy) axes: first, step,
 //   1/step per axis  [14] (n0, n1)  [15] (n_orders, flags: bit 0 = axes uniform)
-//   [16] offset of the ring's table in ring_tab  [17] (offset in ring_ok, collection)  [18..19] -
+//   [16] offset of the ring's table in ring_tab  [17] (offset in ring_ok, collection)
+//   [18] 2 pi / period  [19] 2 pi / lateral period (the reciprocal-lattice steps of the ring)
+// ring_ok holds 4 doubles per order of the ring's table: ox 2 pi / period, oy 2 pi / lateral, ox, oy
 constexpr int RING_HDR = 20;
 
 struct TableSlot {
@@ -250,6 +256,7 @@ struct ml_ctx {
     ml::DevBuf table_desc;   // TableDesc[MAX_SLOTS + 1], last = centre
     ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
+    bool simple_orders = false;   // every present table: ox in {-1, 0, 1}, oy = 0 (refresh_table_desc)
 
     // layout
     bool have_layout = false;

@@ -70,9 +70,14 @@ static int refresh_table_desc(ml_ctx *ctx) {
     if (!ctx->tables_dirty) return ML_OK;
     std::vector<TableDesc> h(MAX_SLOTS + 1);
     memset(h.data(), 0, h.size() * sizeof(TableDesc));
+    ctx->simple_orders = true;
     for (int s = 0; s <= MAX_SLOTS; ++s) {
         const TableSlot &t = (s == MAX_SLOTS) ? ctx->center : ctx->slots[s];
         if (!t.present) continue;
+        for (int o = 0; o < t.n_orders; ++o) {
+            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI)), oy = std::lrint(t.h_order_k[2 * o + 1] / (2 * M_PI));
+            if (ox < -1 || ox > 1 || oy != 0) ctx->simple_orders = false;
+        }
         TableDesc &d = h[s];
         d.axis0 = t.axis0.as<double>();
         d.axis1 = t.axis1.as<double>();
@@ -118,7 +123,11 @@ static int refresh_table_desc(ml_ctx *ctx) {
             for (int o = 0; o < t.n_orders; ++o) {
                 d.center_kx[o] = t.h_order_k[2 * o] / t.center_periods[0];
                 d.center_ky[o] = t.h_order_k[2 * o + 1] / t.center_periods[1];
+                d.center_ox[o] = (int)std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
+                d.center_oy[o] = (int)std::lrint(t.h_order_k[2 * o + 1] / (2 * M_PI));
             }
+            d.center_g[0] = 2 * M_PI / t.center_periods[0];
+            d.center_g[1] = 2 * M_PI / t.center_periods[1];
         }
     }
     ML_TRY(h2d(ctx, ctx->table_desc, h.data(), h.size() * sizeof(TableDesc)));
@@ -162,7 +171,7 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         tab_off[r] = (long long)tab_total;
         ok_off[r] = (int32_t)ok_total;
         tab_total += (size_t)t.n_orders * t.n0 * t.n1 * 4;
-        ok_total += (size_t)t.n_orders * 2;
+        ok_total += (size_t)t.n_orders * 4;
     }
     std::vector<double> tab(tab_total * 2), ok(ok_total);
     for (int r = 0; r < ctx->n_rings; ++r) {
@@ -176,8 +185,10 @@ static int refresh_ring_locations(ml_ctx *ctx) {
                 const double *hi = lo + 8;
                 for (int q = 0; q < 8; ++q) *dst++ = lo[q] * w0 + hi[q] * w1;
             }
-            ok[ok_off[r] + 2 * o] = t.h_order_k[2 * o] / ctx->h_ring_period[r];
-            ok[ok_off[r] + 2 * o + 1] = t.h_order_k[2 * o + 1] / ctx->h_ring_lateral[r];
+            ok[ok_off[r] + 4 * o] = t.h_order_k[2 * o] / ctx->h_ring_period[r];
+            ok[ok_off[r] + 4 * o + 1] = t.h_order_k[2 * o + 1] / ctx->h_ring_lateral[r];
+            ok[ok_off[r] + 4 * o + 2] = std::rint(t.h_order_k[2 * o] / (2 * M_PI));       // ox
+            ok[ok_off[r] + 4 * o + 3] = std::rint(t.h_order_k[2 * o + 1] / (2 * M_PI));   // oy
         }
     }
     // per-ring headers (common.h RING_HDR)
@@ -200,6 +211,8 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         memcpy(q + 15, i15, 8);
         memcpy(q + 16, &tab_off[r], 8);
         memcpy(q + 17, i17, 8);
+        q[18] = 2 * M_PI / ctx->h_ring_period[r];
+        q[19] = 2 * M_PI / ctx->h_ring_lateral[r];
     }
     ML_TRY(h2d(ctx, ctx->ring_hdr, hdr.data(), hdr.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_tab, tab.data(), tab.size() * sizeof(double)));

@@ -160,6 +160,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.use_active = 0;
     a.n_active = 0;
     a.patches_x = (ny + 7) / 8;
+    a.simple_orders = ctx->simple_orders ? 1 : 0;
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
     a.row_first = ctx->row_first.as<int>();

@@ -83,6 +83,9 @@ struct NfArgs {
     int2 *active_list;
     int *active_count, *active_flag;
     int use_active, n_active, patches_x;
+    // every table of the lens holds orders ox = -1, 0, 1 with oy = 0 only: the kernels that build
+    // an order's phasor by one product run (nearfield_fast.hip order_phasor), else the general ones
+    int simple_orders;
     // outputs
     // outside_is_zero: the samples outside the lens already hold zeros in `fields` (the previous
     // launch wrote them for the same grid, layout and buffer) and are not stored again

@@ -60,6 +60,41 @@ __device__ __forceinline__ void sincos_cw(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
+// x = r + k pi/2 with |r| <= pi/4 (three-constant Cody-Waite, as above); k fits an int for the
+// |x| < ~1e9 this kernel meets
+__device__ __forceinline__ void reduce_pio2(double x, double &r, int &k) {
+    const double kd = rint(x * 0.63661977236758138243);
+    r = fma(-kd, 1.57079632679489655800e+00, x);
+    r = fma(-kd, 6.12323399573676603587e-17, r);
+    r = fma(-kd, -1.49738490485916983291e-33, r);
+    k = (int)kd;
+}
+
+// sin and cos of x + kq pi/2 (kq = quadrants already split off a larger angle by reduce_pio2)
+__device__ __forceinline__ void sincos_cw_q(double x, int kq, double &s, double &c) {
+    const double k = rint(x * 0.63661977236758138243);          // 2/pi
+    double r = fma(-k, 1.57079632679489655800e+00, x);          // pi/2 hi
+    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid
+    r = fma(-k, -1.49738490485916983291e-33, r);                // pi/2 lo
+    const double z = r * r;
+    double ps = horner(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = horner(z, ps, 2.75573137070700676789e-06);
+    ps = horner(z, ps, -1.98412698298579493134e-04);
+    ps = horner(z, ps, 8.33333333332248946124e-03);
+    ps = horner(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(z * r, ps, r);
+    double pc = horner(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = horner(z, pc, -2.75573143513906633035e-07);
+    pc = horner(z, pc, 2.48015872894767294178e-05);
+    pc = horner(z, pc, -1.38888888888741095749e-03);
+    pc = horner(z, pc, 4.16666666666666019037e-02);
+    const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int q = ((int)k + kq) & 3;
+    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+    s = (q & 2) ? -a : a;
+    c = ((q + 1) & 2) ? -b : b;
+}
+
 // 1 / sqrt(x) to ~1 ulp for well-scaled x (no denormal / overflow handling): hardware estimate
 // + two Newton steps.  Amplitude-type quantities only.
 __device__ __forceinline__ double rsqrt_fast(double x) {
@@ -203,9 +238,40 @@ struct OrderCommon {
     double cxy, cxx, cyy;    // Z0 / (n k_glass kz) x (kx ky, ky^2 + kz^2, -(kx^2 + kz^2))
 };
 
+// The phasor of order (ox, oy) at a sample (nearfield.py:268-269,291 periphery, :391-409 centre):
+//     exp(i ((k u_x' + ox Gx) x' + (k u_y' + oy Gy) y'))  =  E0 * Ex^ox * exp(i oy Gy y')
+// with E0 = exp(i k (u_x' x' + u_y' y')) - the order-(0,0) phase, into which the caller has also
+// folded the propagation phase from the source (one sincos for both) - and Ex = exp(i Gx x').
+// This is the form of the kernels instantiated with GEN = false, chosen when every table of the
+// lens holds orders ox = -1, 0, +1 with oy = 0 only (every order of a round lens' rings that
+// propagates in air): an order then costs at most ONE phasor product instead of a sincos, and a
+// sample two sincos in all instead of one per order + one for the propagation.  Any other order
+// set (|ox| <= 5 in general, grating.lua:406-423; oy != 0 enters with the lateral period) runs the
+// GEN = true kernels, which evaluate every order's argument the reference's way
+// (order_factors_arg) - a sincos inside the order loop costs registers the fast form does not have.
+__device__ __forceinline__ c2 cmulf(c2 a, c2 b) {   // product of two phasors, fused (4 operations)
+    return {fma(a.r, b.r, -(a.i * b.i)), fma(a.r, b.i, a.i * b.r)};
+}
+
+__device__ __forceinline__ c2 order_phasor(c2 E0, c2 Ex, int ox) {   // ox in {-1, 0, 1}
+    const c2 sx = {ox ? Ex.r : 1.0, ox == 0 ? 0.0 : ox < 0 ? -Ex.i : Ex.i};
+    return cmulf(E0, sx);
+}
+
 __device__ __forceinline__ void order_factors(OrderCommon &oc, double kx, double ky, double kz2,
-                                              double k_glass, double inv_n, double Z0, double arg) {
-    sincos_cw(arg, oc.sn, oc.cs);
+                                              double k_glass, double inv_n, double Z0, c2 ph);
+
+__device__ __forceinline__ void order_factors_arg(OrderCommon &oc, double kx, double ky, double kz2,
+                                                  double k_glass, double inv_n, double Z0, double arg) {
+    c2 ph;
+    sincos_cw(arg, ph.i, ph.r);
+    order_factors(oc, kx, ky, kz2, k_glass, inv_n, Z0, ph);
+}
+
+__device__ __forceinline__ void order_factors(OrderCommon &oc, double kx, double ky, double kz2,
+                                              double k_glass, double inv_n, double Z0, c2 ph) {
+    oc.cs = ph.r;
+    oc.sn = ph.i;
     const double g = Z0 * inv_n * recip(k_glass) * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
     oc.cxy = kx * ky * g;
     oc.cxx = fma(ky, ky, kz2) * g;
@@ -431,7 +497,7 @@ __device__ __forceinline__ void wave_lds_sync() {
     }
 }
 
-template <bool RECORDS, int NP, int WPB>
+template <bool RECORDS, int NP, int WPB, bool GEN>
 __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_kernel(const NfArgs a) {
     __shared__ double2 s_tab_all[WPB * NF_SLOTS * NF_PITCH];
     double2 *s_tab = s_tab_all + (WPB == 1 ? 0 : (threadIdx.x >> 6) * (NF_SLOTS * NF_PITCH));
@@ -540,60 +606,121 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
             h7 = h[7];
         }
     }
-    c2 prop = {1.0, 0.0};   // exp(i k |grating centre - source|) x the plan's column phasor
+    // periphery: order (0, 0)'s phasor x the propagation phasor, exp(i Gx x'), Gy y' (order_phasor)
+    // (GEN: the propagation phasor alone in E0, the local coordinates x', y' in xp, yp)
+    c2 E0 = {1.0, 0.0}, Ex1 = {1.0, 0.0};
     {
         const double x = x_ld, y = y_ld;
 #pragma unroll
         for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
         ML_MARK(2, Hx_i[0]);
 
-        if (lens && !peri) {
-            // ================= centre: the record holds the nearest hexagonal cell =================
+        // ================= centre: the record holds the nearest hexagonal cell =================
+        // A centre sample needs per order the 4 table nodes around (ux, uy) x 4 amplitudes of ITS
+        // cell type: 16 complex out of the [order][i0][i1][4][K] table.  The lanes of a patch sit in
+        // ~50 cells of up to K types but (almost always) ONE table cell (i0, i1), so the wave stages
+        // that cell's 16 K complex per order in LDS with K / 4 coalesced loads per lane and every
+        // lane picks its type's 16 values there (conflict-free 16-byte reads) instead of gathering
+        // 16 scattered lines per lane and order from the L1.  Same values, same weights, same order of
+        // additions as the gather, which remains for lanes in another table cell and for K > 24.
+        const bool centre = lens && !peri;
+        if (__any(centre)) {   // wave-uniform
             Acc acc[NP];
 #pragma unroll
             for (int m = 0; m < NP; ++m) acc[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-            if (aux >= 0) {
-                const TableDesc &T = a.center_desc;
-                int i0, i1;
-                double c0, c1;
+            const bool cell = centre && aux >= 0;
+            const TableDesc &T = a.center_desc;
+            const int n2 = T.n2;
+            const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
+            const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
+            // centre table, amplitude-major: [order][i0][i1][4][K]
+            const double2 *tab = a.center_tab;
+            int i0 = 0, i1 = 0, which = 0;
+            double c0 = 0.0, c1 = 0.0, ccx = 0.0, ccy = 0.0, ox_ = 0.0, oy_ = 0.0;
+            bool out_c = false;
+            c2 E0 = {1.0, 0.0}, Exc = {1.0, 0.0};
+            if (cell) {
                 locate_uv(T, ux, uy, i0, c0, i1, c1);
                 const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3];
-                const bool out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
-                const int n2 = T.n2;
-                const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
-                const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
+                out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
                 // the record holds the cell's slot in the bin-sorted arrays
                 const double2 cc = a.cxy[aux];
-                const double ccx = cc.x, ccy = cc.y;
-                const int which = min(a.cwhich[aux], n2 - 1);
-                // centre table, amplitude-major: [order][i0][i1][4][K]
-                const double2 *tab = a.center_tab;
+                ccx = cc.x;
+                ccy = cc.y;
+                which = min(a.cwhich[aux], n2 - 1);
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
-                const double ox_ = x - ccx, oy_ = y - ccy;
-                for (int o = 0; o < T.n_orders; ++o) {
-                    const double kx = fma(p.kvac, ux, T.center_kx[o]);
-                    const double ky = fma(p.kvac, uy, T.center_ky[o]);
-                    const double kt2 = fma(kx, kx, ky * ky);
-                    if (kt2 <= p.kvac2) {
-                        if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
-                        OrderCommon oc;
-                        order_common_gather(oc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which,
-                                            st0, st1, n2, c0, c1);
-                        order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                      kx * ox_ + ky * oy_);
-                        // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
-#pragma unroll
-                        for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
+                ox_ = x - ccx;
+                oy_ = y - ccy;
+                // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
+                // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
+                // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
+                // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
+                if (!GEN) {
+                    double a0 = (p.kvac * ux) * ox_ + (p.kvac * uy) * oy_;
+                    int kq = 0;
+                    if (!p.plane_wave) {
+                        const double gx = ccx - p.source_x, gy = ccy - p.source_y;
+                        const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                        double r;
+                        reduce_pio2(p.kvac * air, r, kq);
+                        a0 = r + a0;
                     }
+                    sincos_cw_q(a0, kq, E0.i, E0.r);
+                    sincos_cw(T.center_g[0] * ox_, Exc.i, Exc.r);
                 }
-                // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
+            }
+            const unsigned long long cells = __ballot(cell);
+            if (cells) {   // wave-uniform
+                const int lead = __ffsll((long long)cells) - 1;
+                const int li0 = __builtin_amdgcn_readlane(i0, lead), li1 = __builtin_amdgcn_readlane(i1, lead);
+                const bool staged = 16 * n2 <= NF_SLOTS * NF_PITCH;   // wave-uniform
+                const bool mine = cell && i0 == li0 && i1 == li1;
+                for (int o = 0; o < T.n_orders; ++o) {
+                    if (staged) {
+                        // element e = (node c = 2 (i0 step) + (i1 step), amplitude q, type k) of the
+                        // leader's table cell: nodes (i0, i1) and (i0, i1 + 1) are contiguous
+                        const double2 *src = tab + o * st_o + (size_t)li0 * st0 + (size_t)li1 * st1;
+                        for (int e = lane; e < 16 * n2; e += 64) {
+                            const int c = e / (4 * n2), rest = e - c * (4 * n2);
+                            s_tab[e] = src[(c >> 1) * st0 + (c & 1) * st1 + rest];
+                        }
+                        wave_lds_sync<WPB>();
+                    }
+                    if (cell) {
+                        const double kx = fma(p.kvac, ux, T.center_kx[o]);
+                        const double ky = fma(p.kvac, uy, T.center_ky[o]);
+                        const double kt2 = fma(kx, kx, ky * ky);
+                        if (kt2 <= p.kvac2) {
+                            if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                            OrderCommon oc;
+                            if (staged && mine)
+                                order_common_gather(oc, s_tab + which, 8 * n2, 4 * n2, n2, c0, c1);
+                            else
+                                order_common_gather(oc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which,
+                                                    st0, st1, n2, c0, c1);
+                            if (GEN)
+                                order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                                  kx * ox_ + ky * oy_);
+                            else
+                                order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                              order_phasor(E0, Exc, T.center_ox[o]));
+                            // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+#pragma unroll
+                            for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
+                        }
+                    }
+                    if (staged) wave_lds_sync<WPB>();   // the next order overwrites the block
+                }
+            }
+            if (cell) {
+                // input modulation of the far-field plan's stage 1, applied here for free (NfArgs);
+                // GEN: and the phase-critical propagation from the cell centre (nearfield.py:453-461)
                 c2 e = {1.0, 0.0};
                 if (a.premod) {
                     const double2 t2 = a.premod[j];
                     e = {t2.x, t2.y};
                 }
-                if (!p.plane_wave) {
-                    // phase-critical: propagation from the cell centre (nearfield.py:453-461)
+                if (GEN && !p.plane_wave) {
                     const double gx = ccx - p.source_x, gy = ccy - p.source_y;
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double sn, cn;
@@ -601,7 +728,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
                     const c2 prop = {cn, sn};
                     e = a.premod ? cmul(prop, e) : prop;
                 }
-                if (!p.plane_wave || a.premod) {
+                if (a.premod || (GEN && !p.plane_wave)) {
 #pragma unroll
                     for (int m = 0; m < NP; ++m) {
                         acc[m].Ex = cmul(acc[m].Ex, e);
@@ -611,10 +738,13 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
                     }
                 }
             }
+            if (centre) {
 #pragma unroll
-            for (int m = 0; m < NP; ++m)
-                store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
-        } else if (inb && !lens && !a.outside_is_zero) {
+                for (int m = 0; m < NP; ++m)
+                    store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
+            }
+        }
+        if (inb && !lens && !a.outside_is_zero) {
             const c2 zero = {0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
@@ -676,21 +806,31 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
             // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
             // block per lane (still correct, just not shared)
             key = (n0 > 64 || n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
-            // input modulation of the far-field plan's stage 1, applied for free (see NfArgs), and
-            // the phase-critical propagation from the grating centre (nearfield.py:337-341);
-            // evaluated HERE so that its arithmetic runs while the table blocks are on their way
-            if (a.premod) {
-                const double2 t2 = a.premod[j];
-                prop = {t2.x, t2.y};
-            }
-            if (!p.plane_wave) {
+            // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
+            // nearfield.py:268-269,291 with ox = oy = 0) times the phase-critical propagation phasor
+            // from the grating centre (:337-341, exact argument), through ONE sincos: the large
+            // angle k |r| is reduced to [-pi/4, pi/4] + quadrants first and the small one added
+            // to the remainder.  Ex = exp(i Gx x').  Evaluated HERE so that the arithmetic runs
+            // while the table blocks are on their way.
+            if (!GEN) {
+                double a0 = (p.kvac * uxp) * xp + (p.kvac * uyp) * yp;
+                int kq = 0;
+                if (!p.plane_wave) {
+                    const double rcen = h0.x;
+                    const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
+                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
+                    double r;
+                    reduce_pio2(p.kvac * air, r, kq);
+                    a0 = r + a0;
+                }
+                sincos_cw_q(a0, kq, E0.i, E0.r);
+                sincos_cw(h[9].x * xp, Ex1.i, Ex1.r);   // 2 pi / period: header slot 18
+            } else if (!p.plane_wave) {
+                // GEN: the propagation phasor on its own; every order evaluates its own argument
                 const double rcen = h0.x;
                 const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
                 const double air = sqrt(gx * gx + gy * gy + p.source_z2);
-                double sn, cn;
-                sincos_cw(p.kvac * air, sn, cn);
-                const c2 e = {cn, sn};
-                prop = a.premod ? cmul(e, prop) : e;   // free ride: one more phasor product
+                sincos_cw(p.kvac * air, E0.i, E0.r);
             }
         }
     }
@@ -757,11 +897,12 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
                 // the order's grating vector one iteration ahead: its load (an L1 hit) is in
                 // flight during the previous order's arithmetic instead of in front of its own
                 typedef double double2v __attribute__((ext_vector_type(2)));
-                const double2v *ok2 = reinterpret_cast<const double2v *>(ok);
-                double2v k_next = NP == 1 ? ok2[o0] : (double2v){0.0, 0.0};
+                const double2v *ok2 = reinterpret_cast<const double2v *>(ok);   // per order: (kx, ky), (ox, oy)
+                double2v k_next = NP == 1 ? ok2[2 * o0] : (double2v){0.0, 0.0};
                 for (int o = o0; o < o1; ++o) {
-                    const double2v k_here = NP == 1 ? k_next : ok2[o];
-                    if (NP == 1) k_next = ok2[min(o + 1, o1 - 1)];
+                    const double2v k_here = NP == 1 ? k_next : ok2[2 * o];
+                    const double2v ord = GEN ? (double2v){0.0, 0.0} : ok2[2 * o + 1];
+                    if (NP == 1) k_next = ok2[2 * min(o + 1, o1 - 1)];
                     const double kxp = fma(p.kvac, uxp, k_here.x);
                     const double kyp = fma(p.kvac, uyp, k_here.y);
                     const double kt2 = fma(kxp, kxp, kyp * kyp);
@@ -772,8 +913,12 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
                         }
                         OrderCommon oc;
                         order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
-                        order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                      kxp * xp + kyp * yp);
+                        if (GEN)
+                            order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                              kxp * xp + kyp * yp);
+                        else
+                            order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                          order_phasor(E0, Ex1, (int)ord.x));
 #pragma unroll
                         for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
                     }
@@ -785,13 +930,20 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
     ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
     if (peri) {
         // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
-        const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
+        const double2 cs2 = (NP == 1 && GEN) ? cs : a.rot_table[aux];
         const double cosr = cs2.x, sinr = cs2.y;
-        const c2 e = prop;
+        // (the propagation phasor already rides in every order's phasor; what is left is the
+        // far-field plan's input modulation, if the plan has one: re-read here, an L2 hit)
+        c2 e = {1.0, 0.0};
+        if (a.premod) {
+            const double2 t2 = a.premod[j];
+            e = {t2.x, t2.y};
+        }
+        if (GEN && !p.plane_wave) e = a.premod ? cmul(E0, e) : E0;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             Acc &q = pr[m];
-            if (!p.plane_wave || a.premod) {
+            if (a.premod || (GEN && !p.plane_wave)) {
                 q.Ex = cmul(q.Ex, e);
                 q.Ey = cmul(q.Ey, e);
                 q.Hx = cmul(q.Hx, e);
@@ -851,17 +1003,24 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     const dim3 grid = a.use_active ? dim3(a.n_active) : full;
 #ifdef ML_DIAG
     if (!a.geo_ix) {   // diagnostic build only: decisions inline, no records
-        hipLaunchKernelGGL((nearfield_field_kernel<false, 1, 1>), grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<false, 1, 1, true>), grid, dim3(64), 0, ctx->stream, a);
         ML_HIP(hipGetLastError());
         return ML_OK;
     }
 #endif
-    if (a.n_pol == 1)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1>), grid, dim3(64), 0, ctx->stream, a);
+    const bool gen = !a.simple_orders;
+    if (a.n_pol == 1 && gen)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, true>), grid, dim3(64), 0, ctx->stream, a);
+    else if (a.n_pol == 1)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, false>), grid, dim3(64), 0, ctx->stream, a);
+    else if (a.n_pol == 2 && gen)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 2, 1, true>), grid, dim3(64), 0, ctx->stream, a);
     else if (a.n_pol == 2)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 2, 1>), grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 2, 1, false>), grid, dim3(64), 0, ctx->stream, a);
+    else if (gen)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 3, 1, true>), grid, dim3(64), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 3, 1>), grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 3, 1, false>), grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
@@ -874,10 +1033,14 @@ int nearfield_band_launch(hipStream_t stream, const NfArgs &a0, int first, int c
     a.use_active = 1;
     a.active_list = a0.active_list + first;
     a.n_active = count;
-    if (wpb == 4)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 4>), dim3((count + 3) / 4), dim3(256), 0, stream, a);
+    if (wpb == 4 && a.simple_orders)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 4, false>), dim3((count + 3) / 4), dim3(256), 0, stream, a);
+    else if (wpb == 4)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 4, true>), dim3((count + 3) / 4), dim3(256), 0, stream, a);
+    else if (a.simple_orders)
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, false>), dim3(count), dim3(64), 0, stream, a);
     else
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1>), dim3(count), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, true>), dim3(count), dim3(64), 0, stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

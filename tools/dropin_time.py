@@ -18,3 +18,15 @@ t1 = time.perf_counter()
 P = ma.farfield_from_nearfield(*ff, x, x, 580e-9, out[7])
 t2 = time.perf_counter()
 print('numpy fft2 x4: %.1f ms; farfield_from_nearfield (drop-in, host in/out): %.1f ms' % ((t1 - t) * 1e3, (t2 - t1) * 1e3))
+# the same flow with the near field staying on the GPU (farfield_from_resident_nearfield)
+for k in range(3):
+    t = time.perf_counter()
+    out2 = ma.build_nearfield(*args, x_pts=x, y_pts=x, download=False)
+    t1 = time.perf_counter()
+    P2 = ma.farfield_from_resident_nearfield(x, x, 580e-9, out2[7])
+    t2 = time.perf_counter()
+    print('resident flow 2048^2: build_nearfield(download=False) %.2f ms + farfield_from_resident_nearfield '
+          '(all 2048^2 lattice directions, P to the host) %.2f ms' % ((t1 - t) * 1e3, (t2 - t1) * 1e3))
+ok = ~np.isnan(P[0])
+print('resident vs host-FFT drop-in: max |dP| / max P = %.2e, total_P rel diff %.2e'
+      % (np.abs(P2[0][ok] - P[0][ok]).max() / np.nanmax(P[0]), abs(P2[1] - P[1]) / abs(P[1])))
