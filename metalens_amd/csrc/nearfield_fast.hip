@@ -615,46 +615,38 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
         for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
         ML_MARK(2, Hx_i[0]);
 
-        // ================= centre: the record holds the nearest hexagonal cell =================
-        // A centre sample needs per order the 4 table nodes around (ux, uy) x 4 amplitudes of ITS
-        // cell type: 16 complex out of the [order][i0][i1][4][K] table.  The lanes of a patch sit in
-        // ~50 cells of up to K types but (almost always) ONE table cell (i0, i1), so the wave stages
-        // that cell's 16 K complex per order in LDS with K / 4 coalesced loads per lane and every
-        // lane picks its type's 16 values there (conflict-free 16-byte reads) instead of gathering
-        // 16 scattered lines per lane and order from the L1.  Same values, same weights, same order of
-        // additions as the gather, which remains for lanes in another table cell and for K > 24.
-        const bool centre = lens && !peri;
-        if (__any(centre)) {   // wave-uniform
+        if (lens && !peri) {
+            // ================= centre: the record holds the nearest hexagonal cell =================
+            // (its table nodes are gathered per lane: the lanes of a patch sit in ~50 cells of up to K
+            // types; staging the wave's table cell through LDS like the ring blocks was measured
+            // twice - per workgroup in round 1, per wave and per order in round 3 - and cost 3-4 %:
+            // the gathers are L1 hits behind the same dependent record load either way)
             Acc acc[NP];
 #pragma unroll
             for (int m = 0; m < NP; ++m) acc[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-            const bool cell = centre && aux >= 0;
-            const TableDesc &T = a.center_desc;
-            const int n2 = T.n2;
-            const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
-            const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
-            // centre table, amplitude-major: [order][i0][i1][4][K]
-            const double2 *tab = a.center_tab;
-            int i0 = 0, i1 = 0, which = 0;
-            double c0 = 0.0, c1 = 0.0, ccx = 0.0, ccy = 0.0, ox_ = 0.0, oy_ = 0.0;
-            bool out_c = false;
-            c2 E0 = {1.0, 0.0}, Exc = {1.0, 0.0};
-            if (cell) {
+            if (aux >= 0) {
+                const TableDesc &T = a.center_desc;
+                int i0, i1;
+                double c0, c1;
                 locate_uv(T, ux, uy, i0, c0, i1, c1);
                 const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3];
-                out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
+                const bool out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
+                const int n2 = T.n2;
+                const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
+                const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
                 // the record holds the cell's slot in the bin-sorted arrays
                 const double2 cc = a.cxy[aux];
-                ccx = cc.x;
-                ccy = cc.y;
-                which = min(a.cwhich[aux], n2 - 1);
+                const double ccx = cc.x, ccy = cc.y;
+                const int which = min(a.cwhich[aux], n2 - 1);
+                // centre table, amplitude-major: [order][i0][i1][4][K]
+                const double2 *tab = a.center_tab;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
-                ox_ = x - ccx;
-                oy_ = y - ccy;
+                const double ox_ = x - ccx, oy_ = y - ccy;
                 // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
                 // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
                 // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
                 // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
+                c2 E0 = {1.0, 0.0}, Exc = {1.0, 0.0};
                 if (!GEN) {
                     double a0 = (p.kvac * ux) * ox_ + (p.kvac * uy) * oy_;
                     int kq = 0;
@@ -668,51 +660,26 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
                     sincos_cw_q(a0, kq, E0.i, E0.r);
                     sincos_cw(T.center_g[0] * ox_, Exc.i, Exc.r);
                 }
-            }
-            const unsigned long long cells = __ballot(cell);
-            if (cells) {   // wave-uniform
-                const int lead = __ffsll((long long)cells) - 1;
-                const int li0 = __builtin_amdgcn_readlane(i0, lead), li1 = __builtin_amdgcn_readlane(i1, lead);
-                const bool staged = 16 * n2 <= NF_SLOTS * NF_PITCH;   // wave-uniform
-                const bool mine = cell && i0 == li0 && i1 == li1;
                 for (int o = 0; o < T.n_orders; ++o) {
-                    if (staged) {
-                        // element e = (node c = 2 (i0 step) + (i1 step), amplitude q, type k) of the
-                        // leader's table cell: nodes (i0, i1) and (i0, i1 + 1) are contiguous
-                        const double2 *src = tab + o * st_o + (size_t)li0 * st0 + (size_t)li1 * st1;
-                        for (int e = lane; e < 16 * n2; e += 64) {
-                            const int c = e / (4 * n2), rest = e - c * (4 * n2);
-                            s_tab[e] = src[(c >> 1) * st0 + (c & 1) * st1 + rest];
-                        }
-                        wave_lds_sync<WPB>();
-                    }
-                    if (cell) {
-                        const double kx = fma(p.kvac, ux, T.center_kx[o]);
-                        const double ky = fma(p.kvac, uy, T.center_ky[o]);
-                        const double kt2 = fma(kx, kx, ky * ky);
-                        if (kt2 <= p.kvac2) {
-                            if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
-                            OrderCommon oc;
-                            if (staged && mine)
-                                order_common_gather(oc, s_tab + which, 8 * n2, 4 * n2, n2, c0, c1);
-                            else
-                                order_common_gather(oc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which,
-                                                    st0, st1, n2, c0, c1);
-                            if (GEN)
-                                order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                                  kx * ox_ + ky * oy_);
-                            else
-                                order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                              order_phasor(E0, Exc, T.center_ox[o]));
-                            // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+                    const double kx = fma(p.kvac, ux, T.center_kx[o]);
+                    const double ky = fma(p.kvac, uy, T.center_ky[o]);
+                    const double kt2 = fma(kx, kx, ky * ky);
+                    if (kt2 <= p.kvac2) {
+                        if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                        OrderCommon oc;
+                        order_common_gather(oc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which,
+                                            st0, st1, n2, c0, c1);
+                        if (GEN)
+                            order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                              kx * ox_ + ky * oy_);
+                        else
+                            order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                          order_phasor(E0, Exc, T.center_ox[o]));
+                        // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
 #pragma unroll
-                            for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
-                        }
+                        for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
                     }
-                    if (staged) wave_lds_sync<WPB>();   // the next order overwrites the block
                 }
-            }
-            if (cell) {
                 // input modulation of the far-field plan's stage 1, applied here for free (NfArgs);
                 // GEN: and the phase-critical propagation from the cell centre (nearfield.py:453-461)
                 c2 e = {1.0, 0.0};
@@ -738,11 +705,9 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_ker
                     }
                 }
             }
-            if (centre) {
 #pragma unroll
-                for (int m = 0; m < NP; ++m)
-                    store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
-            }
+            for (int m = 0; m < NP; ++m)
+                store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
         }
         if (inb && !lens && !a.outside_is_zero) {
             const c2 zero = {0.0, 0.0};
