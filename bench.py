@@ -47,18 +47,58 @@ HBM_PEAK_GBS = 8000.0             # spec; ~6300 GB/s is what a streaming copy re
 
 RGB = ((450e-9, 1.4656), (532e-9, 1.4607), (635e-9, 1.4570))   # configs[3]; n_glass of fused silica
 
-# HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads), measured
-# for the default N = 1 command: profiles/r02*_summary.txt.  None until measured for a config.
-PMC_TRAFFIC = {
-    # (gpus, aperture, farfield, precision, method, zoom): bytes per launch, profiles/r02_summary.txt
-    #   near field: FETCH x2 183 MB (8-byte records of the active patches, tables) + WRITE 729 MB
-    #               (zeros outside the lens are not re-stored)
-    #   stage 1:    FETCH x2 725 MB (rows outside the lens circle are not read) + WRITE 134 MB
-    #   step:       + stage 2 (135 + 17 MB) + projection (17 + 10 MB)
-    # (counted where the L2s meet the fabric: reads the Infinity Cache serves are included)
-    (1, 4096, 512, 'f64', 'auto', 1.0): {'nearfield': 912e6, 'stage1': 859e6, 'step': 1950e6},
-}
+# fp64 vector issue: one fp64 VALU instruction occupies a SIMD for 4 cycles per wave (16 lanes per
+# clock); 256 CUs x 4 SIMDs at 2.4 GHz.  As an instruction rate: 1024 x 2.4e9 / 4 wave-instructions/s.
+SIMDS, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 4
+VALU_PEAK_GINST = SIMDS * CLOCK_HZ / CYCLES_PER_VALU / 1e9     # 614.4 G wave-instructions/s
+
+# Counter figures per launch (HBM bytes = FETCH_SIZE x 2 + WRITE_SIZE in separate rocprofv3 --pmc
+# passes, as MI355X_MICROARCH.md prescribes; SQ_INSTS_VALU; ...) of the configurations that have
+# been profiled: profiles/pmc_table.json, written by tools/pmc_table.py from the rocprofv3 output
+# of the same bench.py command (key = pmc_key() below).  A configuration that has not been
+# profiled reports null - the counters cannot be read from inside the benchmark process.
+def load_pmc_table():
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_table.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def nearfield_roof(avg_ms, nf_bytes, pmc_nf):
+    """roofline object of the synthesis kernel: by fp64 vector issue where the configuration has a
+    counter profile (SQ_INSTS_VALU per launch in ``pmc_nf``), with the HBM figure of the compulsory
+    stores beside it; the HBM figure alone otherwise"""
+    hbm_gbs = nf_bytes / (avg_ms * 1e-3) / 1e9
+    insts = pmc_nf.get('SQ_INSTS_VALU')
+    roof = {
+        'kernel': 'nearfield_field_kernel', 'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
+        'hbm_achieved': hbm_gbs, 'hbm_peak': HBM_PEAK_GBS, 'hbm_frac': hbm_gbs / HBM_PEAK_GBS,
+        'traffic': pmc_nf.get('traffic_bytes'), 'valu_insts': insts}
+    if insts:
+        # THE ROOF THAT BINDS: vector-instruction issue.  SQ_INSTS_VALU wave-instructions per
+        # launch (counter, profiles/pmc_table.json) x 4 cycles each / (1024 SIMDs x 2.4 GHz) is
+        # the time the launch needs if every SIMD issues back to back
+        issue_ms = insts * CYCLES_PER_VALU / (SIMDS * CLOCK_HZ) * 1e3
+        roof.update({'bound': 'valu_fp64', 'achieved': insts / (avg_ms * 1e-3) / 1e9,
+                     'peak': VALU_PEAK_GINST, 'unit': 'G wave-instructions/s',
+                     'frac': issue_ms / avg_ms, 'valu_issue_ms': issue_ms})
+        roof['note'] = ('bound by fp64 vector issue, not HBM: frac = (SQ_INSTS_VALU x 4 cycles / '
+                        '(1024 SIMDs x 2.4 GHz)) / launch time; hbm_frac = the 64 B/sample of '
+                        'compulsory stores / launch time / 8 TB/s (DESIGN.md 4.1, 5)')
+    else:
+        roof.update({'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': hbm_gbs / HBM_PEAK_GBS})
+        roof['note'] = ('no counter profile for this configuration (profiles/pmc_table.json): the HBM '
+                        'figure of the compulsory 64 B/sample of stores; the kernel is bound by fp64 '
+                        'vector issue where it has been profiled (DESIGN.md 4.1)')
+    return roof
+
+
+def pmc_key(gpus, aperture, farfield, precision, method, zoom, pols, overlap):
+    key = ('gpus=%d,aperture=%d,farfield=%d,precision=%s,method=%s,zoom=%g,pols=%d'
+           % (gpus, aperture, farfield, precision, method, zoom, pols))
+    return key + (',overlap=%d' % overlap if overlap > 1 else '')
 
 
 def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0):
@@ -209,6 +249,13 @@ def main():
     ap.add_argument('--method', choices=('auto', 'gemm'), default='auto',
                     help='auto: output-pruned FFT on axes whose direction grid sits on the FFT '
                          'lattice (zoom 1), GEMMs elsewhere; gemm: the folded matrix-core GEMMs')
+    ap.add_argument('--sharding', choices=('auto', 'interleaved', 'mirrored', 'rows'), default='auto',
+                    help='N > 1: how the aperture rows are dealt to the ranks (auto: interleaved blocks '
+                         'where the x direction grid sits on the FFT lattice, else mirrored pairs, else '
+                         'contiguous blocks)')
+    ap.add_argument('--cold', type=int, default=1,
+                    help='1: also time single steps on a sample grid the context has not seen '
+                         '(ms_first_step_new_geometry); N = 1 only')
     ap.add_argument('--overlap', default='0',
                     help="the banded step (metalens_hip.h ml_step_overlap): 'B' or 'B,wpb,lean,per_cu,same_stream' - "
                          'B > 1 bands of aperture rows, the synthesis of band b + 1 runs beside the row '
@@ -254,7 +301,7 @@ def main():
                  pair_list=bool(args.pair_list),
                  rank=0 if replicas else rank, world=1 if replicas else world,
                  precision=args.precision, reduce=args.reduce,
-                 fuse_modulation=bool(args.fuse_modulation), method=args.method)
+                 fuse_modulation=bool(args.fuse_modulation), method=args.method, sharding=args.sharding)
 
     ov = [int(v) for v in args.overlap.split(',')]
     ov = ov + [4, 1, 1, 0][len(ov) - 1:]
@@ -358,8 +405,8 @@ def main():
                    '%d listed directions' % args.pair_list if args.pair_list else
                    '%dx%d far-field directions (bins of the aperture FFT lattice x %g)'
                    % (u.size, u.size, args.zoom)))
-        par = ('aperture rows (mirrored pairs) sharded over %d GPU(s), 1 RCCL all-reduce of the %s'
-               % (world, 'two projected amplitudes' if args.reduce == 'amplitudes'
+        par = ('aperture rows (%s) sharded over %d GPU(s), 1 RCCL all-reduce of the %s'
+               % (hp.sharding, world, 'two projected amplitudes' if args.reduce == 'amplitudes'
                   else 'four radiation vectors'))
     line = {
         'metric': 'aperture x far-field pair-evals/sec',
@@ -373,7 +420,8 @@ def main():
         'config': {'workload': what, 'aperture': side, 'farfield': u.size,
                    'rings': int(len(lens['lens_periphery_summary']['r_center_list'])),
                    'centre_cells': int(len(lens['lens_center_summary'])),
-                   'parallelism': par, 'sources_per_step': n_pols,
+                   'parallelism': par, 'sharding': hp.sharding, 'sources_per_step': n_pols,
+                   'overlap_bands': ov[0],
                    'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]}},
         # the same K steps again, args.blocks times in all: spread of the measurement
         'ms_per_step_blocks': block_ms, 'ms_per_step_median': float(np.median(block_ms)),
@@ -392,11 +440,14 @@ def main():
                                    for k, v in prof.items() if v['launches']}
     line['kernel_timing'] = {'mode': args.profile, 'timed_every_n_steps': every}
     local_rows = hp.x_local.size
-    cfg_key = (world, side, u.size, args.precision, args.method, args.zoom)
+    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols, ov[0])
+    line['config']['pmc_key'] = key
+    pmc = load_pmc_table().get(key, {})
     roofs = {}
     s1 = prof['zgemm_stage1']
     if s1['launches']:
         avg_ms = s1['total_ms'] / s1['launches']
+        traffic = pmc.get('stage1', {}).get('traffic_bytes')
         if stage_kernels[0] == 'fft':
             nbytes = 64.0 * local_rows * side + 64.0 * local_rows * u.size
             achieved = nbytes / (avg_ms * 1e-3) / 1e9
@@ -404,11 +455,17 @@ def main():
                 'bound': 'hbm', 'kernel': 'zfft_kernel (stage 1, output-pruned FFT in LDS)',
                 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('stage1'),
+                'traffic': traffic,
+                # the same by the bytes the counters saw (rows outside the lens circle are known
+                # zeros and are not read, so this is the kernel's real HBM rate)
+                'traffic_gbs': traffic / (avg_ms * 1e-3) / 1e9 if traffic else None,
+                'traffic_frac': traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                 'avg_launch_ms': avg_ms, 'bytes_per_launch': nbytes,
                 'note': 'algorithmic bytes = every aperture sample read once (4 fields x 16 B) + the '
                         'row transforms written; samples outside the lens circle are known zeros '
-                        'and are not read, so traffic can be below bytes_per_launch'}
+                        'and are not read, so traffic is below bytes_per_launch and frac (algorithmic) '
+                        'above traffic_frac (measured); what bounds the kernel is the LDS pipe and '
+                        'its barriers (DESIGN.md 4.2)'}
         else:
             flops = 8.0 * 4 * local_rows * side * u.size
             mfma_peak = FP64_MFMA_PEAK_TFLOPS if args.precision == 'f64' else FP32_MFMA_PEAK_TFLOPS
@@ -429,7 +486,7 @@ def main():
                           + ' (stage 1)' + (', fp32 matrix cores' if args.precision == 'f32' else ''),
                 'achieved': achieved, 'peak': mfma_peak, 'unit': 'TFLOP/s',
                 'frac': achieved / mfma_peak,
-                'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('stage1'),
+                'traffic': traffic,
                 'avg_launch_ms': avg_ms, 'flops_per_launch': executed,
                 'algorithmic_tflops': flops / (avg_ms * 1e-3) / 1e12,
                 'note': 'achieved = flops EXECUTED on the matrix cores / time (matrix-pipe occupancy '
@@ -437,17 +494,9 @@ def main():
                         '(sample, direction) pair, of which the folded kernel executes a quarter'}
     nf = prof['nearfield']
     if nf['launches']:
-        nf_bytes = 64.0 * local_rows * side
-        avg_ms = nf['total_ms'] / nf['launches']
-        achieved = nf_bytes / (avg_ms * 1e-3) / 1e9
-        roofs['nearfield'] = {
-            'bound': 'hbm', 'kernel': 'nearfield_field_kernel', 'achieved': achieved,
-            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': PMC_TRAFFIC.get(cfg_key, {}).get('nearfield'),
-            'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-            'note': 'compulsory traffic is the 64 B/sample of stores; what bounds the kernel is fp64 '
-                    'issue (vector pipe 73 % busy at four waves per SIMD, ~1000 instructions per '
-                    'wave), not HBM bandwidth (DESIGN.md 4.1)'}
+        # one field set (4 complex128 planes) per member of a polarisation batch
+        nf_bytes = 64.0 * local_rows * side * n_pols
+        roofs['nearfield'] = nearfield_roof(nf['total_ms'] / nf['launches'], nf_bytes, pmc.get('nearfield', {}))
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
@@ -455,12 +504,41 @@ def main():
             line['roofline_other'] = roofs[order[1]]
         # the whole step against the north_star's bound: compulsory bytes (the
         # four fields once + the four radiation vectors) / step time / HBM peak
-        step_bytes = (64.0 * side * side + 64.0 * n_dir) * (world if replicas else 1)
+        step_bytes = (64.0 * side * side + 64.0 * n_dir) * (world if replicas else 1) * n_pols
         line['roofline']['step_hbm_frac'] = step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
         line['roofline']['step_bytes'] = step_bytes
-        line['roofline']['step_traffic'] = PMC_TRAFFIC.get(cfg_key, {}).get('step')
+        line['roofline']['step_traffic'] = pmc.get('step_traffic_bytes')
     if rel_err is not None:
         line['rel_err'] = rel_err
+    # ---- what a single call on a NEW sample grid costs (rows a1 / a5 of the scope table are plan-like:
+    # the geometry kernel, the two scans, the list read-back and the first launch that also stores the
+    # zeros outside the lens run once per geometry, outside the timed region above).  Same lens,
+    # tables and directions; the grid shifted by a fraction of its pitch.
+    if world == 1 and n_pols == 1 and not args.pair_list and args.cold:
+        shift = 0.37 * (x[1] - x[0])
+        hp2 = HotPath(source, wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                      lens['hexgridset'], x + shift, x + shift, ux, uy, ctx=ctx, precision=args.precision,
+                      fuse_modulation=bool(args.fuse_modulation), method=args.method)
+        ctx.sync()
+        t0 = time.perf_counter()
+        hp2.step()
+        hp2.sync()
+        t1 = time.perf_counter()
+        hp2.step()
+        hp2.sync()
+        t2 = time.perf_counter()
+        hp2.step()
+        hp2.sync()
+        t3 = time.perf_counter()
+        line['ms_first_step_new_geometry'] = 1e3 * (t1 - t0)
+        line['cold_step'] = {
+            'first_ms': 1e3 * (t1 - t0), 'second_ms': 1e3 * (t2 - t1), 'third_ms': 1e3 * (t3 - t2),
+            'note': 'host-timed single steps (queue + sync) on a sample grid the context has not seen: '
+                    'first = axes upload, plan tables, row extents, geometry kernel + scans, a synthesis '
+                    'over ALL patches that also stores the zeros outside the lens, transform, projection; '
+                    'second = reads the active-patch count back (one sync) and launches the listed '
+                    'patches; third = a steady single step, launch latency included (the timed region '
+                    'queues its steps back to back)'}
     if rank == 0 and world == 1:
         if args.cpu_rows > 0 and not args.pair_list:
             line['cpu_baseline'] = cpu_baseline(lens, x, u, wavelength, min(args.cpu_rows, side),

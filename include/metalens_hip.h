@@ -292,6 +292,19 @@ int ml_nearfield_async(ml_ctx *ctx, const ml_nearfield_params *p,
                        const double *x_pts, int nx, const double *y_pts, int ny);
 int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate);
 int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate);
+/* INTERLEAVED row shards (multi-GPU; the aperture sum of nearfield_farfield.py:
+ * 111-138 is linear in the rows, so any partition of them is exact).  Rank r of n_ranks holds the
+ * rows n = block (n_ranks m + r) + i, i < block: blocks of `block` rows dealt round robin, resident
+ * in that order.  With the rows dealt this way a rank's partial sum along x is `block` short DFTs of
+ * nx_total / (block n_ranks) samples on the plan's own bins (decimation in time), so the column pass
+ * costs every rank 1 / n_ranks of the whole aperture's - a contiguous or mirrored block of rows
+ * costs each rank the full-length pass - and the ranks' loads balance by construction (every rank
+ * crosses the centre disc and the rim alike).  ml_farfield_interleave_block: the block size for
+ * the ACTIVE plan and n_ranks, 0 if the plan cannot be sharded this way (x axis not on the pruned
+ * FFT, lattice longer than the aperture, nx_total not a multiple of 256 n_ranks): shard by
+ * mirrored or contiguous rows then.                                                             */
+int ml_farfield_interleave_block(ml_ctx *ctx, int n_ranks, int *block);
+int ml_farfield_transform_interleaved_async(ml_ctx *ctx, int block, int n_ranks, int rank, int accumulate);
 int ml_farfield_project_async(ml_ctx *ctx, double Z0);
 /* ---- batched sources --------------------------------------------
  * The reference's use of this path is the INCOHERENT sum over x-, y- and z-polarised dipoles,

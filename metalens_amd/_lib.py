@@ -41,6 +41,7 @@ SYMBOLS = (
     'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
     'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
     'ml_farfield_plan_kernels', 'ml_farfield_set_method', 'ml_step_overlap',
+    'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_host_alloc', 'ml_host_free',
 )
@@ -128,6 +129,8 @@ def load():
     lib.ml_farfield_plan_kernels.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.ml_farfield_set_method.argtypes = [c_void_p, c_int]
     lib.ml_step_overlap.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int]
+    lib.ml_farfield_interleave_block.argtypes = [c_void_p, c_int, POINTER(c_int)]
+    lib.ml_farfield_transform_interleaved_async.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
     lib.ml_profile_select.argtypes = [c_void_p, ctypes.c_uint]
     lib.ml_profile_sample.argtypes = [c_void_p, c_int]

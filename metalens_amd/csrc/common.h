@@ -182,6 +182,11 @@ struct FarfieldPlan {
     int method = 0;    // ml_farfield_set_method value the plan was made under
     ZfftAxis fft_y, fft_x;
     DevBuf fft_tw1;
+    // column pass of an interleaved row shard (transform_impl): tables of its `block` short
+    // transforms and what they were built for (plan serial, block, ranks, rank)
+    DevBuf il_wk, il_pj, il_kbin;
+    long il_key[4] = {-1, -1, -1, -1};
+    int il_pad1 = 0, il_pad2 = 0;
     long serial = 0;   // incremented by every ml_farfield_plan call
     bool amplitudes_reduced = false;   // ml_farfield_project_reduce ran on the current vectors
     int nx_total = 0, ny = 0, mx = 0, my = 0, pair_list = 0;
@@ -415,6 +420,8 @@ bool zfft_commensurate(int n, double step, long double kappa, const double *u, i
 int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M,
                       int j0, int N_eff, int c);
 void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2);
+int zfft_build_interleave_tables(hipStream_t stream, double *wk, double *pj, int *kbin, int M, int j0, int Nsub,
+                                 int N, int c, int first, int block);
 int zfft_run(hipStream_t stream, const ZfftCall &c);
 // comm.hip
 void comm_release(ml_ctx *ctx);

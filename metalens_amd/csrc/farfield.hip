@@ -753,8 +753,33 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     return ML_OK;
 }
 
-static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
+// Block size of an interleaved shard over n_ranks ranks: rank r holds the rows n = s (G m + r) + i,
+// i < s - blocks of s rows, dealt round robin.  The column pass of such a shard is s transforms of
+// Nsub = N / (s G) points per column (decimation in time: the partial sum over rows sG apart IS a
+// short DFT on the same bins), i.e. 1 / G of the whole aperture's column pass, where a contiguous
+// or mirrored block of rows costs every rank the full-length pass.  Needs the x axis on the pruned
+// FFT with a lattice of exactly the aperture's rows; Nsub = 256 R3 with R3 <= 32.  s is taken as
+// large as that allows (up to 8: the synthesis works on 8-row patches and wants neighbouring rows).
+static int interleave_block(const FarfieldPlan &pl, int n_ranks) {
+    if (!pl.ready || pl.pair_list || !pl.fft_x.ok || pl.fft_x.N_eff != pl.nx_total || n_ranks < 2) return 0;
+    const int N = pl.nx_total;
+    for (int s = 8; s >= 1; s >>= 1) {
+        if (N % (s * n_ranks * 256) != 0) continue;
+        const int r3 = N / (s * n_ranks * 256);
+        if (r3 >= 1 && r3 <= 32) return s;
+    }
+    return 0;
+}
+
+struct Shard {
+    int kind = 0;          // 0: rows [row0, row0 + nx), 1: mirrored pairs from row0, 2: interleaved
+    int row0 = 0;
+    int block = 0, n_ranks = 1, rank = 0;   // kind 2
+};
+
+static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     ML_REQUIRE(ctx, "ctx is NULL");
+    const int row0 = sh.row0, mirrored = sh.kind == 1;
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready) {
         set_error("ml_farfield_plan has not been called");
@@ -766,7 +791,14 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     }
     ML_REQUIRE(ctx->ny == pl.ny, "resident fields have ny=%d but the plan has ny=%d", ctx->ny,
                pl.ny);
-    if (mirrored) {
+    if (sh.kind == 2) {
+        ML_REQUIRE(sh.block >= 1 && sh.block == interleave_block(pl, sh.n_ranks),
+                   "interleaved shard: block %d is not what ml_farfield_interleave_block gives for %d ranks "
+                   "on this plan (%d)", sh.block, sh.n_ranks, interleave_block(pl, sh.n_ranks));
+        ML_REQUIRE(sh.rank >= 0 && sh.rank < sh.n_ranks && ctx->nx == pl.nx_total / sh.n_ranks,
+                   "interleaved shard: rank %d of %d with %d resident rows of %d", sh.rank, sh.n_ranks,
+                   ctx->nx, pl.nx_total);
+    } else if (mirrored) {
         ML_REQUIRE(ctx->nx % 2 == 0 && row0 >= 0 && 2 * row0 + ctx->nx <= pl.nx_total,
                    "mirrored shard: %d resident rows starting at %d do not form row pairs of a "
                    "%d-row aperture", ctx->nx, row0, pl.nx_total);
@@ -811,7 +843,7 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     const bool whole = (row0 == 0 && nxl == pl.nx_total);
     const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
     const bool fft1 = pl.fft_y.ok, fft2 = pl.fft_x.ok && !pl.pair_list;
-    const bool use_fold2 = !fft2 && !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole);
+    const bool use_fold2 = !fft2 && !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole) && sh.kind != 2;
     // both stages folded: stage 1 writes its result already transposed for stage 2
     static const bool no_direct = diag_int("ML_NO_GT_DIRECT", 0) != 0;
     const bool gt_direct = pl.fold && use_fold2 && !no_direct;
@@ -928,7 +960,58 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
         }
         return ML_OK;
     };
-    if (fft2) {
+    if (sh.kind == 2) {
+        // stage 2 of an interleaved shard: `block` short transforms per column (see interleave_block).
+        // Transform i reads the local rows i, i + s, i + 2 s, ... of column (f, b) and adds its M
+        // bins, carried to the full lattice by pj[i][.], into V[3 - f][.][b]
+        ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
+        ML_TRY(collapse_stage1());
+        const int s = sh.block, G = sh.n_ranks, N = pl.nx_total, Nsub = N / (s * G);
+        const long key[4] = {pl.serial, s, G, sh.rank};
+        if (memcmp(key, pl.il_key, sizeof key) != 0) {
+            ML_TRY(pl.il_wk.reserve((size_t)mx * 2 * sizeof(double)));
+            ML_TRY(pl.il_kbin.reserve((size_t)mx * sizeof(int)));
+            ML_TRY(pl.il_pj.reserve((size_t)s * mx * 2 * sizeof(double)));
+            ML_TRY(zfft_build_interleave_tables(ctx->stream, pl.il_wk.as<double>(), pl.il_pj.as<double>(),
+                                                pl.il_kbin.as<int>(), mx, pl.fft_x.j0, Nsub, N, N - N / 2,
+                                                s * sh.rank, s));
+            zfft_choose_pads(Nsub, mx, pl.fft_x.j0, &pl.il_pad1, &pl.il_pad2);
+            memcpy(pl.il_key, key, sizeof key);
+        }
+        for (int i = 0; i < s; ++i) {
+            ZfftCall c;
+            c.N_eff = Nsub;
+            c.n_valid = Nsub;
+            c.M = mx;
+            c.j0 = pl.fft_x.j0;
+            c.pad1 = pl.il_pad1;
+            c.pad2 = pl.il_pad2;
+            c.in = pl.stage1.as<double>() + (size_t)i * my * 2;
+            c.rows = 4 * my;
+            c.in_rb = my;
+            c.in_s1 = (int64_t)nxl * my;
+            c.in_s2 = 1;
+            c.in_es = (int64_t)s * my;
+            c.a0 = 0;
+            c.h0 = Nsub;
+            c.a1 = c.h1 = 0;
+            c.row_first = nullptr;
+            c.rf_mod = 1;
+            c.out = pl.vectors.as<double>() + (size_t)3 * mx * my * 2;
+            c.out_rb = my;
+            c.out_s1 = -(int64_t)mx * my;
+            c.out_s2 = 1;
+            c.out_es = my;
+            c.tw1 = pl.fft_tw1.as<double>();
+            c.wk = pl.il_wk.as<double>();
+            c.pj = pl.il_pj.as<double>() + (size_t)i * mx * 2;
+            c.kbin = pl.il_kbin.as<int>();
+            for (int k = 0; k < 4; ++k) c.alpha[k] = alpha[k];
+            c.alpha_rb = my;
+            c.accumulate = (i > 0) ? 1 : accumulate;
+            ML_TRY(zfft_run(ctx->stream, c));
+        }
+    } else if (fft2) {
         // stage 2 along x as a pruned FFT over the columns of stage 1's result: row (f, b) reads
         // G[f][n1][b] for the resident n1 (zero elsewhere) and writes V[3 - f][a][b] * alpha_f
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
@@ -1011,24 +1094,50 @@ static int transform_impl(ml_ctx *ctx, int row0, int mirrored, int accumulate) {
     return ML_OK;
 }
 
+static Shard block_shard(int row0, int mirrored) {
+    Shard sh;
+    sh.kind = mirrored ? 1 : 0;
+    sh.row0 = row0;
+    return sh;
+}
+
 int ml_farfield_transform_async(ml_ctx *ctx, int row0, int accumulate) {
-    return transform_impl(ctx, row0, 0, accumulate);
+    return transform_impl(ctx, block_shard(row0, 0), accumulate);
 }
 
 int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate) {
-    return transform_impl(ctx, row0, 1, accumulate);
+    return transform_impl(ctx, block_shard(row0, 1), accumulate);
 }
 
 int ml_farfield_transform(ml_ctx *ctx, int row0, int accumulate) {
-    ML_TRY(transform_impl(ctx, row0, 0, accumulate));
+    ML_TRY(transform_impl(ctx, block_shard(row0, 0), accumulate));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return prof_harvest(ctx);
 }
 
 int ml_farfield_transform_mirrored(ml_ctx *ctx, int row0, int accumulate) {
-    ML_TRY(transform_impl(ctx, row0, 1, accumulate));
+    ML_TRY(transform_impl(ctx, block_shard(row0, 1), accumulate));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return prof_harvest(ctx);
+}
+
+int ml_farfield_interleave_block(ml_ctx *ctx, int n_ranks, int *block) {
+    ML_REQUIRE(ctx && block, "NULL argument");
+    if (!ctx->plan.ready) {
+        set_error("ml_farfield_plan has not been called");
+        return ML_ESTATE;
+    }
+    *block = interleave_block(ctx->plan, n_ranks);
+    return ML_OK;
+}
+
+int ml_farfield_transform_interleaved_async(ml_ctx *ctx, int block, int n_ranks, int rank, int accumulate) {
+    Shard sh;
+    sh.kind = 2;
+    sh.block = block;
+    sh.n_ranks = n_ranks;
+    sh.rank = rank;
+    return transform_impl(ctx, sh, accumulate);
 }
 
 static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream = nullptr) {

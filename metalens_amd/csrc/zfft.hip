@@ -248,6 +248,91 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     }
 }
 
+// Short transforms (N_eff = 256 or 512: R3 = 1, 2), several rows per workgroup.  The column pass of
+// an INTERLEAVED row shard (farfield.hip transform_impl: rank r of G holds the rows n = s (G m + r)
+// + i) is s transforms of N / (s G) points per column instead of one of N points, and sixteen or
+// thirty-two threads are no workgroup: `cpw` rows share one, each with its own exchange buffer,
+// all in step.  Plain form of the kernel above: no prefetch, twiddles applied in place.
+template <int PASS>
+__global__ __launch_bounds__(256) void zfft_multi_kernel(const FftArgs a, int cpw) {
+    extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
+    const zf::Geo g = a.g;
+    const int NT = 16 * g.R3, sub = threadIdx.x / NT, tid = threadIdx.x - sub * NT;
+    cd *lds = reinterpret_cast<cd *>(zfft_lds_raw) + (size_t)sub * zf::lds_elems(g);
+    cd *s_tw = reinterpret_cast<cd *>(zfft_lds_raw) + (size_t)cpw * zf::lds_elems(g);
+    for (int e = threadIdx.x; e < 256; e += blockDim.x) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];
+    const int n1 = tid / g.R3;
+    __syncthreads();
+    const int groups = (a.rows + cpw - 1) / cpw, chunk = (groups + 7) / 8;
+    const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+    for (int idx = blockIdx.x >> 3; idx < chunk; idx += step) {
+        const int grp = xcd * chunk + idx;   // block-uniform
+        if (grp >= groups) break;
+        const int row = grp * cpw + sub;
+        const bool live = row < a.rows;
+        cd v[16];
+        if (live) {
+            load_row<0, PASS == 1>(a, g, row, tid, v);
+        } else {
+#pragma unroll
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = zf::mk(0.0, 0.0);
+        }
+        zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
+        __syncthreads();
+        zf::gather2(g, tid, v, lds);
+        __syncthreads();
+        zf::scatter2(g, tid, v, lds);
+        __syncthreads();
+        if (live) {
+            cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
+            const double al = a.alpha[row / a.alpha_rb];
+            for (int o = tid; o < g.M; o += NT) {
+                cd x = zf::cmul(zf::stage3(g, a.kbin[o], a.wk[o], lds), a.pj[o]);
+                x.x *= al;
+                x.y *= al;
+                cd *d = dst + o * a.out_es;
+                if (a.accumulate) x = zf::cadd(x, *d);
+                *d = x;
+            }
+        }
+        __syncthreads();   // the next group's stage 1 overwrites the buffers
+    }
+}
+
+// tables of the s transforms of an interleaved shard's column pass (farfield.hip): output j is bin
+// k_j = j + j0 of the FULL lattice of N samples; the short transform over m (N / (s G) = Nsub
+// samples sG apart) sees it as bin k_j mod Nsub with Horner ratio W_Nsub^(k_j), and the position of
+// its first sample, s r + i, and the aperture's origin c enter through
+//     pj[i][j] = exp(+2 pi i (c - s r - i) k_j / N)
+__global__ __launch_bounds__(256) void zfft_interleave_tables_kernel(cd *wk, cd *pj, int *kbin, int M, int j0,
+                                                                     int Nsub, int N, int c, int first,
+                                                                     int block) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M) return;
+    const long long kj = (long long)e + j0;
+    long long k = kj % Nsub;
+    if (k < 0) k += Nsub;
+    kbin[e] = (int)k;
+    double s, co;
+    sincospi(-2.0 * (double)k / (double)Nsub, &s, &co);
+    wk[e] = zf::mk(co, s);
+    for (int i = 0; i < block; ++i) {
+        long long m = ((long long)(c - first - i) * kj) % N;
+        if (m < 0) m += N;
+        sincospi(2.0 * (double)m / (double)N, &s, &co);
+        pj[(size_t)i * M + e] = zf::mk(co, s);
+    }
+}
+
+int zfft_build_interleave_tables(hipStream_t stream, double *wk, double *pj, int *kbin, int M, int j0, int Nsub,
+                                 int N, int c, int first, int block) {
+    hipLaunchKernelGGL(zfft_interleave_tables_kernel, dim3((M + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<cd *>(wk), reinterpret_cast<cd *>(pj), kbin, M, j0, Nsub, N, c, first,
+                       block);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
 // tables of one axis: tw1 (shared by all axes), wk / pj / kbin per plan axis
 __global__ __launch_bounds__(256) void zfft_tables_kernel(cd *tw1, cd *wk, cd *pj, int *kbin, int M,
                                                           int j0, int N, int c) {
@@ -360,6 +445,20 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     a.rows = c.rows;
     a.accumulate = c.accumulate;
     a.chunk = (c.rows + 7) / 8;
+    if (a.g.R3 <= 2) {
+        // short transforms: 64 threads = 4 or 2 rows per workgroup (zfft_multi_kernel)
+        const int cpw = 4 / a.g.R3;
+        const size_t bytes = ((size_t)cpw * zf::lds_elems(a.g) + 256) * sizeof(cd);
+        const int groups = (a.rows + cpw - 1) / cpw;
+        int grid = std::min(256 * 8, (groups + 7) / 8 * 8);
+        grid = std::max(grid, 8);
+        if (c.in_es == 1)
+            hipLaunchKernelGGL(zfft_multi_kernel<1>, dim3(grid), dim3(16 * a.g.R3 * cpw), bytes, stream, a, cpw);
+        else
+            hipLaunchKernelGGL(zfft_multi_kernel<2>, dim3(grid), dim3(16 * a.g.R3 * cpw), bytes, stream, a, cpw);
+        ML_HIP(hipGetLastError());
+        return ML_OK;
+    }
     const size_t lds_bytes = ((size_t)zf::lds_elems(a.g) + 256) * sizeof(cd);   // exchange buffer + twiddles
     // workgroups resident per CU (LDS-limited), 256 CUs; a multiple of 8 so that a workgroup
     // stays on the rows of one XCD

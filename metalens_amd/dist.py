@@ -77,6 +77,16 @@ def mirrored_rows(n_rows, q0, q1):
     return np.concatenate((np.arange(q0, q1), np.arange(n_rows - q1, n_rows - q0)))
 
 
+def interleaved_rows(n_rows, world, rank, block):
+    """row indices of rank ``rank`` when blocks of ``block`` rows are dealt round robin over
+    ``world`` ranks (rows ``block * (world * m + rank) + i``), in resident order; needs
+    ``n_rows`` to be a multiple of ``block * world``"""
+    import numpy as np
+    assert n_rows % (block * world) == 0
+    m = np.arange(n_rows // (block * world))
+    return (block * (world * m[:, None] + rank) + np.arange(block)[None, :]).ravel()
+
+
 def _id_path():
     key = '%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'),
                         os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())

@@ -29,11 +29,12 @@ class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
                  c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None,
-                 reduce='amplitudes', fuse_modulation=True, method=None):
+                 reduce='amplitudes', fuse_modulation=True, method=None, sharding='auto'):
         """``reduce`` (multi-GPU only): 'amplitudes' all-reduces the two projected complex
         amplitudes (half the payload; the radiation vectors in ``results()`` are then this
         rank's partial sums), 'vectors' all-reduces Nx, Ny, Lx, Ly and projects afterwards."""
         assert reduce in ('amplitudes', 'vectors')
+        assert sharding in ('auto', 'interleaved', 'mirrored', 'rows')
         self.reduce = reduce
         # the plan's stage-1 input modulation rides in the synthesis kernel (metalens_hip.h,
         # ml_nearfield_premodulate); host downloads of the fields are un-modulated first
@@ -65,12 +66,29 @@ class HotPath:
         self.y = _lib.f64(y_pts)
         self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
         self.pair_list = bool(pair_list)
-        # rows of this rank: mirrored row pairs when the aperture has an even number of rows
-        # (both far-field stages fold), one contiguous block otherwise (pair lists have no
+        self.dxp = x_pts[1] - x_pts[0]
+        self.dyp = y_pts[1] - y_pts[0]
+        # rows of this rank.  INTERLEAVED (blocks of rows dealt round robin) when the direction grid
+        # along x sits on the aperture's FFT lattice: the column pass then costs every rank 1 / world
+        # of the whole aperture's and the ranks' loads balance by construction (metalens_hip.h
+        # ml_farfield_interleave_block); else mirrored row pairs when the aperture has an even number
+        # of rows (both far-field stages fold), one contiguous block otherwise (pair lists have no
         # folded form: csrc/farfield.hip rejects mirrored shards for them)
-        self.mirrored = world > 1 and not self.pair_list and self.x_all.size % 2 == 0
+        self.interleave = 0
+        if world > 1 and not self.pair_list and sharding in ('auto', 'interleaved'):
+            self._plan()
+            block = _lib.c_int(0)
+            _lib.check(self.ctx.lib.ml_farfield_interleave_block(self.ctx.handle, world, _lib.byref(block)))
+            self.interleave = block.value
+            if sharding == 'interleaved' and not self.interleave:
+                raise ValueError('this plan cannot be sharded by interleaved rows over %d ranks' % world)
+        self.mirrored = (world > 1 and not self.pair_list and not self.interleave and
+                         self.x_all.size % 2 == 0 and sharding != 'rows')
         self._shard_weights = None
-        if self.mirrored:
+        if self.interleave:
+            self.row0 = self.row1 = 0
+            self.rows = dist.interleaved_rows(self.x_all.size, world, rank, self.interleave)
+        elif self.mirrored:
             # rows through the centre disc cost more near-field time (nearest-cell search, more
             # scattered table gathers); the GEMM cost per row is uniform.  Measured per-row totals
             # (tools/shard_probe.py, 8-way shards): rim 8.0e-4 ms, centre 8.7e-4 ms -> +13 % for
@@ -87,6 +105,8 @@ class HotPath:
         else:
             self.row0, self.row1 = dist.row_block(self.x_all.size, world, rank)
             self.rows = np.arange(self.row0, self.row1)
+        self.sharding = ('interleaved blocks of %d rows' % self.interleave if self.interleave else
+                         'mirrored pairs' if self.mirrored else 'rows' if world > 1 else 'whole aperture')
         self.x_local = np.ascontiguousarray(self.x_all[self.rows])
         # an empty shard would leave this rank without radiation vectors while the others wait
         # for it inside the all-reduce: refuse identically on every rank instead
@@ -96,12 +116,30 @@ class HotPath:
                 raise ValueError('%d aperture rows cannot be sharded over %d ranks: a rank would '
                                  'hold no rows' % (self.x_all.size, world))
         self.shape = (self.ux.size,) if pair_list else (self.ux.size, self.uy.size)
-        self.dxp = x_pts[1] - x_pts[0]
-        self.dyp = y_pts[1] - y_pts[0]
+
+    def _plan(self):
+        ctx = self.ctx
+        _lib.check(ctx.lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
+                                            self.dyp, self.wavelength, self.n_glass,
+                                            _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
+                                            self.uy.size, int(self.pair_list)))
+
+    def _transform(self):
+        """both transform stages of this rank's resident rows"""
+        ctx, lib = self.ctx, self.ctx.lib
+        if self.interleave:
+            _lib.check(lib.ml_farfield_transform_interleaved_async(ctx.handle, self.interleave, self.world,
+                                                                   self.rank, 0))
+        elif self.mirrored:
+            _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
+        else:
+            _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
 
     def _rows_of(self, rank):
         """aperture rows rank ``rank`` owns under this object's partition"""
         n = self.x_all.size
+        if self.interleave:
+            return dist.interleaved_rows(n, self.world, rank, self.interleave)
         if self.mirrored:
             q0, q1 = dist.mirrored_block(n, self.world, rank, weights=self._shard_weights)
             return dist.mirrored_rows(n, q0, q1)
@@ -118,27 +156,18 @@ class HotPath:
         """near field + transform of this object's rows only (no reduction, no projection)"""
         ctx, lib = self.ctx, self.ctx.lib
         _lib.check(lib.ml_nearfield_premodulate(ctx.handle, int(self.fuse_modulation)))
-        _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
-                                        self.dyp, self.wavelength, self.n_glass,
-                                        _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
-                                        self.uy.size, int(self.pair_list)))
+        self._plan()
         if self.x_local.size:
             _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(self.params),
                                               _lib.dptr(self.x_local), self.x_local.size,
                                               _lib.dptr(self.y), self.y.size))
-            if self.mirrored:
-                _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
-            else:
-                _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
+            self._transform()
 
     def queue_synthesis(self):
         """first half of a step: near field of this rank's rows into the resident field set"""
         ctx, lib = self.ctx, self.ctx.lib
         _lib.check(lib.ml_nearfield_premodulate(ctx.handle, int(self.fuse_modulation)))
-        _lib.check(lib.ml_farfield_plan(ctx.handle, self.x_all.size, self.y.size, self.dxp,
-                                        self.dyp, self.wavelength, self.n_glass,
-                                        _lib.dptr(self.ux), self.ux.size, _lib.dptr(self.uy),
-                                        self.uy.size, int(self.pair_list)))
+        self._plan()
         if self.x_local.size:
             _lib.check(lib.ml_nearfield_async(ctx.handle, _lib.byref(self.params),
                                               _lib.dptr(self.x_local), self.x_local.size,
@@ -148,10 +177,7 @@ class HotPath:
         """second half: both transform stages, the reduction over ranks, the projection"""
         ctx, lib = self.ctx, self.ctx.lib
         if self.x_local.size:
-            if self.mirrored:
-                _lib.check(lib.ml_farfield_transform_mirrored_async(ctx.handle, self.row0, 0))
-            else:
-                _lib.check(lib.ml_farfield_transform_async(ctx.handle, self.row0, 0))
+            self._transform()
         if (self.world > 1 or dist.force_rccl()) and self.reduce == 'amplitudes':
             _lib.check(lib.ml_farfield_project_reduce(ctx.handle, self.Z0))
         else:

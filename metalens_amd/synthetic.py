@@ -122,7 +122,8 @@ def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=55
 
 def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 * nm,
               switch_angle=12 * degree, n_glass=0, num_gratings=24, num_entries=12,
-              max_collection_span=9 * degree, design_kwargs=None, axis_warp=0.0, u_steps=5):
+              max_collection_span=9 * degree, design_kwargs=None, axis_warp=0.0, u_steps=5,
+              periphery_orders=PERIPHERY_ORDERS, center_orders=CENTER_ORDERS):
     """A complete synthetic round lens of ``radius`` and ``numerical_aperture``
     for an on-axis source at the focal distance ``radius / tan(asin(NA))``.
 
@@ -141,10 +142,11 @@ def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 *
         lo, hi = float(bounds[i]), float(bounds[i + 1])
         gc = make_collection(Grating, GratingCollection, lo, hi, wavelength, n_glass=n_glass,
                              num_gratings=num_gratings, seed=i, axis_warp=axis_warp,
-                             u_steps=u_steps)
+                             u_steps=u_steps, orders=periphery_orders)
         collections.append([(lo, hi), gc])
     hgs = make_hexgridset(Grating, HexGridSet, wavelength, n_glass=n_glass,
-                          num_entries=num_entries, axis_warp=axis_warp, u_steps=u_steps)
+                          num_entries=num_entries, axis_warp=axis_warp, u_steps=u_steps,
+                          orders=center_orders)
     for _, gc in collections:
         gc.build_interpolators()
     hgs.build_interpolators()

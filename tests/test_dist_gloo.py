@@ -50,6 +50,43 @@ def test_row_block_partitions_cover_everything():
                 assert all(a % 16 == 0 for a, _ in blocks)
 
 
+def test_interleaved_rows_cover_everything():
+    for n, world, block in ((16, 2, 1), (2048, 8, 1), (8192, 8, 4), (4096, 4, 4), (512, 2, 2)):
+        shards = [dist.interleaved_rows(n, world, r, block) for r in range(world)]
+        assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(n))
+        for r, rows in enumerate(shards):
+            assert rows.size == n // world
+            assert np.array_equal(rows[:block], block * r + np.arange(block))
+            assert np.array_equal(np.diff(rows.reshape(-1, block), axis=0),
+                                  np.full((rows.size // block - 1, block), block * world))
+
+
+@pytest.mark.parametrize('N,G,s,M,j0', [(1024, 4, 1, 64, -32), (2048, 8, 1, 100, -37), (4096, 4, 4, 512, -256),
+                                        (1024, 2, 2, 1024, -512), (2048, 2, 4, 96, 900)])
+def test_interleaved_shard_column_pass_is_a_short_dft(N, G, s, M, j0):
+    """What csrc/farfield.hip's interleaved column pass computes, in NumPy: rank r's partial sum
+    over its rows n = s (G m + r) + i on the bins k_j = j + j0 of the FULL N-point lattice is, per
+    i, an (N / sG)-point DFT over m read at bin k_j mod (N / sG), times exp(2 pi i (c - s r - i) k_j / N)
+    (zfft_interleave_tables_kernel).  The ranks' partial sums add up to the whole aperture sum
+    sum_n x[n] exp(-2 pi i (n - c) k_j / N)  (nearfield_farfield.py:111-120)."""
+    rng = np.random.default_rng(N + G + s)
+    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    c = N - N // 2
+    k = np.arange(M) + j0
+    whole = np.array([np.sum(x * np.exp(-2j * np.pi * ((np.arange(N) - c) * kj % N) / N)) for kj in k])
+    Nsub = N // (s * G)
+    total = np.zeros(M, dtype=complex)
+    for r in range(G):
+        rows = dist.interleaved_rows(N, G, r, s)
+        local = x[rows]                                   # resident order
+        for i in range(s):
+            sub = np.fft.fft(local[i::s])                 # Nsub points, sG apart in the aperture
+            assert sub.size == Nsub
+            pj = np.exp(2j * np.pi * (((c - s * r - i) * k) % N) / N)
+            total += sub[k % Nsub] * pj
+    assert np.abs(total - whole).max() <= 1e-12 * np.abs(whole).max()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -58,7 +95,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, sharding='mirrored'):
     import torch
     import torch.distributed as td
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -69,17 +106,22 @@ def _worker(rank, world, port, out_dir):
     lens = golden_io.load_lens(golden_io.golden_path(str(case['lens'])))
     x, y = case['x_pts'], case['y_pts']
     wl = float(case['wavelength'])
-    # the decomposition HotPath uses for N > 1: mirrored row pairs per rank
-    q0, q1 = dist.mirrored_block(len(x), world, rank, align=2)
-    rows = dist.mirrored_rows(len(x), q0, q1)
-    # (the near-field oracle checks that x_pts is uniform, so feed it the two runs separately)
-    h = q1 - q0
+    # the decompositions HotPath uses for N > 1: blocks of rows dealt round robin (direction grids
+    # on the FFT lattice) or mirrored row pairs per rank
+    if sharding == 'interleaved':
+        rows = dist.interleaved_rows(len(x), world, rank, 2)
+        runs = rows.reshape(-1, 2)
+    else:
+        q0, q1 = dist.mirrored_block(len(x), world, rank, align=2)
+        rows = dist.mirrored_rows(len(x), q0, q1)
+        runs = (rows[:q1 - q0], rows[q1 - q0:])
+    # (the near-field oracle checks that x_pts is uniform, so feed it the runs separately)
     parts = [nearfield_oracle.build_nearfield(
         float(case['source_x']), float(case['source_y']), float(case['source_z']),
         str(case['source_pol']), wl, lens[0], lens[1], lens[2], x_pts=x[run], y_pts=y,
-        c0=float(case['c0']), Z0=float(case['Z0'])) for run in (rows[:h], rows[h:])]
-    Ex, Ey, Hx, Hy = (np.vstack((a, b)) for a, b in zip(parts[0][:4], parts[1][:4]))
-    power = parts[0][6] + parts[1][6]
+        c0=float(case['c0']), Z0=float(case['Z0'])) for run in runs]
+    Ex, Ey, Hx, Hy = (np.vstack([p[k] for p in parts]) for k in range(4))
+    power = sum(p[6] for p in parts)
     n_glass = parts[0][7]
     ux = np.linspace(-0.3, 0.5, 9)
     uy = np.linspace(-0.2, 0.2, 7)
@@ -96,12 +138,13 @@ def _worker(rank, world, port, out_dir):
     td.destroy_process_group()
 
 
-def test_two_rank_sharded_sum_equals_whole(tmp_path):
+@pytest.mark.parametrize('sharding', ['mirrored', 'interleaved'])
+def test_two_rank_sharded_sum_equals_whole(tmp_path, sharding):
     torch = pytest.importorskip('torch')
     import torch.multiprocessing as mp
     from oracle import farfield_oracle
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), sharding), nprocs=2, join=True)
     z = np.load(os.path.join(str(tmp_path), 'reduced.npz'))
     case = np.load(golden_io.golden_path('nearfield_B_straddle_offaxis_y.npz'))
     whole = farfield_oracle.radiation_vectors(case['Ex'], case['Ey'], case['Hx'], case['Hy'],

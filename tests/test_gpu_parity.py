@@ -281,6 +281,58 @@ def test_mirrored_shards_sum_to_whole(ma, nx, ny, mx, my):
         assert np.abs(got[key] - w).max() <= TOL * np.abs(w).max(), key
 
 
+@pytest.mark.parametrize('N,world,block', [(512, 2, 1), (1024, 2, 2), (2048, 8, 1), (2048, 2, 4), (4096, 4, 4),
+                                           (1536, 2, 1)])
+def test_interleaved_shards_sum_to_whole(ma, N, world, block):
+    """Blocks of rows dealt round robin over the ranks (metalens_hip.h ml_farfield_interleave_block):
+    every rank's shard through its own synthesis and its SHORT column pass on one GPU, the partial
+    radiation vectors added up on the host = the whole aperture in one piece, and the incident power
+    likewise.  Shapes cover R3 = 1, 2 (several columns per workgroup), 4 and 3 of the short transform."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from metalens_amd import _lib
+    from metalens_amd.pipeline import HotPath
+    wl = 580e-9
+    lens, x, u = bench.build_workload(N, 96, 0.2e-3, 0.4, wl, 1.0)
+    src = (0.2e-6, -0.1e-6, -lens['source_distance'], 'y')
+    args = (src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'],
+            x, x, u, u)
+    ctx = _lib.default_context()
+    whole = HotPath(*args, ctx=ctx)
+    whole.step()
+    whole.sync()
+    want = whole.results()
+    assert ctx.plan_kernels() == ('fft', 'fft')
+    total = {k: 0 for k in ('Nx', 'Ny', 'Lx', 'Ly')}
+    power = 0.0
+    for rank in range(world):
+        part = HotPath(*args, ctx=ctx, rank=rank, world=world)
+        assert part.interleave == block and part.sharding.startswith('interleaved')
+        assert np.array_equal(part.rows[:block], block * rank + np.arange(block))
+        part.step_local()
+        part.sync()
+        vec = [np.empty(part.shape, dtype=np.complex128) for _ in range(4)]
+        _lib.check(ctx.lib.ml_farfield_download(ctx.handle, *[_lib.dptr(v) for v in vec]))
+        for k, v in zip(('Nx', 'Ny', 'Lx', 'Ly'), vec):
+            total[k] = total[k] + v
+        pw = _lib.c_double(0)
+        _lib.check(ctx.lib.ml_nearfield_result(ctx.handle, _lib.byref(pw), None, 0, None))
+        power += pw.value * part.dxp * part.dyp
+    for key in total:
+        assert np.abs(total[key] - want[key]).max() <= 1e-13 * np.abs(want[key]).max(), key
+    assert abs(power - want['power_local_rows']) <= 1e-12 * want['power_local_rows']
+    # a plan that cannot be dealt this way says so, and 'auto' falls back to mirrored pairs
+    off = HotPath(src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'],
+                  x, x, 0.7 * u, u, ctx=ctx, rank=0, world=world)
+    assert off.interleave == 0 and off.sharding.startswith('mirrored')
+    with pytest.raises(ValueError):
+        HotPath(src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'],
+                x, x, 0.7 * u, u, ctx=ctx, rank=0, world=world, sharding='interleaved')
+
+
 def _synthetic_lens(radius, na, wavelength, n_glass=0, switch_deg=12.0):
     import math
     import metalens_amd as ma_
@@ -586,17 +638,18 @@ def _run_bench(extra, env, timeout=600, aperture=512):
                             stderr=subprocess.PIPE, text=True)
 
 
-@pytest.mark.parametrize('reduce,aperture,pairs', [('amplitudes', 512, 0), ('vectors', 512, 0),
-                                                   ('amplitudes', 511, 0), ('amplitudes', 512, 300),
-                                                   ('vectors', 512, 300)])
-def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs):
-    """bench.py --gpus 2 end to end on ONE GPU: two processes (ranks 0 and 1, both on device 0)
+@pytest.mark.parametrize('reduce,aperture,pairs,world', [
+    ('amplitudes', 512, 0, 2), ('vectors', 512, 0, 2), ('amplitudes', 511, 0, 2), ('amplitudes', 512, 300, 2),
+    ('vectors', 512, 300, 2), ('amplitudes', 2048, 0, 4), ('amplitudes', 2048, 0, 8), ('amplitudes', 1000, 0, 4)])
+def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs, world):
+    """bench.py --gpus N end to end on ONE GPU: N processes (ranks 0 .. N-1, all on device 0)
     with the test communicator (ML_COMM_BACKEND=file; RCCL refuses two ranks per GPU): unique-id
-    rendezvous, weighted mirrored row shards, per-rank synthesis and transform, the reduction,
-    max-over-ranks timing - and the far field must equal the one-process result.  The odd
-    aperture takes contiguous row blocks, and only the rank that owns the x = 0 row meets
-    nearest-cell ties: results() has to settle them collectively.  ``pairs`` > 0: a LIST of
-    directions instead of the tensor grid (no folded / mirrored form: contiguous row blocks)."""
+    rendezvous, row shards (interleaved blocks on lattice grids - 512 and 2048 rows -, weighted
+    mirrored pairs at 1000 rows, whose lattice is not a multiple of 256 N), per-rank synthesis and
+    transform, the reduction, max-over-ranks timing - and the far field must equal the one-process
+    result.  The odd aperture takes contiguous row blocks, and only the rank that owns the x = 0
+    row meets nearest-cell ties: results() has to settle them collectively.  ``pairs`` > 0: a LIST
+    of directions instead of the tensor grid (no folded / mirrored form: contiguous row blocks)."""
     import json
     more = ['--pair-list', str(pairs)] if pairs else []
     one = str(tmp_path / 'one.npz')
@@ -604,18 +657,21 @@ def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs):
     out, err = p.communicate(timeout=600)
     assert p.returncode == 0, err[-2000:]
     two = str(tmp_path / 'two.npz')
-    env = dict(ML_COMM_BACKEND='file', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-               MASTER_PORT=str(29533 + (reduce == 'vectors') + 2 * (aperture % 2) + 4 * (pairs > 0)))
-    procs = [_run_bench(['--gpus', '2', '--dump', two, '--reduce', reduce] + more,
+    env = dict(ML_COMM_BACKEND='file', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(29533 + (reduce == 'vectors') + 2 * (aperture % 2) + 4 * (pairs > 0) + 8 * world))
+    procs = [_run_bench(['--gpus', str(world), '--dump', two, '--reduce', reduce] + more,
                         dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=aperture)
-             for r in range(2)]
+             for r in range(world)]
     outs = [q.communicate(timeout=600) for q in procs]
     for q, (o, e) in zip(procs, outs):
         assert q.returncode == 0, e[-2000:]
     lines = [l for l in outs[0][0].splitlines() if l.strip()]
     assert len(lines) == 1 and not outs[1][0].strip(), (outs[0][0], outs[1][0])
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
+    assert line['n_gpus'] == world and line['scaling'] == 'strong'
+    want_sharding = ('interleaved' if not pairs and aperture % (256 * world) == 0 else
+                     'mirrored' if not pairs and aperture % 2 == 0 else 'rows')
+    assert line['config']['sharding'].startswith(want_sharding), line['config']['sharding']
     a, b = np.load(one), np.load(two)
     for key in ('a_theta', 'a_phi'):
         assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), key
@@ -647,9 +703,18 @@ def test_bench_line_contract():
     assert len(d['ms_per_step_blocks']) == 2 and 'workload' in d['config']
     for key in ('roofline', 'roofline_other'):
         r = d[key]
-        assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] <= 1 and r['peak'] > 0
+        assert r['bound'] in ('hbm', 'mfma', 'valu_fp64') and 0 < r['frac'] <= 1 and r['peak'] > 0
         assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['avg_launch_ms'] > 0
+        if r['kernel'].startswith('nearfield'):
+            # the binding roof is fp64 issue where the configuration has a counter profile; the HBM
+            # figure of the compulsory stores is always there
+            assert 0 < r['hbm_frac'] <= 1 and 'valu_insts' in r and 'traffic' in r
+        else:
+            assert 'traffic_frac' in r and 'traffic' in r
     assert 0 < d['roofline']['step_hbm_frac'] <= 1
+    assert d['config']['pmc_key'].startswith('gpus=1,aperture=512,farfield=64,precision=f64')
+    # a single call on a grid the context has not seen (geometry kernel, scans, zeros stored)
+    assert d['ms_first_step_new_geometry'] > 0 and d['cold_step']['first_ms'] >= d['cold_step']['third_ms'] > 0
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c
     assert d['cpu_baseline_reference_route']['value'] > 0
@@ -1039,6 +1104,46 @@ def test_merged_launches_keep_per_call_semantics(ma):
     for got, w in zip((got2['Nx'], got2['Ny'], got2['Lx'], got2['Ly']), N2):
         assert np.abs(got - w).max() <= TOL * np.abs(w).max()
     assert abs(got2['power_local_rows'] - want2[6]) <= 1e-12 * abs(want2[6])
+
+
+@pytest.mark.parametrize('per,cen', [
+    (((0, 0), (-1, 0), (1, 0), (0, 1), (-2, 0)), ((0, 0), (-1, 0), (1, 0))),      # general rings, simple centre
+    (((0, 0), (-1, 0), (1, 0)), ((0, 0), (-1, 0), (1, 0), (0, -1), (1, 1))),      # simple rings, general centre
+    (((0, 0), (-1, 1), (2, -1)), ((0, 0), (0, 1), (-1, -1), (2, 0))),             # both general
+])
+@pytest.mark.parametrize('pol,sz', [('x', -1.0), ('y', -float('inf'))])
+def test_general_order_sets_vs_oracle(ma, per, cen, pol, sz):
+    """Tables whose orders go beyond ox = -1, 0, 1 / oy = 0 (|o| <= 5 in general, grating.lua:406-423)
+    take the GENERAL kernels, which evaluate every order's phase argument the reference's way
+    (nearfield.py:268-269,291; :391-409); the three-order sets of every other test take the kernels
+    that build the phasors by products.  Windows in the centre, across the switch radius and in the
+    periphery, dipole and plane wave, against the oracle."""
+    from oracle import nearfield_oracle
+    import math
+    from metalens_amd import layout, synthetic
+    wl = 580e-9
+    lens = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design,
+                               radius=40e-6, numerical_aperture=0.4, wavelength=wl,
+                               switch_angle=9 * math.pi / 180, num_gratings=20, num_entries=12,
+                               design_kwargs={'wavelength': wl}, periphery_orders=per, center_orders=cen)
+    rsw = lens['r_for_switch']
+    pitch = wl / 2.2
+    for cx, cy in ((1e-6, -2e-6), (rsw * math.cos(0.7), rsw * math.sin(0.7)), (-30e-6, 12e-6)):
+        x = cx + (np.arange(40) - 20) * pitch
+        y = cy + (np.arange(56) - 28) * pitch
+        args = dict(source_x=0.3e-6, source_y=-0.2e-6,
+                    source_z=sz if sz == -float('inf') else -lens['source_distance'], source_pol=pol,
+                    wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                    lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'],
+                    x_pts=x, y_pts=y)
+        got = ma.build_nearfield(**args)
+        want = nearfield_oracle.build_nearfield(**args)
+        scale = max(np.abs(w).max() for w in want[:4])
+        assert scale > 0
+        for g, w in zip(got[:4], want[:4]):
+            assert int(np.count_nonzero((g == 0) != (w == 0))) == 0
+            assert np.abs(g - w).max() <= TOL * scale
+        assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
 
 
 @pytest.mark.parametrize('seed', [5, 6])
