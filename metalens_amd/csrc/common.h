@@ -420,6 +420,9 @@ bool zfft_commensurate(int n, double step, long double kappa, const double *u, i
 int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M,
                       int j0, int N_eff, int c);
 void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2);
+// the column pass of an interleaved shard: s short transforms per column in one workgroup; c.pj holds
+// [s][M] phasors, sub-sequence i starts sub_off elements behind sub-sequence i - 1
+int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off);
 int zfft_build_interleave_tables(hipStream_t stream, double *wk, double *pj, int *kbin, int M, int j0, int Nsub,
                                  int N, int c, int first, int block);
 int zfft_run(hipStream_t stream, const ZfftCall &c);

@@ -766,7 +766,8 @@ static int interleave_block(const FarfieldPlan &pl, int n_ranks) {
     for (int s = 8; s >= 1; s >>= 1) {
         if (N % (s * n_ranks * 256) != 0) continue;
         const int r3 = N / (s * n_ranks * 256);
-        if (r3 >= 1 && r3 <= 32) return s;
+        // (the s transforms of a column share one workgroup: 16 r3 s threads, s buffers of 4 r3 KB)
+        if (r3 >= 1 && r3 <= 32 && r3 * s <= 32) return s;
     }
     return 0;
 }
@@ -978,7 +979,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             zfft_choose_pads(Nsub, mx, pl.fft_x.j0, &pl.il_pad1, &pl.il_pad2);
             memcpy(pl.il_key, key, sizeof key);
         }
-        for (int i = 0; i < s; ++i) {
+        {
             ZfftCall c;
             c.N_eff = Nsub;
             c.n_valid = Nsub;
@@ -986,7 +987,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.j0 = pl.fft_x.j0;
             c.pad1 = pl.il_pad1;
             c.pad2 = pl.il_pad2;
-            c.in = pl.stage1.as<double>() + (size_t)i * my * 2;
+            c.in = pl.stage1.as<double>();
             c.rows = 4 * my;
             c.in_rb = my;
             c.in_s1 = (int64_t)nxl * my;
@@ -1004,12 +1005,12 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.out_es = my;
             c.tw1 = pl.fft_tw1.as<double>();
             c.wk = pl.il_wk.as<double>();
-            c.pj = pl.il_pj.as<double>() + (size_t)i * mx * 2;
+            c.pj = pl.il_pj.as<double>();
             c.kbin = pl.il_kbin.as<int>();
             for (int k = 0; k < 4; ++k) c.alpha[k] = alpha[k];
             c.alpha_rb = my;
-            c.accumulate = (i > 0) ? 1 : accumulate;
-            ML_TRY(zfft_run(ctx->stream, c));
+            c.accumulate = accumulate;
+            ML_TRY(zfft_run_interleaved(ctx->stream, c, s, my));
         }
     } else if (fft2) {
         // stage 2 along x as a pruned FFT over the columns of stage 1's result: row (f, b) reads

@@ -299,6 +299,105 @@ __global__ __launch_bounds__(256) void zfft_multi_kernel(const FftArgs a, int cp
     }
 }
 
+// The column pass of an INTERLEAVED row shard in one launch: workgroup = one column (f, b), its s
+// short transforms side by side (sub-group i = threads [i NT, (i + 1) NT) transforms the local rows
+// i, i + s, i + 2 s, ... in its own exchange buffer, all in step), and the last stage sums the s
+// results of a wanted bin - each carried to the full lattice by its pj[i][.] - before the ONE store.
+// (Launched once per i with an accumulating store instead, the 4 x 2048 x 512 scattered 16-byte
+// read-modify-writes of configs[2]'s 8-rank shard cost twice the full-length pass they replace.)
+__global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, int s, int64_t sub_off) {
+    extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
+    const zf::Geo g = a.g;
+    const int NT = 16 * g.R3, sub = threadIdx.x / NT, tid = threadIdx.x - sub * NT, T = NT * s;
+    cd *base = reinterpret_cast<cd *>(zfft_lds_raw);
+    const int stride = zf::lds_elems(g);
+    cd *lds = base + (size_t)sub * stride;
+    cd *s_tw = base + (size_t)s * stride;
+    for (int e = threadIdx.x; e < 256; e += T) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];
+    const int n1 = tid / g.R3;
+    __syncthreads();
+    const int chunk = (a.rows + 7) / 8, xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+    for (int idx = blockIdx.x >> 3; idx < chunk; idx += step) {
+        const int row = xcd * chunk + idx;   // block-uniform
+        if (row >= a.rows) break;
+        const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2 + sub * sub_off;
+        cd v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[(int64_t)(tid + NT * n2) * a.in_es];
+        zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
+        __syncthreads();
+        zf::gather2(g, tid, v, lds);
+        __syncthreads();
+        zf::scatter2(g, tid, v, lds);
+        __syncthreads();
+        cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
+        const double al = a.alpha[row / a.alpha_rb];
+        for (int o = threadIdx.x; o < g.M; o += T) {
+            const int k = a.kbin[o];
+            const cd w = a.wk[o];
+            cd x = zf::mk(0.0, 0.0);
+            for (int i = 0; i < s; ++i)
+                x = zf::cmac(zf::stage3(g, k, w, base + (size_t)i * stride), a.pj[(size_t)i * g.M + o], x);
+            x.x *= al;
+            x.y *= al;
+            cd *d = dst + o * a.out_es;
+            if (a.accumulate) x = zf::cadd(x, *d);
+            *d = x;
+        }
+        __syncthreads();   // the next column's stage 1 overwrites the buffers
+    }
+}
+
+int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off) {
+    FftArgs a;
+    a.g.R3 = c.N_eff / 256;
+    a.g.n_valid = c.n_valid;
+    a.g.M = c.M;
+    a.g.j0 = c.j0;
+    a.g.pad1 = c.pad1;
+    a.g.pad2 = c.pad2;
+    a.in = reinterpret_cast<const cd *>(c.in);
+    a.in_s1 = c.in_s1;
+    a.in_s2 = c.in_s2;
+    a.in_es = c.in_es;
+    a.in_rb = c.in_rb;
+    a.a0 = 0;
+    a.h0 = c.n_valid;
+    a.a1 = a.h1 = 0;
+    a.row_first = nullptr;
+    a.rf_mod = 1;
+    a.out = reinterpret_cast<cd *>(c.out);
+    a.out_s1 = c.out_s1;
+    a.out_s2 = c.out_s2;
+    a.out_es = c.out_es;
+    a.out_rb = c.out_rb;
+    a.tw1 = reinterpret_cast<const cd *>(c.tw1);
+    a.wk = reinterpret_cast<const cd *>(c.wk);
+    a.pj = reinterpret_cast<const cd *>(c.pj);
+    a.kbin = c.kbin;
+    for (int k = 0; k < 4; ++k) a.alpha[k] = c.alpha[k];
+    a.alpha_rb = c.alpha_rb;
+    a.rows = c.rows;
+    a.accumulate = c.accumulate;
+    a.chunk = (c.rows + 7) / 8;
+    const int threads = 16 * a.g.R3 * s;
+    const size_t bytes = ((size_t)s * zf::lds_elems(a.g) + 256) * sizeof(cd);
+    ML_REQUIRE(threads <= 512 && bytes <= 160 * 1024, "interleaved column pass: %d transforms of %d points "
+               "do not fit one workgroup", s, c.N_eff);
+    static bool attr_done = false;
+    if (!attr_done) {
+        ML_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(zfft_interleaved_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (160 * 1024) / bytes, (size_t)(2048 / threads)}));
+    int grid = std::min(256 * per_cu, a.chunk * 8);
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(zfft_interleaved_kernel, dim3(grid), dim3(threads), bytes, stream, a, s, sub_off);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
 // tables of the s transforms of an interleaved shard's column pass (farfield.hip): output j is bin
 // k_j = j + j0 of the FULL lattice of N samples; the short transform over m (N / (s G) = Nsub
 // samples sG apart) sees it as bin k_j mod Nsub with Horner ratio W_Nsub^(k_j), and the position of
