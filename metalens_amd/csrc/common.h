@@ -174,6 +174,9 @@ struct CellRec {
 struct ZfftAxis {
     bool ok = false;
     int N_eff = 0, j0 = 0, pad1 = 0, pad2 = 0;
+    // split > 1 (lattices beyond 8192 samples): `split` launches over interleaved sub-sequences of
+    // N_eff / split samples; wk / kbin then belong to the SHORT lattice and pj holds [split][M]
+    int split = 1;
     DevBuf wk, pj, kbin;   // per-bin Horner ratio, origin phasor, reduced bin (zfft.hip FftArgs)
 };
 
@@ -406,6 +409,7 @@ struct ZfftCall {
     int in_rb, a0, h0, a1, h1;
     const int *row_first;
     int rf_mod;
+    int sub_s = 1, sub_i = 0;   // this launch: samples sub_i, sub_i + sub_s, ... of the axis (two-level)
     double *out;                // complex
     int64_t out_s1, out_s2, out_es;
     int out_rb;
@@ -415,6 +419,7 @@ struct ZfftCall {
     int alpha_rb, rows, accumulate;
     int lean = 0, lean_per_cu = 1;   // pass 1 only: the <= 128-VGPR kernel, workgroups per CU
 };
+int zfft_split(int N_eff);   // sub-sequences a lattice of N_eff samples is transformed in (0: none)
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
                        long double tol, int *N_eff, int *j0);
 int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M,

@@ -484,14 +484,21 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
     int N_eff = 0, j0 = 0;
     if (!zfft_commensurate(n, step, kappa, u, m, symmetry_tolerance(kappa, p_max, u, m), &N_eff, &j0))
         return ML_OK;
+    const int split = zfft_split(N_eff);
     ML_TRY(pl.fft_tw1.reserve(256 * 2 * sizeof(double)));
     ML_TRY(ax.wk.reserve((size_t)m * 2 * sizeof(double)));
-    ML_TRY(ax.pj.reserve((size_t)m * 2 * sizeof(double)));
+    ML_TRY(ax.pj.reserve((size_t)split * m * 2 * sizeof(double)));
     ML_TRY(ax.kbin.reserve((size_t)m * sizeof(int)));
     ProfScope scope(ctx, ML_K_TWIDDLE);
+    // (tw1 is shared by every axis and every lattice; with split > 1 the per-bin tables belong to the
+    // sub-sequences' lattice and pj[i][.] carries sub-sequence i's bins to the full one)
     ML_TRY(zfft_build_tables(ctx->stream, pl.fft_tw1.as<double>(), ax.wk.as<double>(),
                              ax.pj.as<double>(), ax.kbin.as<int>(), m, j0, N_eff, n - n / 2));
-    zfft_choose_pads(N_eff, m, j0, &ax.pad1, &ax.pad2);
+    if (split > 1)
+        ML_TRY(zfft_build_interleave_tables(ctx->stream, ax.wk.as<double>(), ax.pj.as<double>(),
+                                            ax.kbin.as<int>(), m, j0, N_eff / split, N_eff, n - n / 2, 0, split));
+    zfft_choose_pads(N_eff / split, m, j0, &ax.pad1, &ax.pad2);
+    ax.split = split;
     ax.N_eff = N_eff;
     ax.j0 = j0;
     ax.ok = true;
@@ -873,7 +880,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
         if (fft1) {
             ZfftCall c;
-            c.N_eff = pl.fft_y.N_eff;
+            const int split1 = pl.fft_y.split;
+            c.N_eff = pl.fft_y.N_eff / split1;
             c.n_valid = ny;
             c.M = my;
             c.j0 = pl.fft_y.j0;
@@ -903,7 +911,16 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.alpha_rb = c.rows;
             c.accumulate = 0;
             Overlap &ov = ctx->ov;
-            if (ov.live && ov.live_rows == nxl && ov.bands > 1 && (int)ov.row.size() == ov.bands + 1) {
+            if (split1 > 1) {
+                // two-level: sub-sequence i of every row adds its bins (zfft.hip zfft_split)
+                for (int i = 0; i < split1; ++i) {
+                    c.sub_s = split1;
+                    c.sub_i = i;
+                    c.pj = pl.fft_y.pj.as<double>() + (size_t)i * my * 2;
+                    c.accumulate = i > 0;
+                    ML_TRY(zfft_run(ctx->stream, c));
+                }
+            } else if (ov.live && ov.live_rows == nxl && ov.bands > 1 && (int)ov.row.size() == ov.bands + 1) {
                 // the banded step: band b's rows as soon as its synthesis is through, on the second
                 // stream, beside the synthesis of the bands behind it (nearfield.hip banded_launch)
                 for (int b = 0; b < ov.bands; ++b) {
@@ -1018,7 +1035,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(collapse_stage1());
         ZfftCall c;
-        c.N_eff = pl.fft_x.N_eff;
+        const int split2 = pl.fft_x.split;
+        c.N_eff = pl.fft_x.N_eff / split2;
         c.n_valid = pl.nx_total;
         c.M = mx;
         c.j0 = pl.fft_x.j0;
@@ -1053,8 +1071,13 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         c.kbin = pl.fft_x.kbin.as<int>();
         for (int k = 0; k < 4; ++k) c.alpha[k] = alpha[k];
         c.alpha_rb = my;
-        c.accumulate = accumulate;
-        ML_TRY(zfft_run(ctx->stream, c));
+        for (int i = 0; i < split2; ++i) {
+            c.sub_s = split2;
+            c.sub_i = i;
+            c.pj = pl.fft_x.pj.as<double>() + (size_t)i * mx * 2;
+            c.accumulate = i > 0 ? 1 : accumulate;
+            ML_TRY(zfft_run(ctx->stream, c));
+        }
     } else if (use_fold2) {
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(stage2_folded(ctx, row0, mirrored, accumulate, alpha, gt_direct, gt_direct,

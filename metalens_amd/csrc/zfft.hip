@@ -40,6 +40,10 @@ struct FftArgs {
     // min(n, n_valid - 1 - n) < row_first[r % rf_mod] are not read (nullptr: read everything)
     const int *row_first;
     int rf_mod;
+    // two-level transforms (lattices beyond 8192 samples, farfield.hip plan_fft_axis): this launch
+    // transforms the sub-sequence sub_i, sub_i + sub_s, sub_i + 2 sub_s, ... of the axis; sample n
+    // of the transform is sample n sub_s + sub_i of the axis (1, 0: the whole axis)
+    int sub_s, sub_i;
     // output: bin j of row r at out + (r / out_rb) * out_s1 + (r % out_rb) * out_s2 + j * out_es
     cd *out;
     int64_t out_s1, out_s2, out_es;
@@ -71,7 +75,7 @@ __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int
     const int first = a.row_first ? a.row_first[row % a.rf_mod] : 0;
 #pragma unroll
     for (int n2 = 0; n2 < 16; ++n2) {
-        const int n = tid + NT * n2;
+        const int n = (tid + NT * n2) * a.sub_s + a.sub_i;   // sample of the axis
         int q = -1;
         if (n >= a.a0 && n < a.a0 + a.h0) q = n - a.a0;
         if (n >= a.a1 && n < a.a1 + a.h1) q = a.h0 + n - a.a1;
@@ -366,6 +370,8 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
     a.a1 = a.h1 = 0;
     a.row_first = nullptr;
     a.rf_mod = 1;
+    a.sub_s = 1;
+    a.sub_i = 0;
     a.out = reinterpret_cast<cd *>(c.out);
     a.out_s1 = c.out_s1;
     a.out_s2 = c.out_s2;
@@ -460,6 +466,19 @@ __global__ __launch_bounds__(256) void zfft_tables_kernel(cd *tw1, cd *wk, cd *p
 // Is the uniform grid u[0..M) a run of consecutive bins of the FFT lattice of an axis of n samples
 // `step` apart?  kappa = n_glass / wavelength (turns per unit length per unit direction cosine).
 // `tol`: allowed phase deviation [rad] at the aperture edge.  On success fills N_eff and j0.
+// Two-level transforms: an axis of N_eff = 256 R3 samples with R3 > 32 is transformed as s
+// interleaved sub-sequences of N_eff / s samples (decimation in time: X[k] = sum_i W_N^(i k) X_i[k
+// mod N / s]), each by one launch of the one-level kernel that adds its bins - carried to the full
+// lattice by a per-bin phasor - to the result.  Smallest s that brings R3 / s to <= 32; 0 if none
+// up to 8 does (lattices beyond 65536 samples, or R3 with no such divisor).
+int zfft_split(int N_eff) {
+    if (N_eff % 256) return 0;
+    const int R3 = N_eff / 256;
+    for (int s = 1; s <= 8; ++s)
+        if (R3 % s == 0 && R3 / s <= 32) return s;
+    return 0;
+}
+
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
                        long double tol, int *N_eff, int *j0) {
     if (M < 2 || n < 2) return false;
@@ -472,7 +491,9 @@ bool zfft_commensurate(int n, double step, long double kappa, const double *u, i
     const long N = lrintl(inv);
     if (N < n || N < M || N % 256 != 0) return false;
     const int R3 = (int)(N / 256);
-    if (R3 < 1 || R3 > 32) return false;               // LDS: 257 * R3 * 16 bytes per workgroup
+    // one workgroup holds 8192 samples in LDS (257 * R3 * 16 bytes, R3 <= 32); longer lattices are
+    // split into up to 8 interleaved sub-sequences, one launch each (zfft_split)
+    if (R3 < 1 || zfft_split((int)N) == 0) return false;
     const long double du_exact = 1.0L / (kappa * fabsl((long double)step) * N);
     const long jj = lrintl((long double)u[0] / du_exact);
     if (labs(jj) > (1L << 30)) return false;
@@ -530,6 +551,8 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     a.h1 = c.h1;
     a.row_first = c.row_first;
     a.rf_mod = c.rf_mod > 0 ? c.rf_mod : 1;
+    a.sub_s = c.sub_s > 0 ? c.sub_s : 1;
+    a.sub_i = c.sub_i;
     a.out = reinterpret_cast<cd *>(c.out);
     a.out_s1 = c.out_s1;
     a.out_s2 = c.out_s2;
@@ -564,7 +587,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds_bytes));
     int grid = std::min(256 * per_cu, a.chunk * 8);
     grid = (grid + 7) / 8 * 8;
-    if (c.lean && c.in_es == 1) {
+    if (c.lean && c.in_es == 1 && a.sub_s == 1) {
         // co-resident form (banded step): one workgroup per CU is what fits beside the synthesis
         grid = std::min(256 * std::max(1, c.lean_per_cu), a.chunk * 8);
         grid = (grid + 7) / 8 * 8;

@@ -1171,7 +1171,8 @@ def pointwise_rel_err(got, ref, floor=1e-3):
     (4096, 512, 1e-3, 0.5, 'f64', 'auto'),        # north-star size; both axes run as pruned FFTs
     (4096, 512, 1e-3, 0.5, 'f64', 'gemm'),        # the same through the folded fp64 GEMMs
     (8192, 512, 2e-3, 0.94, 'f64', 'auto'),       # BASELINE configs[2]'s problem on one GPU
-    (16384, 1024, 4e-3, 0.5, 'f64', 'auto'),      # BASELINE configs[4]'s size (GEMMs: lattice > 8192)
+    (16384, 1024, 4e-3, 0.5, 'f64', 'auto'),      # BASELINE configs[4]'s size (two-level FFT: lattice > 8192)
+    (16384, 1024, 4e-3, 0.5, 'f64', 'gemm'),      # ... through the folded fp64 GEMMs
     (16384, 1024, 4e-3, 0.5, 'f32', 'auto'),      # ... and its fp32 GEMM-cast MFMA path, tolerance 1e-4
 ])
 def test_north_star_size_properties(ma, side, M, diameter, na, precision, method):
@@ -1203,8 +1204,8 @@ def test_north_star_size_properties(ma, side, M, diameter, na, precision, method
         one.step()
         one.sync()
         r1 = one.results()
-        want_kernels = {('auto', 4096): ('fft', 'fft'), ('auto', 8192): ('fft', 'fft')}.get(
-            (method, side), ('folded', 'folded'))
+        # (lattices beyond 8192 samples run as two-level FFTs; the fp32 mode asks for the GEMMs)
+        want_kernels = ('fft', 'fft') if method == 'auto' and precision == 'f64' else ('folded', 'folded')
         assert ctx.plan_kernels() == want_kernels
         # (a) sample against the oracle
         rows = slice(side // 2 - 8, side // 2 + 8)
@@ -1293,10 +1294,10 @@ def test_large_aperture_plans_take_the_folded_path(ma, N, M):
         bent = u.copy()
         bent[3] += 1e-9 * du * M      # far above rounding, far below anything a user would notice
         assert planned_kernel(bent) == 0
-        # left to itself the plan takes the pruned FFT where the lattice fits its LDS (<= 8192
-        # samples), and the same perturbation sends it back to the GEMMs
+        # left to itself the plan takes the pruned FFT (one level up to 8192 samples, up to eight
+        # interleaved sub-sequences beyond), and the same perturbation sends it back to the GEMMs
         ctx.set_method('auto')
-        assert planned_kernel(u) == (2 if N <= 8192 else 1)
+        assert planned_kernel(u) == 2
         assert planned_kernel(bent) == 0
     finally:
         ctx.set_method('auto')
