@@ -47,7 +47,7 @@ def fields(nx, ny, seed):
     (300, 1000, 1024, 2048, 64, 64, -40, -20),      # finer than the lattice: zoom 1/3.4 and 1/2
     (40, 4000, 256, 4096, 16, 300, -8, 3990),       # window wrapping around the end of the lattice
     (24, 16384, 256, 16384, 16, 600, -8, -300),     # beyond one workgroup's LDS: two interleaved halves of 8192
-    (20, 12288, 512, 12288, 24, 100, -12, 6100),    # R3 = 48 -> two sub-sequences of R3 = 24
+    (20, 12288, 512, 12288, 24, 100, -12, -50),     # R3 = 48 -> two sub-sequences of R3 = 24
     (16, 20000, 256, 24576, 16, 90, -8, -45),       # R3 = 96 -> three of R3 = 32, zero-padded axis
     (16384, 12, 16384, 256, 70, 12, -35, -6),       # ... and along x (the column pass)
 ])
