@@ -680,6 +680,39 @@ def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs, world):
     assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
 
 
+def test_wavelength_replicas(tmp_path):
+    """BASELINE configs[3] (tri-wavelength sweep, one wavelength per rank, no collective in the data
+    path): ``bench.py --replicas wavelength`` as three single-rank runs, one per wavelength, then as
+    two ranks sharing the GPU through the file communicator.  Every replica checks itself against the
+    oracle and reports the substrate index it ran with - explicit, because none of the three
+    wavelengths is in the reference's table (grating.py:1277-1288, nearfield.py:111-113)."""
+    import json
+    want = {450: 1.4656, 532: 1.4607, 635: 1.4570}
+    extra = ['--replicas', 'wavelength', '--check', '1', '--cold', '0']
+    for k, (nm_, ng) in enumerate(want.items()):
+        p = _run_bench(extra + ['--replica-index', str(k)], {}, aperture=512)
+        out, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-2000:]
+        d = json.loads([l for l in out.splitlines() if l.strip()][-1])
+        (rep,) = d['config']['replicas']
+        assert round(rep['wavelength_nm']) == nm_ and rep['n_glass'] == ng
+        assert 0 <= d['rel_err']['nearfield_vs_oracle'] < 1e-12 and 0 <= d['rel_err']['farfield_E_vs_oracle'] < 1e-12
+        assert d['config']['parallelism'].startswith('replicas only')
+    env = dict(ML_COMM_BACKEND='file', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611')
+    procs = [_run_bench(['--gpus', '2'] + extra, dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=512)
+             for r in range(2)]
+    outs = [q.communicate(timeout=600) for q in procs]
+    for q, (o, e) in zip(procs, outs):
+        assert q.returncode == 0, e[-2000:]
+    d = json.loads([l for l in outs[0][0].splitlines() if l.strip()][-1])
+    assert d['n_gpus'] == 2 and [round(r['wavelength_nm']) for r in d['config']['replicas']] == [450, 532]
+    assert [r['n_glass'] for r in d['config']['replicas']] == [1.4656, 1.4607]
+    for r in d['config']['replicas']:
+        assert 0 <= r['nearfield_vs_oracle'] < 1e-12 and 0 <= r['farfield_E_vs_oracle'] < 1e-12
+    # twice the work of one replica in the same time: the aggregate counts both apertures
+    assert abs(d['value'] - 2 * 512.0 ** 2 * 64 ** 2 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
+
+
 def test_bench_line_contract():
     """bench.py at N = 1 prints exactly one JSON line with the fields the driver reads: the
     metric, K timed steps, a roofline object with a fraction <= 1 and the per-launch duration it

@@ -73,10 +73,10 @@ def test_reference_flow_on_the_default_grid_golden():
     assert dux == z['dux'] and duy == z['duy']
 
 
-@pytest.mark.parametrize('N', [512, 768, 500])
+@pytest.mark.parametrize('N', [512, 768, 500, 1024])
 def test_whole_lattice_vs_oracle_flow(N):
-    """a lens window of N x N samples (512, 768: multiples of 256 -> both axes run as the pruned FFT
-    with nothing pruned; 500: the folded GEMMs): every lattice direction against the oracle's
+    """a lens window of N x N samples (512, 768, 1024: multiples of 256 -> both axes run as the pruned
+    FFT with nothing pruned; 500: the folded GEMMs): every lattice direction against the oracle's
     restatement of the reference flow (numpy.fft on the host) - ALL N^2 directions, not a sample"""
     import metalens_amd as ma
     from metalens_amd import _lib
