@@ -98,7 +98,7 @@ def nearfield_roof(avg_ms, nf_bytes, pmc_nf):
 def pmc_key(gpus, aperture, farfield, precision, method, zoom, pols, overlap):
     key = ('gpus=%d,aperture=%d,farfield=%d,precision=%s,method=%s,zoom=%g,pols=%d'
            % (gpus, aperture, farfield, precision, method, zoom, pols))
-    return key + (',overlap=%d' % overlap if overlap > 1 else '')
+    return key + (',overlap=%d' % overlap if overlap > 1 else '') + (',pipeline' if overlap == -1 else '')
 
 
 def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0):
@@ -258,6 +258,10 @@ def main():
     ap.add_argument('--cold', type=int, default=1,
                     help='1: also time single steps on a sample grid the context has not seen '
                          '(ms_first_step_new_geometry); N = 1 only')
+    ap.add_argument('--pipeline', default='0',
+                    help="the pipelined sweep (metalens_hip.h ml_step_pipeline): '1' or '1,wpb,lean,per_cu' - "
+                         'consecutive steps overlap: the synthesis of step k + 1 runs beside the transform of '
+                         'step k on a second stream (two field buffers); N = 1 only')
     ap.add_argument('--overlap', default='0',
                     help="the banded step (metalens_hip.h ml_step_overlap): 'B' or 'B,wpb,lean,per_cu,same_stream' - "
                          'B > 1 bands of aperture rows, the synthesis of band b + 1 runs beside the row '
@@ -313,6 +317,11 @@ def main():
     ov = [int(v) for v in args.overlap.split(',')]
     ov = ov + [4, 1, 1, 0][len(ov) - 1:]
     ctx.set_overlap(ov[0], ov[1], bool(ov[2]), ov[3], bool(ov[4]))
+    pl_ = [int(v) for v in args.pipeline.split(',')]
+    pl_ = pl_ + [4, 1, 1][len(pl_) - 1:]
+    if pl_[0]:
+        assert world == 1, '--pipeline is a single-GPU mode'
+        ctx.set_pipeline(True, pl_[1], bool(pl_[2]), pl_[3])
     n_pols = len(args.pols)
     if n_pols > 1:
         assert world == 1 and not args.pair_list, '--pols batches are a single-GPU tensor-grid mode'
@@ -451,7 +460,7 @@ def main():
                    'rings': int(len(lens['lens_periphery_summary']['r_center_list'])),
                    'centre_cells': int(len(lens['lens_center_summary'])),
                    'parallelism': par, 'sharding': hp.sharding, 'sources_per_step': n_pols,
-                   'overlap_bands': ov[0], 'replicas': replica_table,
+                   'overlap_bands': ov[0], 'pipelined_steps': bool(pl_[0]), 'replicas': replica_table,
                    'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]}},
         # the same K steps again, args.blocks times in all: spread of the measurement
         'ms_per_step_blocks': block_ms, 'ms_per_step_median': float(np.median(block_ms)),
@@ -470,7 +479,7 @@ def main():
                                    for k, v in prof.items() if v['launches']}
     line['kernel_timing'] = {'mode': args.profile, 'timed_every_n_steps': every}
     local_rows = hp.x_local.size
-    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols, ov[0])
+    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols, -1 if pl_[0] else ov[0])
     line['config']['pmc_key'] = key
     pmc = load_pmc_table().get(key, {})
     roofs = {}

@@ -231,6 +231,17 @@ int ml_farfield_set_method(ml_ctx *ctx, int method);
  * bands = 0 or 1 switches the banding off (default).                                            */
 int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu,
                     int same_stream);
+/* The PIPELINED sweep: the same idea across steps instead of inside one.  The reference's use of
+ * this path is a sweep over sources on one lens (nearfield.py:69-73); with on = 1 consecutive
+ * ml_nearfield_async / ml_farfield_transform*_async / ml_farfield_project_async calls overlap:
+ * syntheses stay on the context's stream and alternate between two field buffers, transforms and
+ * projections are queued on a second stream, step k + 1's synthesis waits only for the transform
+ * that last read its buffer (step k - 1's), step k's transform for step k's synthesis.  What the
+ * host reads back (ml_farfield_project, ml_farfield_download, ml_fields_download, ml_nearfield_result,
+ * ml_sync) is the LAST queued step's, complete - those entry points join the two streams; sums over
+ * the sources of a sweep are taken on the GPU as before (ml_farfield_accumulate, queued behind each
+ * projection).  Single GPU, single-source syntheses; switches the banded step off.               */
+int ml_step_pipeline(ml_ctx *ctx, int on, int nf_waves_per_block, int fft_lean, int fft_per_cu);
 /* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",
  * configs[4] "fp32 GEMM-cast MFMA path").  ML_PRECISION_F64 (default): fp64 matrix cores.
  * ML_PRECISION_F32_GEMM: the folded GEMMs of both stages round their operands to fp32 and

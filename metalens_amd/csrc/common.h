@@ -247,6 +247,25 @@ struct Overlap {
     long key[6] = {-1, -1, -1, -1, -1, -1};   // geo_key + (bands, n_active) the table was built for
     bool live = false;      // the resident fields were synthesised in bands (events valid)
     int live_rows = 0;
+    // The PIPELINED sweep (ml_step_pipeline): consecutive steps overlap instead of the bands of one
+    // step.  Syntheses stay on the main stream and alternate between two field buffers; transforms
+    // and projections run on `aux`; step k + 1's synthesis waits for the transform that last read
+    // its buffer (two steps back), step k's transform for step k's synthesis.
+    int pipeline = 0;
+    int buf = 0;                               // buffer the last synthesis wrote
+    hipEvent_t main_mark = nullptr, aux_mark = nullptr, xf_done[2] = {nullptr, nullptr};
+    bool xf_valid[2] = {false, false};
+    bool aux_busy = false;                     // work queued on aux since the last host join
+};
+
+// transforms and projections of a pipelined sweep are queued on the second stream: everything
+// below the entry point launches on ctx->stream, so it is pointed there for the duration
+struct AuxStreamScope {
+    ml_ctx *ctx;
+    hipStream_t saved = nullptr;
+    bool on = false;
+    int enter(ml_ctx *c);
+    ~AuxStreamScope();
 };
 
 }  // namespace ml
@@ -291,6 +310,9 @@ struct ml_ctx {
     // batch); the far-field and download entry points work on set `field_set`
     int nx = 0, ny = 0, n_sets = 1, field_set = 0;
     ml::DevBuf fields;
+    // the other field buffer of a pipelined sweep and the zero_key that goes with it
+    ml::DevBuf fields_alt;
+    long zero_key_alt[6] = {0, -1, -1, -1, -1, -1};
     double *set_ptr() const {
         return reinterpret_cast<double *>(fields.p) + (size_t)field_set * 4 * nx * ny * 2;
     }

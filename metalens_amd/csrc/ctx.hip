@@ -454,9 +454,11 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     if (ctx->ov.aux) {
         (void)hipStreamSynchronize(ctx->ov.aux);
         for (auto e : ctx->ov.band_done) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(ctx->ov.s1_done);
+        for (hipEvent_t e : {ctx->ov.s1_done, ctx->ov.main_mark, ctx->ov.aux_mark, ctx->ov.xf_done[0], ctx->ov.xf_done[1]})
+            if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(ctx->ov.aux);
     }
+    ctx->fields_alt.release();
     for (auto &s : ctx->slots) {
         s.axis0.release();
         s.axis1.release();
@@ -767,6 +769,15 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
     ML_TRY(grid_axis(ctx->x_pts, ctx->h_x_pts, x_pts, nx));
     ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
+    if (ctx->ov.pipeline && n == 1) {
+        // pipelined sweep: this synthesis writes the OTHER field buffer, once the transform that
+        // read it two steps ago is through
+        Overlap &ov = ctx->ov;
+        std::swap(ctx->fields, ctx->fields_alt);
+        for (int k = 0; k < 6; ++k) std::swap(ctx->zero_key[k], ctx->zero_key_alt[k]);
+        ov.buf ^= 1;
+        if (ov.xf_valid[ov.buf]) ML_HIP(hipStreamWaitEvent(ctx->stream, ov.xf_done[ov.buf], 0));
+    }
     ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
@@ -961,6 +972,7 @@ int ml_fields_download(ml_ctx *ctx, double *Ex, double *Ey, double *Hx, double *
         return ML_ESTATE;
     }
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(comm_join(ctx, false));
     ML_TRY(fields_unmodulate(ctx));   // the host always sees the plain near field
     const size_t plane_bytes = (size_t)ctx->nx * ctx->ny * 2 * sizeof(double);
     double *dst[4] = {Ex, Ey, Hx, Hy};

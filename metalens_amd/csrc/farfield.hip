@@ -818,6 +818,17 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     }
     ML_REQUIRE(!accumulate || pl.have_vectors, "accumulate requested but nothing to add to");
     ML_HIP(hipSetDevice(ctx->device));
+    AuxStreamScope aux_scope;             // pipelined sweep: queued on the second stream
+    ML_TRY(aux_scope.enter(ctx));
+    struct BufferRelease {                // ... and the field buffer is free again once this is through
+        ml_ctx *c;
+        bool on;
+        ~BufferRelease() {
+            if (!on) return;
+            Overlap &ov = c->ov;
+            if (hipEventRecord(ov.xf_done[ov.buf], c->stream) == hipSuccess) ov.xf_valid[ov.buf] = true;
+        }
+    } release{ctx, aux_scope.on};
     // a deferred unfold of the previous transform: needed if this one adds to it, moot otherwise
     if (accumulate)
         ML_TRY(flush_unfold(ctx));
@@ -911,6 +922,10 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.alpha_rb = c.rows;
             c.accumulate = 0;
             Overlap &ov = ctx->ov;
+            if (ov.pipeline) {   // beside the next step's synthesis: the register-lean kernel
+                c.lean = ov.lean;
+                c.lean_per_cu = ov.fft_per_cu;
+            }
             if (split1 > 1) {
                 // two-level: sub-sequence i of every row adds its bins (zfft.hip zfft_split)
                 for (int i = 0; i < split1; ++i) {
@@ -1172,6 +1187,8 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream =
         return ML_ESTATE;
     }
     ML_HIP(hipSetDevice(ctx->device));
+    AuxStreamScope aux_scope;             // pipelined sweep: behind its transform on the second stream
+    if (!stream) ML_TRY(aux_scope.enter(ctx));
     const int mx = pl.mx, my = pl.pair_list ? 1 : pl.my;
     const size_t n = (size_t)mx * my;
     ProjArgs a;
@@ -1397,6 +1414,7 @@ int ml_farfield_sums(ml_ctx *ctx, double *P_sum, double *total_P, double *cone_P
     ML_REQUIRE(n_slots >= 0 && n_slots <= ML_MAX_SWEEP_SLOTS, "n_slots %d out of range", n_slots);
     ML_REQUIRE(ctx->acc_P.p && ctx->acc_sums.p, "ml_farfield_accumulate has not run");
     ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(comm_join(ctx, false));
     FarfieldPlan &pl = ctx->plan;
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     std::vector<double> sums((size_t)2 * std::max(n_slots, 1));
@@ -1441,12 +1459,46 @@ int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean
     // a banded step in flight keeps using the old table: wait for it
     ML_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->ov.aux) ML_HIP(hipStreamSynchronize(ctx->ov.aux));
+    if (bands > 1) {
+        ML_TRY(comm_join(ctx, true));
+        ctx->ov.pipeline = 0;
+    }
     ctx->ov.bands = bands;
     ctx->ov.wpb = nf_waves_per_block;
     ctx->ov.lean = fft_lean ? 1 : 0;
     ctx->ov.fft_per_cu = fft_per_cu;
     ctx->ov.same_stream = same_stream ? 1 : 0;
     ctx->ov.live = false;
+    return ML_OK;
+}
+
+int ml_step_pipeline(ml_ctx *ctx, int on, int nf_waves_per_block, int fft_lean, int fft_per_cu) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(nf_waves_per_block == 1 || nf_waves_per_block == 4, "synthesis workgroups have 1 or 4 waves");
+    ML_REQUIRE(fft_per_cu >= 1 && fft_per_cu <= 4, "1 to 4 transform workgroups per CU");
+    ML_REQUIRE(!on || (!ctx->comm && !ctx->comm_file), "the pipelined sweep is a single-GPU mode");
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(comm_join(ctx, true));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
+    Overlap &ov = ctx->ov;
+    if (on && !ov.aux) {
+        ML_HIP(hipStreamCreateWithFlags(&ov.aux, hipStreamNonBlocking));
+        ML_HIP(hipEventCreateWithFlags(&ov.s1_done, hipEventDisableTiming));
+    }
+    if (on && !ov.main_mark) {
+        ML_HIP(hipEventCreateWithFlags(&ov.main_mark, hipEventDisableTiming));
+        ML_HIP(hipEventCreateWithFlags(&ov.aux_mark, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) ML_HIP(hipEventCreateWithFlags(&ov.xf_done[k], hipEventDisableTiming));
+    }
+    ov.pipeline = on ? 1 : 0;
+    if (on) {
+        ov.bands = 0;
+        ov.wpb = nf_waves_per_block;
+        ov.lean = fft_lean ? 1 : 0;
+        ov.fft_per_cu = fft_per_cu;
+    }
+    ov.live = false;
+    ov.xf_valid[0] = ov.xf_valid[1] = false;
     return ML_OK;
 }
 
@@ -1471,7 +1523,13 @@ int ml_farfield_set_precision(ml_ctx *ctx, int precision) {
     return ML_OK;
 }
 
+int ml_farfield_download_impl(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_TRY(comm_join(ctx, false));
+    return ml_farfield_download_impl(ctx, Nx, Ny, Lx, Ly);
+}
+int ml_farfield_download_impl(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly) {
     ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready || !pl.have_vectors) {

@@ -268,7 +268,13 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     }
     {
         ProfScope scope(ctx, ML_K_NEARFIELD);
-        if (a.use_active && n == 1 && ctx->ov.bands > 1 && nf_mode != 1) {
+        if (a.use_active && n == 1 && ctx->ov.pipeline && nf_mode != 1) {
+            // pipelined sweep: the listed patches as four-wave workgroups (they let the transform of
+            // the previous step, which runs beside this launch, into the CUs - nearfield_fast.hip)
+            ctx->ov.live = false;
+            ML_TRY(nearfield_band_launch(ctx->stream, a, 0, a.n_active, ctx->ov.wpb));
+            n_partials = a.n_partials;
+        } else if (a.use_active && n == 1 && ctx->ov.bands > 1 && nf_mode != 1) {
             ML_TRY(banded_launch(ctx, a, nx, ny, geo_key));
             n_partials = a.n_partials;
         } else {
@@ -283,7 +289,9 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     ctx->power_pending = true;
     // a batch sums the partials of all its members now (the projection kernel's spare block,
     // which does it for free in the single-source pipeline, knows one set only)
-    if (n > 1) ML_TRY(power_flush(ctx));
+    // ... and so does a pipelined sweep: the next synthesis overwrites the partials while this
+    // step's projection is still waiting on the second stream
+    if (n > 1 || ctx->ov.pipeline) ML_TRY(power_flush(ctx));
     return ML_OK;
 }
 

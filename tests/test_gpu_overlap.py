@@ -91,6 +91,46 @@ def test_banded_step_is_bit_identical(side, M, diameter, na, overlap):
         ctx.set_overlap(0)
 
 
+@pytest.mark.parametrize('side,M,diameter,na', [(1024, 128, 0.25e-3, 0.5), (2048, 256, 1e-3, 0.5)])
+@pytest.mark.parametrize('opts', [(4, True, 1), (1, False, 2), (4, True, 2)])
+def test_pipelined_sweep_equals_step_by_step(side, M, diameter, na, opts):
+    """ml_step_pipeline: consecutive steps overlap on two streams and two field buffers.  Whatever
+    the interleaving on the GPU, what the host reads after a run of steps is the LAST step's, and
+    equal to the step-by-step result (bit for bit for the fields and, with the ordinary row
+    transform, for the far field) - also when the sources alternate, so that the two field buffers
+    hold different fields."""
+    from metalens_amd import _lib
+    ctx = _lib.default_context()
+    try:
+        ctx.set_pipeline(False)
+        hp = _hotpath(ctx, side, M, diameter, na)
+        first = hp.params
+        want = {}
+        F_want = {}
+        for name, src in (('a', None), ('b', hp.other_source)):
+            if src is not None:
+                hp.set_source(src)
+            hp.step()
+            hp.sync()
+            want[name] = hp.results()
+            F_want[name] = _fields(ctx, side, side)
+        assert ctx.plan_kernels()[0] == 'fft'
+        a_params, b_params = first, hp.params
+        ctx.set_pipeline(True, *opts)
+        for seq, last in (('ababab', 'b'), ('bbaba', 'a'), ('a', 'a')):
+            for ch in seq:
+                hp.params = a_params if ch == 'a' else b_params
+                hp.step()
+            hp.sync()
+            got = hp.results()
+            for a, b in zip(_fields(ctx, side, side), F_want[last]):
+                assert np.array_equal(a, b)
+            _same(got, want[last], exact=not opts[1])
+            assert got['power_local_rows'] == want[last]['power_local_rows']
+    finally:
+        ctx.set_pipeline(False)
+
+
 def test_banded_step_on_a_mirrored_shard():
     """a rank's mirrored row pairs (what bench.py --gpus 2 gives rank 0) banded = unbanded"""
     from metalens_amd import _lib
