@@ -54,11 +54,17 @@ class SourceSweep:
         self.ux, self.uy = _lib.f64(np.ravel(ux)), _lib.f64(np.ravel(uy))
         self.dxp, self.dyp = x_pts[1] - x_pts[0], y_pts[1] - y_pts[0]
 
-    def prepare(self):
-        """make tables, layout and the far-field plan resident (no-ops when they already are)"""
+    def prepare(self, check_content=True):
+        """make tables, layout and the far-field plan resident (no-ops when they already are).
+        ``check_content=False`` (``queue``): trust the content hashes of the last full ``prepare``
+        as long as the context still holds the tables and layout it left there - hashing the
+        caller's 30 MB of cells on every queued pass would make a sweep host-bound"""
         ctx, lib = self.ctx, self.ctx.lib
-        packing.upload_tables(ctx, *self._tables)
-        packing.upload_layout(ctx, *self._layout)
+        mine = getattr(self, '_resident', None)
+        if check_content or mine is None or mine != (ctx.tables_token, ctx.layout_token):
+            packing.upload_tables(ctx, *self._tables)
+            packing.upload_layout(ctx, *self._layout)
+            self._resident = (ctx.tables_token, ctx.layout_token)
         _lib.check(lib.ml_nearfield_premodulate(ctx.handle, 0))
         _lib.check(lib.ml_farfield_plan(ctx.handle, self.x.size, self.y.size, self.dxp, self.dyp,
                                         self.wavelength, self.n_glass, _lib.dptr(self.ux),
@@ -67,7 +73,7 @@ class SourceSweep:
     def queue(self, sources):
         """queue the whole sweep on the GPU and return without synchronising (benchmarks);
         tie settlement and the downloads are ``run``'s business"""
-        self.prepare()
+        self.prepare(check_content=False)
         weights = np.ones(len(sources))
         for g in self._group(sources):
             self._pass(g, None, (0.0, 0.0, 0.0), weights)

@@ -1,23 +1,30 @@
 #!/bin/bash
 # One round's evidence in one GPU call: rocprofv3 kernel trace + stats of EXACTLY the default
-# bench command (what the driver runs at N = 1), the HBM-traffic counter passes (each in its own
-# run, kernel-trace only, as MI355X_MICROARCH.md prescribes) and the bench lines at the
-# configurations DESIGN.md quotes.  Run on the GPU box:
+# bench command (what the driver runs at N = 1), the counter passes (each in its own run,
+# kernel-trace only, as MI355X_MICROARCH.md prescribes) for the configurations DESIGN.md quotes,
+# and their bench lines.  Run on the GPU box:
 #     tools/profile_round.sh TAG        -> gpurun_out/TAG/...
-# then digest locally with tools/profile_summary.py / tools/pmc_digest.py into profiles/.
+# then digest locally:  tools/profile_summary.py (text summary) and tools/pmc_table.py (the
+# per-configuration counter table bench.py reads, profiles/pmc_table.json).
 # EVERY rocprofv3 call runs under `timeout`: a counter set the profiler cannot collect makes it
 # abort and then wait forever (round 2 lost 40 GPU-minutes to exactly that with TA_* counters).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1
 mkdir -p $O
 T="timeout -k 5 ${PMC_TIMEOUT:-240}"
-SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0"
 cd /tmp && export TMPDIR=/tmp
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --cpu-rows 0 --cpu-fft-side 0 > $O/stats.log 2>&1
-$T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- $SHORT > $O/fetch.log 2>&1
-$T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- $SHORT > $O/write.log 2>&1
-$T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -- $SHORT > $O/sq.log 2>&1
-$T rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/sq2 -- $SHORT > $O/sq2.log 2>&1
+pmc() {   # pmc NAME <bench args>: the three counter passes of one configuration
+  name=$1; shift
+  SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 $@"
+  $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$name/fetch -- $SHORT > $O/$name.fetch.log 2>&1
+  $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/$name/write -- $SHORT > $O/$name.write.log 2>&1
+  $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$name/sq -- $SHORT > $O/$name.sq.log 2>&1
+}
+pmc c4096
+pmc c2048 --aperture 2048 --farfield 256
+pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
+pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
 cd $R
 B="python bench.py --cpu-rows 0 --cpu-fft-side 0"
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench.json
@@ -31,4 +38,7 @@ timeout 300 $B --precision f32 --profile all 2>/dev/null | tail -1 > $O/bench_f3
 timeout 300 $B --zoom 0.5 --profile all 2>/dev/null | tail -1 > $O/bench_zoom05.json
 timeout 300 $B --zoom 0.7 --profile all 2>/dev/null | tail -1 > $O/bench_zoom07.json
 timeout 300 $B --pair-list 4096 --profile all 2>/dev/null | tail -1 > $O/bench_pairlist4096.json
-ls -la $O
+timeout 300 $B --overlap 8,4,1,2 --profile all 2>/dev/null | tail -1 > $O/bench_overlap8.json
+timeout 300 $B --pipeline 1,4,1,2 --profile all 2>/dev/null | tail -1 > $O/bench_pipeline.json
+timeout 300 python tools/dropin_time.py > $O/dropin.log 2>&1
+ls $O
