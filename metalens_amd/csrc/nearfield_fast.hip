@@ -973,7 +973,11 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
         return ML_OK;
     }
 #endif
+#ifdef ML_FORCE_GEN
+    const bool gen = true;   // A/B builds only: the general kernels whatever the order sets
+#else
     const bool gen = !a.simple_orders;
+#endif
     if (a.n_pol == 1 && gen)
         hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, true>), grid, dim3(64), 0, ctx->stream, a);
     else if (a.n_pol == 1)
