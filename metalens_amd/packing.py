@@ -13,6 +13,8 @@ exposing ``.grating_list[i].data``, ``.grating_list[0].n_glass / .grating_period
 import hashlib
 from math import pi
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -65,11 +67,41 @@ except ImportError:       # pragma: no cover
         return hashlib.blake2b(digest_size=16)
 
 
+_POOL = None
+_BIG = 4 << 20        # arrays beyond this are hashed in parallel chunks
+_CHUNKS = 8
+
+
+def _cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:    # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def _chunk_digest(view):
+    h = _hasher()
+    h.update(view)
+    return h.digest()
+
+
 def _feed(h, a):
-    """hash an array's dtype, shape and bytes (no copy for contiguous arrays)"""
+    """hash an array's dtype, shape and bytes (no copy for contiguous arrays).  Large arrays (the
+    cell list of a millimetre lens is 30 MB, hashed on EVERY drop-in call) are hashed as eight
+    chunks on a thread pool - xxhash releases the GIL - and the chunk digests fed in order"""
+    global _POOL
     a = np.ascontiguousarray(a)
     h.update(('%s%s' % (a.dtype.str, a.shape)).encode())
-    h.update(memoryview(a).cast('B'))
+    view = memoryview(a).cast('B')
+    if view.nbytes < _BIG or _cores() < 2 * _CHUNKS:
+        h.update(view)
+        return
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=_CHUNKS)
+    step = -(-view.nbytes // _CHUNKS)
+    for d in _POOL.map(_chunk_digest, [view[k:k + step] for k in range(0, view.nbytes, step)]):
+        h.update(d)
 
 
 def _tables_fingerprint(objs, wavelength_in_nm):
