@@ -218,6 +218,10 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     ML_REQUIRE(ctx && id, "NULL argument");
     ML_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank %d of %d", rank, n_ranks);
     ML_HIP(hipSetDevice(ctx->device));
+    // the pipelined sweep is a single-GPU mode (its transforms run on the second stream, which is
+    // also where a reduction would go): a communicator switches it off
+    ML_TRY(comm_join(ctx, true));
+    ctx->ov.pipeline = 0;
     comm_release(ctx);
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;
