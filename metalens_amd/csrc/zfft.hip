@@ -171,15 +171,6 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
             load_row_lean<R3T>(a, g, row, tid, v);
         else if (more)
             load_row<R3T, PASS == 1>(a, g, row_n, tid, nx);
-        // a row with no sample inside the lens circle (7 % of the rows of a window 8 % wider than
-        // the lens) is all zeros, and so is its transform: no butterflies, no exchanges
-        const bool empty_row = a.row_first && 2 * (long long)a.row_first[row % a.rf_mod] >= g.n_valid;   // block-uniform
-        if (empty_row) {
-            if (!a.accumulate) {
-                cd *dst0 = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-                for (int o = tid; o < g.M; o += NT) dst0[o * a.out_es] = zf::mk(0.0, 0.0);
-            }
-        } else {
         if (LEAN) {
             zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
         } else {
@@ -252,7 +243,6 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
             }
         }
         __syncthreads();   // the next row's stage 1 overwrites the buffer
-        }   // !empty_row
         if (!LEAN) {
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) v[n2] = nx[n2];
