@@ -281,9 +281,12 @@ def test_mirrored_shards_sum_to_whole(ma, nx, ny, mx, my):
         assert np.abs(got[key] - w).max() <= TOL * np.abs(w).max(), key
 
 
-@pytest.mark.parametrize('N,world,block', [(512, 2, 1), (1024, 2, 2), (2048, 8, 1), (2048, 2, 4), (4096, 4, 4),
-                                           (1536, 2, 1)])
-def test_interleaved_shards_sum_to_whole(ma, N, world, block):
+@pytest.mark.parametrize('N,world,block,M,diameter,na', [
+    (512, 2, 1, 96, 0.2e-3, 0.4), (1024, 2, 2, 96, 0.2e-3, 0.4), (2048, 8, 1, 96, 0.2e-3, 0.4),
+    (2048, 2, 4, 96, 0.2e-3, 0.4), (4096, 4, 4, 96, 0.2e-3, 0.4), (1536, 2, 1, 96, 0.2e-3, 0.4),
+    (8192, 8, 4, 512, 2e-3, 0.94),      # BASELINE configs[2] at size: the 2 mm NA 0.94 lens over 8 ranks
+])
+def test_interleaved_shards_sum_to_whole(ma, N, world, block, M, diameter, na):
     """Blocks of rows dealt round robin over the ranks (metalens_hip.h ml_farfield_interleave_block):
     every rank's shard through its own synthesis and its SHORT column pass on one GPU, the partial
     radiation vectors added up on the host = the whole aperture in one piece, and the incident power
@@ -296,7 +299,7 @@ def test_interleaved_shards_sum_to_whole(ma, N, world, block):
     from metalens_amd import _lib
     from metalens_amd.pipeline import HotPath
     wl = 580e-9
-    lens, x, u = bench.build_workload(N, 96, 0.2e-3, 0.4, wl, 1.0)
+    lens, x, u = bench.build_workload(N, M, diameter, na, wl, 1.0)
     src = (0.2e-6, -0.1e-6, -lens['source_distance'], 'y')
     args = (src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'],
             x, x, u, u)
