@@ -449,7 +449,8 @@ int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, i
 void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2);
 // the column pass of an interleaved shard: s short transforms per column in one workgroup; c.pj holds
 // [s][M] phasors, sub-sequence i starts sub_off elements behind sub-sequence i - 1
-int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off);
+// (stuff > 1: the transforms have c.N_eff / stuff samples and run zero-stuffed at c.N_eff)
+int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off, int stuff);
 int zfft_build_interleave_tables(hipStream_t stream, double *wk, double *pj, int *kbin, int M, int j0, int Nsub,
                                  int N, int c, int first, int block);
 int zfft_run(hipStream_t stream, const ZfftCall &c);

@@ -767,12 +767,22 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
 // or mirrored block of rows costs every rank the full-length pass.  Needs the x axis on the pruned
 // FFT with a lattice of exactly the aperture's rows; Nsub = 256 R3 with R3 <= 32.  s is taken as
 // large as that allows (up to 8: the synthesis works on 8-row patches and wants neighbouring rows).
+// A short transform of n_sub samples runs on the lattice of n_sub * stuff = 256 R3 samples, zero-
+// stuffed when n_sub is below 256 (zfft_interleaved_kernel); 0: n_sub does not fit
+static int interleave_stuff(int n_sub) {
+    for (int z = 1; z <= 8; z <<= 1)
+        if ((n_sub * z) % 256 == 0) return z;
+    return 0;
+}
+
 static int interleave_block(const FarfieldPlan &pl, int n_ranks) {
     if (!pl.ready || pl.pair_list || !pl.fft_x.ok || pl.fft_x.N_eff != pl.nx_total || n_ranks < 2) return 0;
     const int N = pl.nx_total;
     for (int s = 8; s >= 1; s >>= 1) {
-        if (N % (s * n_ranks * 256) != 0) continue;
-        const int r3 = N / (s * n_ranks * 256);
+        if (N % (s * n_ranks) != 0) continue;
+        const int stuff = interleave_stuff(N / (s * n_ranks));
+        if (!stuff) continue;
+        const int r3 = N / (s * n_ranks) * stuff / 256;
         // (the s transforms of a column share one workgroup: 16 r3 s threads, s buffers of 4 r3 KB)
         if (r3 >= 1 && r3 <= 32 && r3 * s <= 32) return s;
     }
@@ -999,7 +1009,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         // bins, carried to the full lattice by pj[i][.], into V[3 - f][.][b]
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(collapse_stage1());
-        const int s = sh.block, G = sh.n_ranks, N = pl.nx_total, Nsub = N / (s * G);
+        const int s = sh.block, G = sh.n_ranks, N = pl.nx_total;
+        const int stuff = interleave_stuff(N / (s * G)), Nsub = N / (s * G) * stuff;   // the lattice it runs on
         const long key[4] = {pl.serial, s, G, sh.rank};
         if (memcmp(key, pl.il_key, sizeof key) != 0) {
             ML_TRY(pl.il_wk.reserve((size_t)mx * 2 * sizeof(double)));
@@ -1042,7 +1053,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             for (int k = 0; k < 4; ++k) c.alpha[k] = alpha[k];
             c.alpha_rb = my;
             c.accumulate = accumulate;
-            ML_TRY(zfft_run_interleaved(ctx->stream, c, s, my));
+            ML_TRY(zfft_run_interleaved(ctx->stream, c, s, my, stuff));
         }
     } else if (fft2) {
         // stage 2 along x as a pruned FFT over the columns of stage 1's result: row (f, b) reads

@@ -309,7 +309,12 @@ __global__ __launch_bounds__(256) void zfft_multi_kernel(const FftArgs a, int cp
 // results of a wanted bin - each carried to the full lattice by its pj[i][.] - before the ONE store.
 // (Launched once per i with an accumulating store instead, the 4 x 2048 x 512 scattered 16-byte
 // read-modify-writes of configs[2]'s 8-rank shard cost twice the full-length pass they replace.)
-__global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, int s, int64_t sub_off) {
+// `stuff` > 1: the short transform has N_eff / stuff samples (fewer than the 256 the 16 x 16 x R3
+// factorisation starts at); it runs as the N_eff-point transform of the sequence with stuff - 1
+// zeros between its samples, which has the same bins (sum_m y[m] W_{N_eff}^{stuff m k} =
+// sum_m y[m] W_{N_eff / stuff}^{m k}).  That is what lets a rank hold whole 8-row blocks - the
+// synthesis' patch height - at 8192 rows over 8 ranks (128-sample transforms).
+__global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, int s, int64_t sub_off, int stuff) {
     extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
     const zf::Geo g = a.g;
     const int NT = 16 * g.R3, sub = threadIdx.x / NT, tid = threadIdx.x - sub * NT, T = NT * s;
@@ -327,7 +332,10 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
         const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2 + sub * sub_off;
         cd v[16];
 #pragma unroll
-        for (int n2 = 0; n2 < 16; ++n2) v[n2] = src[(int64_t)(tid + NT * n2) * a.in_es];
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int n = tid + NT * n2, m = n / stuff;   // (stuff is a power of two)
+            v[n2] = (m * stuff == n) ? src[(int64_t)m * a.in_es] : zf::mk(0.0, 0.0);
+        }
         zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
         __syncthreads();
         zf::gather2(g, tid, v, lds);
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
     }
 }
 
-int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off) {
+int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off, int stuff) {
     FftArgs a;
     a.g.R3 = c.N_eff / 256;
     a.g.n_valid = c.n_valid;
@@ -399,7 +407,7 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>({(size_t)8, (160 * 1024) / bytes, (size_t)(2048 / threads)}));
     int grid = std::min(256 * per_cu, a.chunk * 8);
     grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL(zfft_interleaved_kernel, dim3(grid), dim3(threads), bytes, stream, a, s, sub_off);
+    hipLaunchKernelGGL(zfft_interleaved_kernel, dim3(grid), dim3(threads), bytes, stream, a, s, sub_off, stuff);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

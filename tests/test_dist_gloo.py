@@ -61,7 +61,7 @@ def test_interleaved_rows_cover_everything():
                                   np.full((rows.size // block - 1, block), block * world))
 
 
-@pytest.mark.parametrize('N,G,s,M,j0', [(4096, 1, 2, 512, -256), (3072, 1, 3, 100, 1500), (1024, 4, 1, 64, -32), (2048, 8, 1, 100, -37), (4096, 4, 4, 512, -256),
+@pytest.mark.parametrize('N,G,s,M,j0', [(1024, 2, 8, 64, -32), (8192, 8, 8, 512, -256), (4096, 1, 2, 512, -256), (3072, 1, 3, 100, 1500), (1024, 4, 1, 64, -32), (2048, 8, 1, 100, -37), (4096, 4, 4, 512, -256),
                                         (1024, 2, 2, 1024, -512), (2048, 2, 4, 96, 900)])
 def test_interleaved_shard_column_pass_is_a_short_dft(N, G, s, M, j0):
     """What csrc/farfield.hip's interleaved column pass computes, in NumPy: rank r's partial sum

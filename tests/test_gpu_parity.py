@@ -282,15 +282,18 @@ def test_mirrored_shards_sum_to_whole(ma, nx, ny, mx, my):
 
 
 @pytest.mark.parametrize('N,world,block,M,diameter,na', [
-    (512, 2, 1, 96, 0.2e-3, 0.4), (1024, 2, 2, 96, 0.2e-3, 0.4), (2048, 8, 1, 96, 0.2e-3, 0.4),
-    (2048, 2, 4, 96, 0.2e-3, 0.4), (4096, 4, 4, 96, 0.2e-3, 0.4), (1536, 2, 1, 96, 0.2e-3, 0.4),
-    (8192, 8, 4, 512, 2e-3, 0.94),      # BASELINE configs[2] at size: the 2 mm NA 0.94 lens over 8 ranks
+    (512, 2, 8, 96, 0.2e-3, 0.4), (1024, 2, 8, 96, 0.2e-3, 0.4), (2048, 8, 8, 96, 0.2e-3, 0.4),
+    (2048, 2, 8, 96, 0.2e-3, 0.4), (4096, 4, 8, 96, 0.2e-3, 0.4), (1536, 2, 8, 96, 0.2e-3, 0.4),
+    (16384, 2, 8, 128, 0.2e-3, 0.4),    # 1024-sample short transforms (R3 = 4), eight per workgroup of 512 threads
+    (8192, 8, 8, 512, 2e-3, 0.94),      # BASELINE configs[2] at size: the 2 mm NA 0.94 lens over 8 ranks
 ])
 def test_interleaved_shards_sum_to_whole(ma, N, world, block, M, diameter, na):
     """Blocks of rows dealt round robin over the ranks (metalens_hip.h ml_farfield_interleave_block):
     every rank's shard through its own synthesis and its SHORT column pass on one GPU, the partial
     radiation vectors added up on the host = the whole aperture in one piece, and the incident power
-    likewise.  Shapes cover R3 = 1, 2 (several columns per workgroup), 4 and 3 of the short transform."""
+    likewise.  The block is 8 rows - the synthesis' patch height - wherever the aperture divides;
+    the short transforms then have 32 ... 1024 samples and run zero-stuffed below 256 (stuff 8, 4, 2)
+    or with R3 = 3 (1536 rows) and 4 (16384 rows over 2 ranks)."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if root not in sys.path:
