@@ -440,6 +440,7 @@ struct ZfftCall {
     double alpha[4];
     int alpha_rb, rows, accumulate;
     int lean = 0, lean_per_cu = 1;   // pass 1 only: the <= 128-VGPR kernel, workgroups per CU
+    int passes = 0;                  // > 1: the pass-split kernel (0: the library's default)
 };
 int zfft_split(int N_eff);   // sub-sequences a lattice of N_eff samples is transformed in (0: none)
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,

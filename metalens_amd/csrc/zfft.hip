@@ -252,6 +252,138 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     }
 }
 
+// The same transform in P PASSES over groups of R3P = R3 / P residues.  The R3 residue classes of a
+// row go through stages 1 and 2 independently - only the last stage sums over them - so a workgroup
+// of 16 R3P threads can take them R3P at a time in 1 / P of the LDS, keep the wanted bins' partial
+// Horner sums in registers and combine the passes by Horner in W_N^(R3P k):
+//     X[k] = sum_p W_N^(p R3P k) sum_{n0' < R3P} B[p R3P + n0', k1, k2] (W_N^k)^n0'
+// (tools/zfft_emul.cpp run_passes emulates exactly this on the host).  What it buys is workgroups:
+// 4096 samples = 2 x 35 KB instead of 66 KB -> FOUR two-wave workgroups per CU instead of two
+// four-wave ones, 8192 samples TWO instead of one; the phases of a row (loads, butterflies, LDS
+// exchanges, barriers) of more independent workgroups interleave.  A pass reads whole 128-byte
+// lines: the R3P consecutive samples of a pass are R3P x 16 bytes, R3 x 16 bytes apart.
+// NB = wanted bins per thread (M <= NB x 16 R3P); bins 256 apart share their LDS operands.
+template <int R3P, int P, int NB, int MINW, int PASS>
+__global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs a) {
+    extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
+    cd *lds = reinterpret_cast<cd *>(zfft_lds_raw);
+    zf::Geo gp = a.g, gf = a.g;   // a.g: R3 of the FULL lattice, paddings of the pass geometry
+    gp.R3 = R3P;
+    gf.R3 = R3P * P;
+    constexpr int NT = 16 * R3P;
+    const int tid = threadIdx.x;
+    cd *s_tw = lds + zf::lds_elems(gp);
+    for (int e = tid; e < 256; e += NT) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];
+    const int n1 = tid / R3P, n0 = tid - n1 * R3P;
+    cd tb[4];
+    tb[0] = zf::mk(1.0, 0.0);
+#pragma unroll
+    for (int b = 1; b < 4; ++b) tb[b] = a.tw1[n1 * 16 + b];
+    int kq[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) kq[q] = tid + NT * q < gp.M ? a.kbin[tid + NT * q] : 0;
+    constexpr bool PAIR = (NB % 2 == 0) && (NT * (NB / 2) == 256);
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+    int idx = blockIdx.x >> 3;
+    int row = xcd * a.chunk + idx;   // block-uniform
+    cd v[16];
+    // samples of this thread in pass p: base(p) + 16 R3 n2
+    auto base_of = [&](int p) { return p * R3P + n0 + (R3P * P) * n1; };
+    while (idx < a.chunk && row < a.rows) {
+        const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
+        cd acc[NB];
+#pragma unroll
+        for (int p = P - 1; p >= 0; --p) {
+            // (no register prefetch of the next pass: with four workgroups on a CU another
+            // workgroup's arithmetic covers these loads, and 64 registers more would spill)
+            load_row<0, PASS == 1>(a, gf, row, base_of(p), v);
+            {
+                cd ta[4];
+                ta[0] = tb[0];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) ta[q] = s_tw[(4 * q) * 16 + n1];
+                zf::stage1_regs(gp, tid, v, ta, tb, lds);
+            }
+            __syncthreads();
+            zf::gather2(gp, tid, v, lds);
+            __syncthreads();
+            zf::scatter2(gp, tid, v, lds);
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < (PAIR ? NB / 2 : NB); ++q) {
+                const int oa = tid + NT * q, ob = oa + 256;
+                if (PAIR) {
+                    if (ob < gp.M) {
+                        const cd wa = a.wk[oa], wb = a.wk[ob];
+                        cd xa, xb;
+                        zf::stage3_pair(gp, kq[q], wa, wb, lds, xa, xb);
+                        if (p == P - 1) {
+                            acc[q] = xa;
+                            acc[q + NB / 2] = xb;
+                        } else {
+                            cd ra = wa, rb = wb;   // W_N^(R3P k): R3P is a power of two
+#pragma unroll
+                            for (int t = 1; t < R3P; t <<= 1) {
+                                ra = zf::cmul(ra, ra);
+                                rb = zf::cmul(rb, rb);
+                            }
+                            acc[q] = zf::cmac(acc[q], ra, xa);
+                            acc[q + NB / 2] = zf::cmac(acc[q + NB / 2], rb, xb);
+                        }
+                        continue;
+                    }
+                }
+                if (oa < gp.M) {
+                    const cd wa = a.wk[oa];
+                    const cd xa = zf::stage3(gp, kq[q], wa, lds);
+                    if (p == P - 1) {
+                        acc[q] = xa;
+                    } else {
+                        cd ra = wa;
+#pragma unroll
+                        for (int t = 1; t < R3P; t <<= 1) ra = zf::cmul(ra, ra);
+                        acc[q] = zf::cmac(acc[q], ra, xa);
+                    }
+                }
+                if (PAIR) acc[q + NB / 2] = zf::mk(0.0, 0.0);   // (bin beyond M: never stored)
+            }
+            __syncthreads();   // the next pass' stage 1 overwrites the buffer
+        }
+        cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
+        const double al = a.alpha[row / a.alpha_rb];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            // (with PAIR, acc[q + NB / 2] belongs to bin tid + NT q + 256 = tid + NT (q + NB / 2))
+            const int o = tid + NT * q;
+            if (o < gp.M) {
+                cd x = zf::cmul(acc[q], a.pj[o]);
+                x.x *= al;
+                x.y *= al;
+                cd *d = dst + o * a.out_es;
+                if (a.accumulate) x = zf::cadd(x, *d);
+                *d = x;
+            }
+        }
+        idx = idx_n;
+        row = row_n;
+    }
+}
+
+template <int R3P, int P, int NB, int MINW, int PASS>
+static int launch_pass(hipStream_t stream, const FftArgs &a, int grid, size_t lds_bytes) {
+    auto kern = zfft_pass_kernel<R3P, P, NB, MINW, PASS>;
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        ML_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(16 * R3P), lds_bytes, stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
 // Short transforms (N_eff = 256 or 512: R3 = 1, 2), several rows per workgroup.  The column pass of
 // an INTERLEAVED row shard (farfield.hip transform_impl: rank r of G holds the rows n = s (G m + r)
 // + i) is s transforms of N / (s G) points per column instead of one of N points, and sixteen or
@@ -595,6 +727,34 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds_bytes));
     int grid = std::min(256 * per_cu, a.chunk * 8);
     grid = (grid + 7) / 8 * 8;
+    // pass-split form (zfft_pass_kernel): passes = 2 or 4 groups of residues, where an
+    // instantiation covers the shape
+    {
+        // default: two passes for 8192-sample lattices (one 131 KB workgroup per CU otherwise:
+        // stage 1 0.77 -> 0.71 ms at 8192^2); one pass below - at 4096 samples four two-wave
+        // workgroups per CU measured 12 % SLOWER than two four-wave ones with the register prefetch
+        const int R3 = a.g.R3;
+        // (R3 = 16 as 2 x 8: stage 1 0.201 against 0.178 ms; R3 = 8 as 2 x 4: 0.108 against 0.060)
+        const int P = c.passes > 0 ? c.passes : (R3 == 32 ? 2 : 1);
+        if (P > 1 && R3 % P == 0 && !(c.lean && c.in_es == 1)) {
+            const int R3P = R3 / P, NTp = 16 * R3P, M = a.g.M;
+            FftArgs ap = a;
+            zfft_choose_pads(c.N_eff / P, M, c.j0, &ap.g.pad1, &ap.g.pad2);
+            zf::Geo gp = ap.g;
+            gp.R3 = R3P;
+            const size_t bytes = ((size_t)zf::lds_elems(gp) + 256) * sizeof(cd);
+            const int per = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / bytes));
+            int gridp = std::min(256 * per, a.chunk * 8);
+            gridp = (gridp + 7) / 8 * 8;
+            const bool p1 = c.in_es == 1;
+#define ML_PASS(R, PP, NBB)                                                                   \
+    if (R3P == R && P == PP && M <= NBB * NTp)                                                \
+        return p1 ? launch_pass<R, PP, NBB, 2, 1>(stream, ap, gridp, bytes)                   \
+                  : launch_pass<R, PP, NBB, 2, 2>(stream, ap, gridp, bytes);
+            ML_PASS(16, 2, 2)
+#undef ML_PASS
+        }
+    }
     if (c.lean && c.in_es == 1 && a.sub_s == 1) {
         // co-resident form (banded step): one workgroup per CU is what fits beside the synthesis
         grid = std::min(256 * std::max(1, c.lean_per_cu), a.chunk * 8);

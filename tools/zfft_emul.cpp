@@ -74,6 +74,66 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose) {
     return worst / scale;
 }
 
+// The same transform in P PASSES over groups of R3 / P residues (zfft.hip zfft_pass_kernel): pass p
+// runs the ordinary phases on the samples whose residue n mod R3 lies in [p R3', (p + 1) R3') with the
+// geometry of R3' residues (half or a quarter of the LDS), its last stage sums R3' terms with the
+// FULL lattice's ratio W_N^k, and the passes combine by Horner in W_N^(R3' k):
+//     X[k] = sum_p W_N^(p R3' k) sum_{n0' < R3'} B[p R3' + n0', k1, k2] (W_N^k)^n0'
+static double run_passes(int R3, int P, int n_valid, int M, int j0) {
+    const int R3p = R3 / P, N = 256 * R3, NTp = 16 * R3p;
+    zf::Geo g{R3p, n_valid, M, j0, 0, 0};
+    zf::choose_pads(g);
+    std::vector<cd> in(N), lds(zf::lds_elems(g));
+    srand(R3 * 131 + M + P);
+    for (int n = 0; n < N; ++n)
+        in[n] = n < n_valid ? zf::mk(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5)
+                            : zf::mk(0, 0);
+    auto ratio = [&](long long k) {
+        const long double a = -2 * M_PIl * (((k % N) + N) % N) / N;
+        return zf::mk((double)cosl(a), (double)sinl(a));
+    };
+    std::vector<cd> acc(M, zf::mk(0, 0));
+    std::vector<std::vector<cd>> v(NTp, std::vector<cd>(16));
+    for (int p = P - 1; p >= 0; --p) {
+        for (int t = 0; t < NTp; ++t) {
+            cd ta[4], tb[4];
+            const int n0 = t % R3p, n1 = t / R3p;
+            for (int q = 0; q < 4; ++q) {
+                const long double b = -2 * M_PIl * ((n1 * q) % 256) / 256, a = -2 * M_PIl * ((n1 * 4 * q) % 256) / 256;
+                tb[q] = zf::mk((double)cosl(b), (double)sinl(b));
+                ta[q] = zf::mk((double)cosl(a), (double)sinl(a));
+            }
+            const int base = p * R3p + n0 + R3 * n1;           // the thread's samples: base + 16 R3 n2
+            for (int n2 = 0; n2 < 16; ++n2) v[t][n2] = in[base + 16 * R3 * n2];
+            zf::stage1_regs(g, t, v[t].data(), ta, tb, lds.data());
+        }
+        for (int u = 0; u < NTp; ++u) zf::gather2(g, u, v[u].data(), lds.data());
+        for (int u = 0; u < NTp; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
+        for (int j = 0; j < M; ++j) {
+            long long k = ((long long)j + j0) % N;
+            if (k < 0) k += N;
+            const cd part = zf::stage3(g, (int)k, ratio(k), lds.data());
+            acc[j] = p == P - 1 ? part : zf::cmac(acc[j], ratio(k * R3p), part);
+        }
+    }
+    double worst = 0, scale = 0;
+    for (int j = 0; j < M; ++j) {
+        long double re = 0, im = 0;
+        long long k = ((long long)j + j0) % N;
+        if (k < 0) k += N;
+        for (int n = 0; n < n_valid; ++n) {
+            const long double a = -2 * M_PIl * (((long long)n * k) % N) / N;
+            re += in[n].x * cosl(a) - in[n].y * sinl(a);
+            im += in[n].x * sinl(a) + in[n].y * cosl(a);
+        }
+        worst = fmax(worst, fmax(fabs((double)(re - acc[j].x)), fabs((double)(im - acc[j].y))));
+        scale = fmax(scale, fmax(fabsl(re), fabsl(im)));
+    }
+    printf("passes: R3=%2d P=%d N=%5d valid=%5d M=%4d j0=%5d lds=%6d B  err=%.2e\n", R3, P, N, n_valid, M, j0,
+           zf::lds_elems(g) * 16, worst / scale);
+    return worst / scale;
+}
+
 int main() {
     double worst = 0;
     const int cases[][4] = {{16, 4096, 512, -256}, {8, 2048, 256, -128}, {32, 8192, 512, -256},
@@ -81,6 +141,9 @@ int main() {
                             {16, 4096, 300, 1000}, {1, 256, 64, -32},    {2, 512, 512, -256},
                             {16, 4096, 4096, -2048}, {5, 1280, 77, -3}, {12, 3072, 512, -256}};
     for (auto &c : cases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true));
+    const int pcases[][5] = {{16, 2, 4096, 512, -256}, {32, 2, 8192, 512, -256}, {8, 2, 2048, 256, -128},
+                             {16, 4, 4000, 512, -256}, {32, 4, 8192, 300, 4000}, {12, 2, 3072, 100, -50}};
+    for (auto &c : pcases) worst = fmax(worst, run_passes(c[0], c[1], c[2], c[3], c[4]));
     printf("worst relative error %.3e -> %s\n", worst, worst < 1e-13 ? "OK" : "FAIL");
     return worst < 1e-13 ? 0 : 1;
 }
