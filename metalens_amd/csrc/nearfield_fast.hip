@@ -497,8 +497,11 @@ __device__ __forceinline__ void wave_lds_sync() {
     }
 }
 
+#ifndef ML_NF_WAVES
+#define ML_NF_WAVES 4   // waves per SIMD the single-source kernel is compiled for (A/B builds: 5)
+#endif
 template <bool RECORDS, int NP, int WPB, bool GEN>
-__global__ __launch_bounds__(64 * WPB, NP == 1 ? 4 : 3) void nearfield_field_kernel(const NfArgs a) {
+__global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field_kernel(const NfArgs a) {
     __shared__ double2 s_tab_all[WPB * NF_SLOTS * NF_PITCH];
     double2 *s_tab = s_tab_all + (WPB == 1 ? 0 : (threadIdx.x >> 6) * (NF_SLOTS * NF_PITCH));
     const int lane = threadIdx.x & 63;
