@@ -51,3 +51,16 @@ def test_product_does_not_import_the_oracle():
             if f.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
+
+
+def test_pinned_pool_falls_back_to_pageable_memory():
+    """`_lib.pinned.empty` hands out page-locked arrays where the host can pin them and ordinary
+    NumPy arrays where it cannot (here: no HIP device at all) - a drop-in call must not fail for
+    want of pinnable memory"""
+    import numpy as np
+    from metalens_amd import _lib
+    a = _lib.pinned.empty((3, 5), np.complex128)
+    assert a.shape == (3, 5) and a.dtype == np.complex128
+    a[:] = 1 + 2j
+    assert a.sum() == 15 * (1 + 2j)
+    _lib.pinned.drain()
