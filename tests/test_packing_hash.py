@@ -85,3 +85,64 @@ def test_sweep_groups_consecutive_polarisations_of_one_position():
         sw._group([(0, 0, -float('inf'), 'z')])            # no z-polarised plane wave (nearfield.py:224)
     with pytest.raises(AssertionError):
         sw._group([(0, 0, +1.0, 'x')])                     # the source sits below the lens
+
+
+def test_large_arrays_are_hashed_in_parallel_chunks(monkeypatch):
+    """the chunked hash (used where the host has the cores) is deterministic, sees every byte, and
+    is only taken for arrays beyond the threshold"""
+    monkeypatch.setattr(packing, '_BIG', 1 << 12)
+    monkeypatch.setattr(packing, '_cores', lambda: 64)
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((4097, 3))
+
+    def digest(arr):
+        h = packing._hasher()
+        packing._feed(h, arr)
+        return h.digest()
+
+    d = digest(a)
+    assert d == digest(a.copy())
+    for at in (0, 5000, a.size - 1):
+        b = a.copy()
+        b.flat[at] = np.nextafter(b.flat[at], np.inf)
+        assert digest(b) != d
+    small = rng.standard_normal(16)
+    monkeypatch.setattr(packing, '_cores', lambda: 1)
+    assert digest(small) == digest(small.copy()) and digest(a) != d   # serial form: another digest, same content rule
+
+
+def test_failed_table_upload_leaves_nothing_marked_resident():
+    """an upload that fails part-way must not leave a fingerprint / token that a later call would
+    take for 'these tables are on the GPU' """
+    lens = _lens()
+    gcs = lens['lens_periphery_summary']['gratingcollection_list']
+
+    class Lib:
+        def __init__(self):
+            self.calls = 0
+            self.fail_at = 2
+
+        def ml_upload_table(self, *args):
+            self.calls += 1
+            return 3 if self.calls == self.fail_at else 0
+
+        def ml_last_error(self):
+            return b'simulated failure'
+
+    class Ctx:
+        handle = None
+        tables_token = ('tables', 'something older')
+        tables_fingerprint = b'older'
+
+    ctx = Ctx()
+    ctx.lib = Lib()
+    import pytest
+    with pytest.raises(Exception):
+        packing.upload_tables(ctx, gcs, lens['hexgridset'], 580)
+    assert ctx.tables_token is None and ctx.tables_fingerprint is None
+    ctx.lib.fail_at = -1
+    packing.upload_tables(ctx, gcs, lens['hexgridset'], 580)
+    assert ctx.tables_token is not None and ctx.tables_fingerprint is not None
+    n = ctx.lib.calls
+    packing.upload_tables(ctx, gcs, lens['hexgridset'], 580)      # resident: no further upload
+    assert ctx.lib.calls == n
