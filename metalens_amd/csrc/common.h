@@ -177,6 +177,10 @@ struct ZfftAxis {
     // split > 1 (lattices beyond 8192 samples): `split` launches over interleaved sub-sequences of
     // N_eff / split samples; wk / kbin then belong to the SHORT lattice and pj holds [split][M]
     int split = 1;
+    // passes > 1: ONE launch per row set, the residues of a row in that many groups through half
+    // (a quarter) of the LDS (zfft_pass_kernel); lattices of 8192 < N_eff <= 16384 samples with at
+    // most 1024 wanted bins run this way instead of split in two
+    int passes = 0;
     DevBuf wk, pj, kbin;   // per-bin Horner ratio, origin phasor, reduced bin (zfft.hip FftArgs)
 };
 

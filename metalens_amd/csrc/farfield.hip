@@ -484,7 +484,15 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
     int N_eff = 0, j0 = 0;
     if (!zfft_commensurate(n, step, kappa, u, m, symmetry_tolerance(kappa, p_max, u, m), &N_eff, &j0))
         return ML_OK;
-    const int split = zfft_split(N_eff);
+    int split = zfft_split(N_eff);
+    // 8192 < N_eff <= 16384 with at most 1024 wanted bins: one launch in two residue passes (every
+    // row read once, whole 128-byte lines, no accumulating store) instead of two sub-sequences
+    const int r3 = N_eff / 256;
+    ax.passes = 0;
+    if (r3 > 32 && r3 <= 64 && r3 % 2 == 0 && m <= 1024) {
+        split = 1;
+        ax.passes = 2;
+    }
     ML_TRY(pl.fft_tw1.reserve(256 * 2 * sizeof(double)));
     ML_TRY(ax.wk.reserve((size_t)m * 2 * sizeof(double)));
     ML_TRY(ax.pj.reserve((size_t)split * m * 2 * sizeof(double)));
@@ -902,6 +910,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         if (fft1) {
             ZfftCall c;
             const int split1 = pl.fft_y.split;
+            c.passes = pl.fft_y.passes;
             c.N_eff = pl.fft_y.N_eff / split1;
             c.n_valid = ny;
             c.M = my;
@@ -1062,6 +1071,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         ML_TRY(collapse_stage1());
         ZfftCall c;
         const int split2 = pl.fft_x.split;
+        c.passes = pl.fft_x.passes;
         c.N_eff = pl.fft_x.N_eff / split2;
         c.n_valid = pl.nx_total;
         c.M = mx;

@@ -739,7 +739,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
 #define ML_FFT_PASSES_R32 2
 #endif
         const int P = c.passes > 0 ? c.passes : (R3 == 32 ? ML_FFT_PASSES_R32 : 1);
-        if (P > 1 && R3 % P == 0 && !(c.lean && c.in_es == 1)) {
+        if (P > 1 && R3 % P == 0 && !(c.lean && c.in_es == 1 && R3 <= 32)) {
             const int R3P = R3 / P, NTp = 16 * R3P, M = a.g.M;
             FftArgs ap = a;
             zfft_choose_pads(c.N_eff / P, M, c.j0, &ap.g.pad1, &ap.g.pad2);
@@ -755,9 +755,11 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
         return p1 ? launch_pass<R, PP, NBB, 2, 1>(stream, ap, gridp, bytes)                   \
                   : launch_pass<R, PP, NBB, 2, 2>(stream, ap, gridp, bytes);
             ML_PASS(16, 2, 2)
+            ML_PASS(32, 2, 2)
 #undef ML_PASS
         }
     }
+    ML_REQUIRE(a.g.R3 <= 32, "a lattice of %d samples does not fit one workgroup (%d wanted bins)", c.N_eff, c.M);
     if (c.lean && c.in_es == 1 && a.sub_s == 1) {
         // co-resident form (banded step): one workgroup per CU is what fits beside the synthesis
         grid = std::min(256 * std::max(1, c.lean_per_cu), a.chunk * 8);
