@@ -489,7 +489,7 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
     // row read once, whole 128-byte lines, no accumulating store) instead of two sub-sequences
     const int r3 = N_eff / 256;
     ax.passes = 0;
-    if (r3 > 32 && r3 <= 64 && r3 % 2 == 0 && m <= 1024) {
+    if (r3 == 64 && m <= 1024) {   // (the two-pass kernel exists for groups of 16 and 32 residues)
         split = 1;
         ax.passes = 2;
     }

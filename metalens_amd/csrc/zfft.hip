@@ -274,6 +274,15 @@ __global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs
     const int tid = threadIdx.x;
     cd *s_tw = lds + zf::lds_elems(gp);
     for (int e = tid; e < 256; e += NT) s_tw[(e & 15) * 16 + (e >> 4)] = a.tw1[e];
+    // the passes' Horner ratio W_N^(R3P k) per wanted bin, exact (reduced integer phase), once per
+    // workgroup behind the twiddles (repeated squaring of W_N^k costs 2^5 ulp at R3P = 32)
+    cd *s_wr = s_tw + 256;
+    for (int o = tid; o < gp.M; o += NT) {
+        const long long N = 256ll * R3P * P, r = ((long long)R3P * a.kbin[o]) % N;
+        double sn, cs;
+        sincospi(-2.0 * (double)r / (double)N, &sn, &cs);
+        s_wr[o] = zf::mk(cs, sn);
+    }
     const int n1 = tid / R3P, n0 = tid - n1 * R3P;
     cd tb[4];
     tb[0] = zf::mk(1.0, 0.0);
@@ -322,14 +331,8 @@ __global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs
                             acc[q] = xa;
                             acc[q + NB / 2] = xb;
                         } else {
-                            cd ra = wa, rb = wb;   // W_N^(R3P k): R3P is a power of two
-#pragma unroll
-                            for (int t = 1; t < R3P; t <<= 1) {
-                                ra = zf::cmul(ra, ra);
-                                rb = zf::cmul(rb, rb);
-                            }
-                            acc[q] = zf::cmac(acc[q], ra, xa);
-                            acc[q + NB / 2] = zf::cmac(acc[q + NB / 2], rb, xb);
+                            acc[q] = zf::cmac(acc[q], s_wr[oa], xa);
+                            acc[q + NB / 2] = zf::cmac(acc[q + NB / 2], s_wr[ob], xb);
                         }
                         continue;
                     }
@@ -340,10 +343,7 @@ __global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs
                     if (p == P - 1) {
                         acc[q] = xa;
                     } else {
-                        cd ra = wa;
-#pragma unroll
-                        for (int t = 1; t < R3P; t <<= 1) ra = zf::cmul(ra, ra);
-                        acc[q] = zf::cmac(acc[q], ra, xa);
+                        acc[q] = zf::cmac(acc[q], s_wr[oa], xa);
                     }
                 }
                 if (PAIR) acc[q + NB / 2] = zf::mk(0.0, 0.0);   // (bin beyond M: never stored)
@@ -745,7 +745,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
             zfft_choose_pads(c.N_eff / P, M, c.j0, &ap.g.pad1, &ap.g.pad2);
             zf::Geo gp = ap.g;
             gp.R3 = R3P;
-            const size_t bytes = ((size_t)zf::lds_elems(gp) + 256) * sizeof(cd);
+            const size_t bytes = ((size_t)zf::lds_elems(gp) + 256 + M) * sizeof(cd);   // + twiddles + pass ratios
             const int per = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / bytes));
             int gridp = std::min(256 * per, a.chunk * 8);
             gridp = (gridp + 7) / 8 * 8;
