@@ -23,10 +23,12 @@ import sys
 
 CLASSES = (('nearfield', ('nearfield_field_kernel',)),
            ('stage1', ('zfft_kernel<16, 256, 2, 1', 'zfft_kernel<8, 128, 2, 1', 'zfft_kernel<32, 512, 2, 1',
-                       'zfft_kernel<4, 64, 2, 1', 'zfft_kernel<0, 512, 1, 1', 'zfft_multi_kernel<1>')),
+                       'zfft_kernel<4, 64, 2, 1', 'zfft_kernel<0, 512, 1, 1', 'zfft_multi_kernel<1>',
+                       'zfft_pass_kernel<16, 2, 2, 2, 1>', 'zfft_pass_kernel<32, 2, 2, 2, 1>')),
            ('stage2', ('zfft_kernel<16, 256, 2, 2', 'zfft_kernel<8, 128, 2, 2', 'zfft_kernel<32, 512, 2, 2',
                        'zfft_kernel<4, 64, 2, 2', 'zfft_kernel<0, 512, 1, 2', 'zfft_multi_kernel<2>',
-                       'zfft_interleaved_kernel')),
+                       'zfft_interleaved_kernel', 'zfft_pass_kernel<16, 2, 2, 2, 2>',
+                       'zfft_pass_kernel<32, 2, 2, 2, 2>')),
            ('project', ('project_kernel',)))
 
 

@@ -1,5 +1,6 @@
 #!/bin/bash
-# 8 ranks sharing one GPU through the file communicator: the driver's N=8 weak-scaling run in miniature
+# N ranks sharing one GPU through the file communicator: the driver's N-GPU run (BASELINE configs[2],
+# strong scaling) end to end on a 1-GPU box; the timings mean nothing (file all-reduce, one GPU)
 N=${1:-8}
 export ML_COMM_BACKEND=file WORLD_SIZE=$N MASTER_ADDR=127.0.0.1 MASTER_PORT=29577
 pids=()
