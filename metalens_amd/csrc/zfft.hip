@@ -13,6 +13,18 @@
 // workgroups share a CU and one's loads fly while the other computes.  Rows are handed out so
 // that the workgroups of one XCD walk neighbouring rows (the column pass of stage 2 re-uses
 // cache lines between neighbouring columns).
+//
+// Kernels in this file:
+//   zfft_kernel<R3, ...>       the one-level transform, 256 ... 8192 samples (R3 = 1 ... 32), with a
+//                              register prefetch of the next row; <..., LEAN>: <= 128 VGPRs, no prefetch
+//                              (overlap experiments only); sub_s / sub_i: one of s interleaved sub-
+//                              sequences of a longer lattice (two-level, up to 65536 samples)
+//   zfft_pass_kernel           the same row in two passes over groups of R3 / 2 residues, half the LDS:
+//                              8192-sample lattices (two workgroups per CU instead of one) and 16384-
+//                              sample lattices with <= 1024 wanted bins (one launch, rows read once)
+//   zfft_multi_kernel          256- and 512-sample transforms, four / two rows per 64-thread workgroup
+//   zfft_interleaved_kernel    the column pass of an interleaved multi-GPU row shard: the s short
+//                              transforms of a column in one workgroup, one store per bin
 #include <cmath>
 #include <cstdlib>
 #include <map>
