@@ -313,9 +313,10 @@ int ml_farfield_transform_mirrored_async(ml_ctx *ctx, int row0, int accumulate);
  * crosses the centre disc and the rim alike).  ml_farfield_interleave_block: the block size for
  * the ACTIVE plan and n_ranks - 8 rows, the synthesis' patch height, wherever nx_total divides by
  * 8 n_ranks and the short transforms fit (they run zero-stuffed below 256 samples) - or 0 if the
- * plan cannot be sharded this way (x axis not on the pruned FFT, lattice longer than the aperture,
- * nx_total / (block n_ranks) times 1, 2, 4 or 8 not a multiple of 256): shard by mirrored or
- * contiguous rows then.                                                                         */
+ * plan cannot be sharded this way (x axis not on the pruned FFT, nx_total not a multiple of
+ * block n_ranks, lattice length / (block n_ranks) times 1, 2, 4 or 8 not a multiple of 256): shard
+ * by mirrored or contiguous rows then.  A lattice longer than the aperture (direction grids finer
+ * than the aperture's own) is fine: the rows beyond nx_total are zeros that no rank holds.       */
 int ml_farfield_interleave_block(ml_ctx *ctx, int n_ranks, int *block);
 int ml_farfield_transform_interleaved_async(ml_ctx *ctx, int block, int n_ranks, int rank, int accumulate);
 int ml_farfield_project_async(ml_ctx *ctx, double Z0);

@@ -784,10 +784,13 @@ static int interleave_stuff(int n_sub) {
 }
 
 static int interleave_block(const FarfieldPlan &pl, int n_ranks) {
-    if (!pl.ready || pl.pair_list || !pl.fft_x.ok || pl.fft_x.N_eff != pl.nx_total || n_ranks < 2) return 0;
-    const int N = pl.nx_total;
+    if (!pl.ready || pl.pair_list || !pl.fft_x.ok || n_ranks < 2) return 0;
+    // N = the x axis' lattice (longer than the aperture when the direction grid is finer than the
+    // aperture's own: the rows beyond nx_total are zeros nobody holds); the rows that exist must
+    // deal out evenly
+    const int N = pl.fft_x.N_eff;
     for (int s = 8; s >= 1; s >>= 1) {
-        if (N % (s * n_ranks) != 0) continue;
+        if (N % (s * n_ranks) != 0 || pl.nx_total % (s * n_ranks) != 0) continue;
         const int stuff = interleave_stuff(N / (s * n_ranks));
         if (!stuff) continue;
         const int r3 = N / (s * n_ranks) * stuff / 256;
@@ -1018,23 +1021,24 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         // bins, carried to the full lattice by pj[i][.], into V[3 - f][.][b]
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
         ML_TRY(collapse_stage1());
-        const int s = sh.block, G = sh.n_ranks, N = pl.nx_total;
+        const int s = sh.block, G = sh.n_ranks, N = pl.fft_x.N_eff;
         const int stuff = interleave_stuff(N / (s * G)), Nsub = N / (s * G) * stuff;   // the lattice it runs on
+        const int n_have = pl.nx_total / (s * G);   // samples of each short transform that exist
         const long key[4] = {pl.serial, s, G, sh.rank};
         if (memcmp(key, pl.il_key, sizeof key) != 0) {
             ML_TRY(pl.il_wk.reserve((size_t)mx * 2 * sizeof(double)));
             ML_TRY(pl.il_kbin.reserve((size_t)mx * sizeof(int)));
             ML_TRY(pl.il_pj.reserve((size_t)s * mx * 2 * sizeof(double)));
             ML_TRY(zfft_build_interleave_tables(ctx->stream, pl.il_wk.as<double>(), pl.il_pj.as<double>(),
-                                                pl.il_kbin.as<int>(), mx, pl.fft_x.j0, Nsub, N, N - N / 2,
-                                                s * sh.rank, s));
+                                                pl.il_kbin.as<int>(), mx, pl.fft_x.j0, Nsub, N,
+                                                pl.nx_total - pl.nx_total / 2, s * sh.rank, s));
             zfft_choose_pads(Nsub, mx, pl.fft_x.j0, &pl.il_pad1, &pl.il_pad2);
             memcpy(pl.il_key, key, sizeof key);
         }
         {
             ZfftCall c;
             c.N_eff = Nsub;
-            c.n_valid = Nsub;
+            c.n_valid = n_have;
             c.M = mx;
             c.j0 = pl.fft_x.j0;
             c.pad1 = pl.il_pad1;
@@ -1046,7 +1050,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.in_s2 = 1;
             c.in_es = (int64_t)s * my;
             c.a0 = 0;
-            c.h0 = Nsub;
+            c.h0 = n_have;
             c.a1 = c.h1 = 0;
             c.row_first = nullptr;
             c.rf_mod = 1;

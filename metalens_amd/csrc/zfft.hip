@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             const int n = tid + NT * n2, m = n / stuff;   // (stuff is a power of two)
-            v[n2] = (m * stuff == n) ? src[(int64_t)m * a.in_es] : zf::mk(0.0, 0.0);
+            v[n2] = (m * stuff == n && m < g.n_valid) ? src[(int64_t)m * a.in_es] : zf::mk(0.0, 0.0);
         }
         zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
         __syncthreads();

@@ -61,7 +61,8 @@ def test_interleaved_rows_cover_everything():
                                   np.full((rows.size // block - 1, block), block * world))
 
 
-@pytest.mark.parametrize('N,G,s,M,j0', [(1024, 2, 8, 64, -32), (8192, 8, 8, 512, -256), (4096, 1, 2, 512, -256), (3072, 1, 3, 100, 1500), (1024, 4, 1, 64, -32), (2048, 8, 1, 100, -37), (4096, 4, 4, 512, -256),
+@pytest.mark.parametrize('N,G,s,M,j0', [(1024, 2, 8, 64, -32), (8192, 8, 8, 512, -256), (4096, 1, 2, 512, -256),
+                                        ((1024, 960), 4, 8, 64, -32), ((4096, 4000), 8, 4, 512, -256), (3072, 1, 3, 100, 1500), (1024, 4, 1, 64, -32), (2048, 8, 1, 100, -37), (4096, 4, 4, 512, -256),
                                         (1024, 2, 2, 1024, -512), (2048, 2, 4, 96, 900)])
 def test_interleaved_shard_column_pass_is_a_short_dft(N, G, s, M, j0):
     """What csrc/farfield.hip's interleaved column pass computes, in NumPy: rank r's partial sum
@@ -69,18 +70,20 @@ def test_interleaved_shard_column_pass_is_a_short_dft(N, G, s, M, j0):
     i, an (N / sG)-point DFT over m read at bin k_j mod (N / sG), times exp(2 pi i (c - s r - i) k_j / N)
     (zfft_interleave_tables_kernel).  The ranks' partial sums add up to the whole aperture sum
     sum_n x[n] exp(-2 pi i (n - c) k_j / N)  (nearfield_farfield.py:111-120)."""
+    # (N, rows): a lattice longer than the aperture - the rows beyond `rows` are zeros nobody holds
+    N, n_rows = N if isinstance(N, tuple) else (N, N)
     rng = np.random.default_rng(N + G + s)
-    x = rng.standard_normal(N) + 1j * rng.standard_normal(N)
-    c = N - N // 2
+    x = rng.standard_normal(n_rows) + 1j * rng.standard_normal(n_rows)
+    c = n_rows - n_rows // 2
     k = np.arange(M) + j0
-    whole = np.array([np.sum(x * np.exp(-2j * np.pi * ((np.arange(N) - c) * kj % N) / N)) for kj in k])
+    whole = np.array([np.sum(x * np.exp(-2j * np.pi * ((np.arange(n_rows) - c) * kj % N) / N)) for kj in k])
     Nsub = N // (s * G)
     total = np.zeros(M, dtype=complex)
     for r in range(G):
-        rows = dist.interleaved_rows(N, G, r, s)
+        rows = dist.interleaved_rows(n_rows, G, r, s)
         local = x[rows]                                   # resident order
         for i in range(s):
-            sub = np.fft.fft(local[i::s])                 # Nsub points, sG apart in the aperture
+            sub = np.fft.fft(local[i::s], n=Nsub)         # Nsub points (zero-padded), sG apart in the aperture
             assert sub.size == Nsub
             pj = np.exp(2j * np.pi * (((c - s * r - i) * k) % N) / N)
             total += sub[k % Nsub] * pj

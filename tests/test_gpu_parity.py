@@ -285,6 +285,8 @@ def test_mirrored_shards_sum_to_whole(ma, nx, ny, mx, my):
     (512, 2, 8, 96, 0.2e-3, 0.4), (1024, 2, 8, 96, 0.2e-3, 0.4), (2048, 8, 8, 96, 0.2e-3, 0.4),
     (2048, 2, 8, 96, 0.2e-3, 0.4), (4096, 4, 8, 96, 0.2e-3, 0.4), (1536, 2, 8, 96, 0.2e-3, 0.4),
     (16384, 2, 8, 128, 0.2e-3, 0.4),    # 1024-sample short transforms (R3 = 4), eight per workgroup of 512 threads
+    (4000, 8, 4, 96, 0.2e-3, 0.4),      # 4000 rows on the 4096-sample lattice: 125 of 128 samples per short transform
+    (960, 4, 8, 96, 0.2e-3, 0.4),       # 960 rows on the 1024-sample lattice
     (8192, 8, 8, 512, 2e-3, 0.94),      # BASELINE configs[2] at size: the 2 mm NA 0.94 lens over 8 ranks
 ])
 def test_interleaved_shards_sum_to_whole(ma, N, world, block, M, diameter, na):
@@ -302,7 +304,9 @@ def test_interleaved_shards_sum_to_whole(ma, N, world, block, M, diameter, na):
     from metalens_amd import _lib
     from metalens_amd.pipeline import HotPath
     wl = 580e-9
-    lens, x, u = bench.build_workload(N, M, diameter, na, wl, 1.0)
+    # (directions = bins of the lattice of the next multiple of 256 samples, zero-padded when the
+    # aperture has fewer rows)
+    lens, x, u = bench.build_workload(N, M, diameter, na, wl, N / (-(-N // 256) * 256))
     src = (0.2e-6, -0.1e-6, -lens['source_distance'], 'y')
     args = (src, wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'],
             x, x, u, u)
