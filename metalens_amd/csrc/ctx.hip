@@ -677,6 +677,9 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
             sx[at] = cells[3 * c];
             sy[at] = cells[3 * c + 1];
             sw[at] = (int32_t)cells[3 * c + 2];   // .astype(int): truncation (nearfield.py:367)
+            // (the geometry records carry the type in 11 bits above the ring index)
+            ML_REQUIRE(sw[at] >= 0 && sw[at] < 2048, "centre cell %d has grating index %d: 0 ... 2047 are supported",
+                       c, (int)sw[at]);
             si[at] = c;
         }
         ML_TRY(h2d(ctx, ctx->cell_x, sx.data(), n_cells * sizeof(double)));

@@ -355,7 +355,9 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 // centre cell (:363-367) depend on the sample grid and the layout only.  They are evaluated once
 // per (grid, layout, tie answers) into an 8-byte record per sample (stored patch by patch),
 //     geo_ix = (idx, index into the rotation table)     periphery, idx = ring + 1
-//              (0, slot of the nearest cell; -1: no cells) centre
+//              (cell type << 20, slot of the nearest cell; -1: no cells) centre: the cell's type
+//                  rides in the bits above the ring index (rings < 2^19) - one gather fewer
+//                  behind the record in kernel 2
 //              (n_rings + 1, -)                           outside the lens
 // (the rotated coordinates and the cell centre follow from these with one table load each: a
 // 24-byte record that carried them cost 10 % more per extra 16 bytes - the kernel is sensitive
@@ -397,6 +399,8 @@ __device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, doubl
     }
 }
 
+constexpr int REC_TYPE_SHIFT = 20;   // centre records: cell type above the ring index (rings < 2^19, ctx.hip)
+
 __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs a) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.y * 8 + (lane >> 3);
@@ -407,7 +411,8 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
         sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
         // patch-major: the 64 records of a wave are 512 contiguous bytes
         const size_t rec = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
-        a.geo_ix[rec] = make_int2(idx, aux);
+        const int type = (idx == 0 && aux >= 0) ? a.cwhich[aux] : 0;
+        a.geo_ix[rec] = make_int2(idx | (type << REC_TYPE_SHIFT), aux);
     }
     // patches with at least one sample inside the lens: the field kernel visits only these once
     // the zeros of the others are in place.  A flag per patch here, compacted into the list by
@@ -537,10 +542,11 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             typedef int int2v __attribute__((ext_vector_type(2)));
             const size_t rec = ((size_t)by * a.patches_x + bx) * 64 + lane;   // patch-major
             const int2v ix = reinterpret_cast<const int2v *>(a.geo_ix)[rec];
-            idx = ix.x;
+            idx = ix.x;   // centre: the cell type above bit 20, split off below
             aux = ix.y;
         } else {
             sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
+            if (idx == 0 && aux >= 0) idx = a.cwhich[aux] << REC_TYPE_SHIFT;
         }
     }
     // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
@@ -578,6 +584,8 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
         }
     }
     ML_MARK(1, idx + aux);
+    const int cell_type = idx >> REC_TYPE_SHIFT;
+    idx &= (1 << REC_TYPE_SHIFT) - 1;
     const bool lens = idx <= a.n_rings;
     const bool peri = lens && idx >= 1;
     const double inv_n = recip(p.n_glass);
@@ -640,7 +648,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 // the record holds the cell's slot in the bin-sorted arrays
                 const double2 cc = a.cxy[aux];
                 const double ccx = cc.x, ccy = cc.y;
-                const int which = min(a.cwhich[aux], n2 - 1);
+                const int which = min(cell_type, n2 - 1);
                 // centre table, amplitude-major: [order][i0][i1][4][K]
                 const double2 *tab = a.center_tab;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
