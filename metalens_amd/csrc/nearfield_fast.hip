@@ -222,6 +222,8 @@ __device__ __forceinline__ void locate_uv(const TableDesc &T, double u, double v
     }
 }
 
+constexpr int CENTER_TYPES = 20;   // cell types per staged centre block (the reference's default K, lens_center.py:28)
+
 struct Acc {
     c2 Ex, Ey, Hx, Hy;
 };
@@ -294,22 +296,17 @@ __device__ __forceinline__ void order_common_lds(OrderCommon &oc, const double2 
         }
 }
 
-// amplitudes gathered from global memory (`qs` = distance in double2 between the four amplitudes
-// of one node: the centre table is stored amplitude-major, [order][i0][i1][4][K], so that lanes
-// with different cell types still read neighbouring addresses)
-__device__ __forceinline__ void order_common_gather(OrderCommon &oc, const double2 *node00,
-                                                    int stride0, int stride1, int qs, double t0,
-                                                    double t1) {
+// centre amplitudes from the block staged in LDS, [node c][amplitude q][CENTER_TYPES]: blk points at
+// this lane's cell type
+__device__ __forceinline__ void order_common_types(OrderCommon &oc, const double2 *blk, double t0, double t1) {
     const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
-    const double2 *nodes[4] = {node00, node00 + stride1, node00 + stride0,
-                               node00 + stride0 + stride1};
 #pragma unroll
     for (int q = 0; q < 4; ++q) oc.ar[q] = oc.ai[q] = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double2 v = nodes[c][q * qs];
+            const double2 v = blk[(c * 4 + q) * CENTER_TYPES];
             oc.ar[q] = fma(w[c], v.x, oc.ar[q]);
             oc.ai[q] = fma(w[c], v.y, oc.ai[q]);
         }
@@ -484,6 +481,7 @@ __global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int
 constexpr int NF_SLOTS = 6;                  // distinct (ring, cell) blocks staged per round
 constexpr int NF_CHUNK = 4;                  // orders per staging pass (64 lanes = 4 x 4 x 4)
 constexpr int NF_PITCH = NF_CHUNK * 16 + 1;  // +1: blocks start in different 16-byte bank slots
+static_assert(16 * CENTER_TYPES <= NF_SLOTS * NF_PITCH && CENTER_TYPES % 4 == 0, "the centre block must fit the ring slots");
 
 // WPB = waves (patches) per workgroup.  1: one wave per workgroup (the stand-alone synthesis).
 // 4: the banded step (hotpath.hip), where the transform of the previous band of rows runs beside
@@ -599,24 +597,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     const double *ok = a.ring_ok;
     const double2 *node00 = a.ring_tab;
     bool outside = false;
-    // the ring's header and rotation, requested as soon as the record is there.  Of the 160-byte
-    // header: its first and last 16 bytes (it spans two cache lines, both then on their way) and,
-    // in the single-source kernel, the four entries behind the table cell and the staging
-    // address; the table bounds are read where they are used (batches have no registers to hold
-    // more than the two ends until then)
     double2 h0 = {0, 0}, h8 = h0, cs = {1.0, 0.0}, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
-    if (peri) {
-        const double2 *h = a.ring_hdr + (size_t)(idx - 1) * (RING_HDR / 2);
-        h0 = h[0];
-        h8 = h[8];
-        cs = a.rot_table[aux];
-        if (NP == 1) {   // what the table cell and the staging address need: also on its way now
-            h4 = h[4];
-            h5 = h[5];
-            h6 = h[6];
-            h7 = h[7];
-        }
-    }
     // periphery: order (0, 0)'s phasor x the propagation phasor, exp(i Gx x'), Gy y' (order_phasor)
     // (GEN: the propagation phasor alone in E0, the local coordinates x', y' in xp, yp)
     c2 E0 = {1.0, 0.0}, Ex1 = {1.0, 0.0};
@@ -626,38 +607,45 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
         for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
         ML_MARK(2, Hx_i[0]);
 
-        if (lens && !peri) {
+        if (__ballot(lens && !peri)) {   // wave-uniform: some lane is a centre sample
             // ================= centre: the record holds the nearest hexagonal cell =================
-            // (its table nodes are gathered per lane: the lanes of a patch sit in ~50 cells of up to K
-            // types; staging the wave's table cell through LDS like the ring blocks was measured
-            // twice - per workgroup in round 1, per wave and per order in round 3 - and cost 3-4 %:
-            // the gathers are L1 hits behind the same dependent record load either way)
+            // The lanes of a patch sit in ~50 cells of up to K types, and (the direction of incidence
+            // hardly changes over 2 um) almost always in ONE (ux, uy) cell of the centre table.  Per
+            // order the wave stages that cell's four nodes x four amplitudes x K types through LDS
+            // and every lane picks its type's sixteen values from there: per lane gathered from
+            // global memory they are 16 KB per wave and order through the CU's L1, which is what
+            // bounded a centre wave (phase timers: 5 000 cycles per order against 1 600 for a
+            // periphery order).  A round serves the lanes of one (table cell, group of CENTER_TYPES
+            // types); a wave that straddles a table cell, or a table of more types, takes more rounds.
+            const bool cen = lens && !peri && aux >= 0;
             Acc acc[NP];
 #pragma unroll
             for (int m = 0; m < NP; ++m) acc[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-            if (aux >= 0) {
-                const TableDesc &T = a.center_desc;
-                int i0, i1;
-                double c0, c1;
-                locate_uv(T, ux, uy, i0, c0, i1, c1);
-                const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3];
-                const bool out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
-                const int n2 = T.n2;
-                const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
-                const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
+            const TableDesc &T = a.center_desc;
+            int i0, i1;
+            double c0, c1;
+            locate_uv(T, ux, uy, i0, c0, i1, c1);   // (every lane: ux, uy are defined for all of them)
+            const double b0 = T.bounds[0], b1 = T.bounds[1], b2 = T.bounds[2], b3 = T.bounds[3];
+            const bool out_c = (int)(ux < b0) | (int)(ux > b1) | (int)(uy < b2) | (int)(uy > b3);
+            const int n2 = T.n2;
+            const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
+            const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
+            const int which = min(cell_type, n2 - 1);
+            double ccx = 0.0, ccy = 0.0, ox_ = 0.0, oy_ = 0.0;
+            c2 E0 = {1.0, 0.0}, Exc = {1.0, 0.0};
+            if (cen) {
                 // the record holds the cell's slot in the bin-sorted arrays
                 const double2 cc = a.cxy[aux];
-                const double ccx = cc.x, ccy = cc.y;
-                const int which = min(cell_type, n2 - 1);
-                // centre table, amplitude-major: [order][i0][i1][4][K]
-                const double2 *tab = a.center_tab;
+                ccx = cc.x;
+                ccy = cc.y;
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
-                const double ox_ = x - ccx, oy_ = y - ccy;
+                ox_ = x - ccx;
+                oy_ = y - ccy;
+                ML_MARK(3, ox_ + oy_);   // (centre waves: the cell centre has arrived)
                 // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
                 // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
                 // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
                 // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
-                c2 E0 = {1.0, 0.0}, Exc = {1.0, 0.0};
                 if (!GEN) {
                     double a0 = (p.kvac * ux) * ox_ + (p.kvac * uy) * oy_;
                     int kq = 0;
@@ -671,26 +659,70 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                     sincos_cw_q(a0, kq, E0.i, E0.r);
                     sincos_cw(T.center_g[0] * ox_, Exc.i, Exc.r);
                 }
-                for (int o = 0; o < T.n_orders; ++o) {
-                    const double kx = fma(p.kvac, ux, T.center_kx[o]);
-                    const double ky = fma(p.kvac, uy, T.center_ky[o]);
-                    const double kt2 = fma(kx, kx, ky * ky);
-                    if (kt2 <= p.kvac2) {
-                        if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
-                        OrderCommon oc;
-                        order_common_gather(oc, tab + o * st_o + (size_t)i0 * st0 + i1 * st1 + which,
-                                            st0, st1, n2, c0, c1);
-                        if (GEN)
-                            order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                              kx * ox_ + ky * oy_);
-                        else
-                            order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                          order_phasor(E0, Exc, T.center_ox[o]));
-                        // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+                ML_MARK(4, E0.r + Exc.i);   // (centre waves: phasors done, order loop next)
+            }
+            // lane (row, column group) of the staged block [node c][amplitude q][CENTER_TYPES]:
+            // row c * 4 + q = lane / 4, columns lane % 4 + 4 m - a quad of lanes reads 64 contiguous
+            // bytes of the amplitude-major table [order][i0][i1][4][K]
+            const int srow = lane >> 2, scol = lane & 3;
+            const int row_off = (srow >> 3) * st0 + ((srow >> 2) & 1) * st1 + (srow & 3) * n2;
+            unsigned long long todo = __ballot(cen);
+            while (todo) {
+                const int l0 = __ffsll((long long)todo) - 1;
+                const int i0u = __builtin_amdgcn_readlane(i0, l0), i1u = __builtin_amdgcn_readlane(i1, l0);
+                const int tb = __builtin_amdgcn_readlane(which, l0) / CENTER_TYPES * CENTER_TYPES;
+                const bool mine = cen && i0 == i0u && i1 == i1u && which >= tb && which < tb + CENTER_TYPES;
+                todo &= ~__ballot(mine);
+                const int kc = min(CENTER_TYPES, n2 - tb);
+                // (single source, simple orders: the next order's block is requested before this
+                // order's arithmetic and waits in registers - the other instantiations have none to
+                // spare - and replaces the block in LDS once every lane is done with this one)
+                constexpr bool AHEAD = NP == 1 && !GEN && WPB == 1;
+                const double2 *src = a.center_tab + (size_t)i0u * st0 + (size_t)i1u * st1 + tb + row_off + scol;
+                double2 val[CENTER_TYPES / 4];
+                if (AHEAD) {
 #pragma unroll
-                        for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
-                    }
+                    for (int m = 0; m < CENTER_TYPES / 4; ++m)
+                        val[m] = scol + 4 * m < kc ? src[4 * m] : make_double2(0.0, 0.0);
                 }
+                for (int o = 0; o < T.n_orders; ++o) {   // wave-uniform
+                    if (!AHEAD) {
+#pragma unroll
+                        for (int m = 0; m < CENTER_TYPES / 4; ++m)
+                            val[m] = scol + 4 * m < kc ? src[o * st_o + 4 * m] : make_double2(0.0, 0.0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < CENTER_TYPES / 4; ++m)
+                        s_tab[srow * CENTER_TYPES + scol + 4 * m] = val[m];
+                    wave_lds_sync<WPB>();
+                    if (AHEAD && o + 1 < T.n_orders) {
+#pragma unroll
+                        for (int m = 0; m < CENTER_TYPES / 4; ++m)
+                            val[m] = scol + 4 * m < kc ? src[(o + 1) * st_o + 4 * m] : make_double2(0.0, 0.0);
+                    }
+                    if (mine) {
+                        const double kx = fma(p.kvac, ux, T.center_kx[o]);
+                        const double ky = fma(p.kvac, uy, T.center_ky[o]);
+                        const double kt2 = fma(kx, kx, ky * ky);
+                        if (kt2 <= p.kvac2) {
+                            if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
+                            OrderCommon oc;
+                            order_common_types(oc, s_tab + (which - tb), c0, c1);
+                            if (GEN)
+                                order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                                  kx * ox_ + ky * oy_);
+                            else
+                                order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                              order_phasor(E0, Exc, T.center_ox[o]));
+                            // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+#pragma unroll
+                            for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
+                        }
+                    }
+                    wave_lds_sync<WPB>();   // the next order (or round) overwrites the block
+                }
+            }
+            if (cen) {
                 // input modulation of the far-field plan's stage 1, applied here for free (NfArgs);
                 // GEN: and the phase-critical propagation from the cell centre (nearfield.py:453-461)
                 c2 e = {1.0, 0.0};
@@ -716,9 +748,11 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                     }
                 }
             }
+            if (lens && !peri) {
 #pragma unroll
-            for (int m = 0; m < NP; ++m)
-                store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
+                for (int m = 0; m < NP; ++m)
+                    store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
+            }
         }
         if (inb && !lens && !a.outside_is_zero) {
             const c2 zero = {0.0, 0.0};
@@ -726,6 +760,25 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
         }
 
+        // the ring's header and rotation, requested as soon as the record is there
+        // (behind the centre section, which a wave without centre samples skips: while it runs the
+        // registers are the centre's).  Of the 160-byte
+        // header: its first and last 16 bytes (it spans two cache lines, both then on their way) and,
+        // in the single-source kernel, the four entries behind the table cell and the staging
+        // address; the table bounds are read where they are used (batches have no registers to hold
+        // more than the two ends until then)
+        if (peri) {
+            const double2 *h = a.ring_hdr + (size_t)(idx - 1) * (RING_HDR / 2);
+            h0 = h[0];
+            h8 = h[8];
+            cs = a.rot_table[aux];
+            if (NP == 1) {   // what the table cell and the staging address need: also on its way now
+                h4 = h[4];
+                h5 = h[5];
+                h6 = h[6];
+                h7 = h[7];
+            }
+        }
         // ================= periphery: set-up =================
         if (peri) {
             const int ring = idx - 1;

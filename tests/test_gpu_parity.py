@@ -1192,6 +1192,65 @@ def test_general_order_sets_vs_oracle(ma, per, cen, pol, sz):
         assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
 
 
+@pytest.mark.parametrize('entries,pols', [(12, 'x'), (27, 'y'), (45, 'xyz'), (5, 'z')])
+def test_centre_blocks_many_types_and_straddling_waves(ma, entries, pols):
+    """The centre section of the field kernel stages one table cell's nodes x amplitudes x (up to 20)
+    cell types per order through LDS and serves a wave in rounds, one per (table cell, group of 20
+    types) among its lanes.  Tables of 27 and 45 types (two and three groups), a source just off the
+    window's middle (ux = 0 and uy = 0 - table nodes - cross the window, so waves straddle table
+    cells) and the three-polarisation batch, against the oracle; every type must occur."""
+    from oracle import nearfield_oracle
+    import math
+    from metalens_amd import layout, synthetic
+    wl = 580e-9
+    lens = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design,
+                               radius=40e-6, numerical_aperture=0.4, wavelength=wl,
+                               switch_angle=9 * math.pi / 180, num_gratings=20, num_entries=entries,
+                               design_kwargs={'wavelength': wl})
+    cells = np.array(lens['lens_center_summary'], dtype=float)
+    # spread the cell types over the whole table (the design uses what the phase profile needs)
+    rng = np.random.default_rng(entries)
+    cells[:, 2] = rng.integers(0, entries, size=len(cells))
+    assert np.unique(cells[:, 2]).size == entries
+    pitch = wl / 2.2
+    # (the corners of the window lie beyond the switch radius: waves with centre AND ring samples)
+    x = 0.4e-6 + (np.arange(120) - 60) * pitch
+    y = -0.3e-6 + (np.arange(112) - 56) * pitch
+    assert math.hypot(x[0], y[0]) > lens['r_for_switch'] > 0.5 * abs(x[0])
+    common = dict(wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                  lens_center_summary=cells, hexgridset=lens['hexgridset'], x_pts=x, y_pts=y)
+    src = dict(source_x=0.52e-6, source_y=-0.21e-6, source_z=-lens['source_distance'])
+    if len(pols) == 1:
+        got = {pols: ma.build_nearfield(source_pol=pols, **src, **common)}
+    else:
+        # the batch kernel (x, y, z in one pass), fields read back member by member
+        from metalens_amd import _lib
+        from metalens_amd.nearfield import nearfield_params
+        ctx = _lib.default_context()
+        first = ma.build_nearfield(source_pol=pols[0], ctx=ctx, **src, **common)   # uploads tables and layout
+        params = (_lib.NearfieldParams * len(pols))()
+        for m, pol in enumerate(pols):
+            params[m] = nearfield_params(src['source_x'], src['source_y'], src['source_z'], pol, wl, first[7],
+                                         1e-30, ma.constants.c0, ma.constants.Z0)
+        xs, ys = _lib.f64(x), _lib.f64(y)
+        _lib.check(ctx.lib.ml_nearfield_batch_async(ctx.handle, params, len(pols), _lib.dptr(xs), xs.size,
+                                                    _lib.dptr(ys), ys.size))
+        got = {}
+        for m, pol in enumerate(pols):
+            _lib.check(ctx.lib.ml_fields_select(ctx.handle, m))
+            F = [np.empty((x.size, y.size), dtype=np.complex128) for _ in range(4)]
+            _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(f) for f in F]))
+            got[pol] = F
+        _lib.check(ctx.lib.ml_fields_select(ctx.handle, 0))
+    for pol, g in got.items():
+        want = nearfield_oracle.build_nearfield(source_pol=pol, **src, **common)
+        scale = max(np.abs(w).max() for w in want[:4])
+        assert scale > 0
+        for gf, w in zip(g[:4], want[:4]):
+            assert int(np.count_nonzero((gf == 0) != (w == 0))) == 0
+            assert np.abs(gf - w).max() <= TOL * scale
+
+
 @pytest.mark.parametrize('seed', [5, 6])
 def test_random_windows_sweep(ma, seed):
     """random windows, sources and polarisations on two lenses against the oracle

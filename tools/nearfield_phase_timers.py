@@ -29,7 +29,7 @@ buf = np.zeros((n_waves, 10), dtype=np.uint64)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 assert lib.ml_debug_phase_dump(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_waves)) == 0
 t = buf[:, :9].astype(np.int64)
-names = ['records arrive', 'incident field + power', 'ring set-up, locate', 'staging (loads, LDS, barrier)',
+names = ['records arrive', 'incident field + power', 'centre: cell centre arrives', 'periphery: set-up + staging (loads, LDS, barrier) / centre: phasors',
          'orders', 'post (sincos, rotate)', 'stores issued', 'stores drained']
 by = np.arange(n_waves) // nb
 bx = np.arange(n_waves) % nb
