@@ -117,7 +117,8 @@ struct TableDesc {
 // Everything the field kernel needs to know about a periphery sample's RING, in one 160-byte
 // record (one round trip instead of ring -> collection -> table descriptor):
 //   [0] r_center  [1] period  [2..7] table bounds  [8..13] uniform (ux, uy) axes: first, step,
-//   1/step per axis  [14] (n0, n1)  [15] (n_orders, flags: bit 0 = axes uniform)
+//   1/step per axis  [14] (n0, n1)  [15] (n_orders, flags: bit 0 = axes uniform,
+//   bit 1 = period outside the table's range, from bit 2 two bits per order = ox + 1)
 //   [16] offset of the ring's table in ring_tab  [17] (offset in ring_ok, collection)
 //   [18] 2 pi / period  [19] 2 pi / lateral period (the reciprocal-lattice steps of the ring)
 // ring_ok holds 4 doubles per order of the ring's table: ox 2 pi / period, oy 2 pi / lateral, ox, oy
@@ -288,6 +289,7 @@ struct ml_ctx {
     ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
     bool simple_orders = false;   // every present table: ox in {-1, 0, 1}, oy = 0 (refresh_table_desc)
+    double ring_bounds_all[4] = {0, 0, 0, 0};   // intersection of the ring tables' (ux', uy') bounds (NfArgs)
 
     // layout
     bool have_layout = false;

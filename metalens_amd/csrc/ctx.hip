@@ -78,6 +78,7 @@ static int refresh_table_desc(ml_ctx *ctx) {
             const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI)), oy = std::lrint(t.h_order_k[2 * o + 1] / (2 * M_PI));
             if (ox < -1 || ox > 1 || oy != 0) ctx->simple_orders = false;
         }
+        if (t.n_orders > 15) ctx->simple_orders = false;   // (the ring headers hold 15 order codes)
         TableDesc &d = h[s];
         d.axis0 = t.axis0.as<double>();
         d.axis1 = t.axis1.as<double>();
@@ -193,6 +194,8 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     }
     // per-ring headers (common.h RING_HDR)
     std::vector<double> hdr((size_t)ctx->n_rings * RING_HDR, 0.0);
+    ctx->ring_bounds_all[0] = ctx->ring_bounds_all[2] = -INFINITY;
+    ctx->ring_bounds_all[1] = ctx->ring_bounds_all[3] = INFINITY;
     for (int r = 0; r < ctx->n_rings; ++r) {
         const int slot = ctx->h_ring_gc[r];
         const TableSlot &t = ctx->slots[slot];
@@ -204,8 +207,24 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         q[0] = ctx->h_ring_rc[r];
         q[1] = ctx->h_ring_period[r];
         for (int k = 0; k < 6; ++k) q[2 + k] = t.bounds[k];
+        for (int k = 0; k < 4; k += 2) {   // a NaN bound leaves the range empty: every sample then reads its own
+            ctx->ring_bounds_all[k] = t.bounds[k] >= ctx->ring_bounds_all[k] ? t.bounds[k]
+                                      : t.bounds[k] == t.bounds[k] ? ctx->ring_bounds_all[k] : INFINITY;
+            ctx->ring_bounds_all[k + 1] = t.bounds[k + 1] <= ctx->ring_bounds_all[k + 1] ? t.bounds[k + 1]
+                                          : t.bounds[k + 1] == t.bounds[k + 1] ? ctx->ring_bounds_all[k + 1] : -INFINITY;
+        }
         for (int k = 0; k < 6; ++k) q[8 + k] = d.uni_ax[k];
-        const int32_t i14[2] = {t.n0, t.n1}, i15[2] = {t.n_orders, d.uniform ? 1 : 0};
+        // flags: bit 0 = axes uniform; bit 1 = the ring's period lies outside its table's period range
+        // (nearfield.py:302-305: then every evaluated sample of the ring reports); from bit 2, two
+        // bits per order = ox + 1 for the first 15 orders (what the simple-order kernels read
+        // instead of the order list: ox in {-1, 0, 1}, oy = 0)
+        int32_t flags = d.uniform ? 1 : 0;
+        if (ctx->h_ring_period[r] < t.bounds[4] || ctx->h_ring_period[r] > t.bounds[5]) flags |= 2;
+        for (int o = 0; o < std::min(t.n_orders, 15); ++o) {
+            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
+            flags |= (int32_t)((ox + 1) & 3) << (2 + 2 * o);
+        }
+        const int32_t i14[2] = {t.n0, t.n1}, i15[2] = {t.n_orders, flags};
         const int32_t i17[2] = {ok_off[r], slot};
         memcpy(q + 14, i14, 8);
         memcpy(q + 15, i15, 8);

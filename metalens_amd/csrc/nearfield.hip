@@ -161,6 +161,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.n_active = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;
+    for (int k = 0; k < 4; ++k) a.ring_bounds_all[k] = ctx->ring_bounds_all[k];
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
     a.row_first = ctx->row_first.as<int>();

@@ -86,6 +86,9 @@ struct NfArgs {
     // every table of the lens holds orders ox = -1, 0, 1 with oy = 0 only: the kernels that build
     // an order's phasor by one product run (nearfield_fast.hip order_phasor), else the general ones
     int simple_orders;
+    // the (ux', uy') range every ring table covers (intersection of their bounds: lo0, hi0, lo1, hi1);
+    // a sample inside it cannot trip a table bound, and only the others read their ring's own bounds
+    double ring_bounds_all[4];
     // outputs
     // outside_is_zero: the samples outside the lens already hold zeros in `fields` (the previous
     // launch wrote them for the same grid, layout and buffer) and are not stored again

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     const double inv_n = recip(p.n_glass);
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
-    int key = -1, n_orders = 0, stride0 = 0, stride_o = 0;
+    int key = -1, n_orders = 0, stride0 = 0, stride_o = 0, order_codes = 0;
+    double Gx = 0.0;   // simple orders: 2 pi / period; order o adds (code_o - 1) Gx to k ux' (codes: ring header flags)
     double uxp = 0.0, uyp = 0.0, t0 = 0.0, t1 = 0.0, xp = 0.0, yp = 0.0;
     double Hw_x[NP], Hw_y[NP];
 #pragma unroll
@@ -785,7 +786,6 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             // everything that depends on the ring alone comes from ONE record (common.h RING_HDR),
             // whose two cache lines were requested above
             const double2 *h = a.ring_hdr + (size_t)ring * (RING_HDR / 2);
-            const double2 h1 = h[1], h2 = h[2], h3 = h[3];
             if (NP > 1) {
                 h4 = h[4];
                 h5 = h[5];
@@ -830,8 +830,15 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             node00 = a.ring_tab + tab_off + i0 * stride0 + i1 * 4;
             // the table-bound tests do not depend on the order: evaluate them once, and only take
             // the reporting path (per order, in the reference's check order) on failure
-            outside = (int)(uxp < h1.x) | (int)(uxp > h1.y) | (int)(uyp < h2.x) | (int)(uyp > h2.y) |
-                      (int)(period < h3.x) | (int)(period > h3.y);
+            // (a sample inside the range EVERY ring table covers, on a ring whose period its table
+            // covers - flags bit 1 - cannot fail; only the others read their ring's own bounds)
+            outside = (int)(uxp < a.ring_bounds_all[0]) | (int)(uxp > a.ring_bounds_all[1]) |
+                      (int)(uyp < a.ring_bounds_all[2]) | (int)(uyp > a.ring_bounds_all[3]) | ((flags >> 1) & 1);
+            if (outside) {
+                const double2 h1 = h[1], h2 = h[2], h3 = h[3];
+                outside = (int)(uxp < h1.x) | (int)(uxp > h1.y) | (int)(uyp < h2.x) | (int)(uyp > h2.y) |
+                          (int)(period < h3.x) | (int)(period > h3.y);
+            }
             // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
             // block per lane (still correct, just not shared)
             key = (n0 > 64 || n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
@@ -853,7 +860,9 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                     a0 = r + a0;
                 }
                 sincos_cw_q(a0, kq, E0.i, E0.r);
-                sincos_cw(h[9].x * xp, Ex1.i, Ex1.r);   // 2 pi / period: header slot 18
+                Gx = h[9].x;   // 2 pi / period: header slot 18
+                order_codes = flags >> 2;
+                sincos_cw(Gx * xp, Ex1.i, Ex1.r);
             } else if (!p.plane_wave) {
                 // GEN: the propagation phasor on its own; every order evaluates its own argument
                 const double rcen = h0.x;
@@ -925,13 +934,22 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
                 // the order's grating vector one iteration ahead: its load (an L1 hit) is in
                 // flight during the previous order's arithmetic instead of in front of its own
+                // (general orders only; the simple-order kernels build the grating vector from the
+                // ring header: ox from its order codes, 2 pi / period - the same rounding as the
+                // reference's ox*2*pi/grating_period for ox = -1, 0, 1 - and oy = 0)
                 typedef double double2v __attribute__((ext_vector_type(2)));
                 const double2v *ok2 = reinterpret_cast<const double2v *>(ok);   // per order: (kx, ky), (ox, oy)
-                double2v k_next = NP == 1 ? ok2[2 * o0] : (double2v){0.0, 0.0};
+                double2v k_next = (GEN && NP == 1) ? ok2[2 * o0] : (double2v){0.0, 0.0};
                 for (int o = o0; o < o1; ++o) {
-                    const double2v k_here = NP == 1 ? k_next : ok2[2 * o];
-                    const double2v ord = GEN ? (double2v){0.0, 0.0} : ok2[2 * o + 1];
-                    if (NP == 1) k_next = ok2[2 * min(o + 1, o1 - 1)];
+                    double2v k_here;
+                    int ox_here = 0;
+                    if (GEN) {
+                        k_here = NP == 1 ? k_next : ok2[2 * o];
+                        if (NP == 1) k_next = ok2[2 * min(o + 1, o1 - 1)];
+                    } else {
+                        ox_here = ((order_codes >> (2 * o)) & 3) - 1;
+                        k_here = (double2v){(double)ox_here * Gx, 0.0};
+                    }
                     const double kxp = fma(p.kvac, uxp, k_here.x);
                     const double kyp = fma(p.kvac, uyp, k_here.y);
                     const double kt2 = fma(kxp, kxp, kyp * kyp);
@@ -947,7 +965,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                                               kxp * xp + kyp * yp);
                         else
                             order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                          order_phasor(E0, Ex1, (int)ord.x));
+                                          order_phasor(E0, Ex1, ox_here));
 #pragma unroll
                         for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
                     }
