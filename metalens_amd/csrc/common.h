@@ -114,15 +114,21 @@ struct TableDesc {
     double ax0[PACKED_AXIS], inv0[PACKED_AXIS], ax1[PACKED_AXIS], inv1[PACKED_AXIS];
 };
 
-// Everything the field kernel needs to know about a periphery sample's RING, in one 160-byte
-// record (one round trip instead of ring -> collection -> table descriptor):
-//   [0] r_center  [1] period  [2..7] table bounds  [8..13] uniform (ux, uy) axes: first, step,
-//   1/step per axis  [14] (n0, n1)  [15] (n_orders, flags: bit 0 = axes uniform,
-//   bit 1 = period outside the table's range, from bit 2 two bits per order = ox + 1)
-//   [16] offset of the ring's table in ring_tab  [17] (offset in ring_ok, collection)
-//   [18] 2 pi / period  [19] 2 pi / lateral period (the reciprocal-lattice steps of the ring)
-// ring_ok holds 4 doubles per order of the ring's table: ox 2 pi / period, oy 2 pi / lateral, ox, oy
-constexpr int RING_HDR = 20;
+// What the field kernel needs to know about a periphery sample's RING: 32 bytes per ring
+// (ring_rec: two 16-byte loads per lane),
+//   r_center, period | 2 pi / period, bits: offset of the ring's table in ring_tab (bits 0-39),
+//   bit 40 = the period lies outside its table's period range (nearfield.py:302-305)
+// and about the ring's GRATING COLLECTION, which almost every wave shares among all its lanes: a
+// CollDesc per collection IN USE (dense numbering, ml_upload_layout), held in the kernel arguments
+// so that a wave reads it with scalar loads - the geometry records carry the dense number.
+// ring_ok holds 4 doubles per order of the ring's table (general order sets only):
+//   ox 2 pi / period, oy 2 pi / lateral, ox, oy;  ring_ok_off[ring] = the ring's offset in it.
+constexpr int MAX_RING_COLLS = 16;   // grating collections in use by the rings of one lens
+struct CollDesc {
+    double uni_ax[6];   // uniform (ux', uy') axes: first, step, 1 / step per axis (flags bit 0)
+    int n0, n1, n_orders;
+    int flags;          // bit 0 = axes uniform; from bit 2, two bits per order = ox + 1 (simple order sets)
+};
 
 struct TableSlot {
     bool present = false;
@@ -298,7 +304,10 @@ struct ml_ctx {
     std::vector<int32_t> h_ring_gc;
     ml::DevBuf ring_boundaries, ring_r_center, ring_period, ring_dphi, ring_lateral, ring_gc;
     ml::DevBuf rot_table, tie_table, ring_rot_center, ring_rot_half;
-    ml::DevBuf ring_hdr;                                       // RING_HDR doubles per ring, see ctx.hip
+    ml::DevBuf ring_rec, ring_coll;                            // 4 doubles per ring (above); dense collection number per ring
+    int n_colls = 0;
+    int32_t coll_slot[ml::MAX_RING_COLLS] = {0};               // dense collection number -> slot
+    ml::CollDesc h_coll[ml::MAX_RING_COLLS] = {};
     std::vector<ml::TableDesc> h_table_desc;                   // host copy of table_desc
     ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables
     ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis

@@ -192,48 +192,48 @@ static int refresh_ring_locations(ml_ctx *ctx) {
             ok[ok_off[r] + 4 * o + 3] = std::rint(t.h_order_k[2 * o + 1] / (2 * M_PI));   // oy
         }
     }
-    // per-ring headers (common.h RING_HDR)
-    std::vector<double> hdr((size_t)ctx->n_rings * RING_HDR, 0.0);
+    // per-ring records and per-collection descriptors (common.h ring_rec, CollDesc)
+    std::vector<double> rec((size_t)ctx->n_rings * 4, 0.0);
     ctx->ring_bounds_all[0] = ctx->ring_bounds_all[2] = -INFINITY;
     ctx->ring_bounds_all[1] = ctx->ring_bounds_all[3] = INFINITY;
-    for (int r = 0; r < ctx->n_rings; ++r) {
-        const int slot = ctx->h_ring_gc[r];
+    for (int c = 0; c < ctx->n_colls; ++c) {
+        const int slot = ctx->coll_slot[c];
         const TableSlot &t = ctx->slots[slot];
         const TableDesc &d = ctx->h_table_desc[slot];
         // the field kernel addresses a ring's table with 24-bit products (nearfield_fast.hip)
         ML_REQUIRE((long long)t.n0 * t.n1 * 4 < (1ll << 24), "table of collection %d is too large (%d x %d nodes)",
                    slot, t.n0, t.n1);
-        double *q = hdr.data() + (size_t)r * RING_HDR;
-        q[0] = ctx->h_ring_rc[r];
-        q[1] = ctx->h_ring_period[r];
-        for (int k = 0; k < 6; ++k) q[2 + k] = t.bounds[k];
+        CollDesc &C = ctx->h_coll[c];
+        for (int k = 0; k < 6; ++k) C.uni_ax[k] = d.uni_ax[k];
+        C.n0 = t.n0;
+        C.n1 = t.n1;
+        C.n_orders = t.n_orders;
+        C.flags = d.uniform ? 1 : 0;
+        for (int o = 0; o < std::min(t.n_orders, 15); ++o) {
+            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
+            C.flags |= (int32_t)((ox + 1) & 3) << (2 + 2 * o);
+        }
         for (int k = 0; k < 4; k += 2) {   // a NaN bound leaves the range empty: every sample then reads its own
             ctx->ring_bounds_all[k] = t.bounds[k] >= ctx->ring_bounds_all[k] ? t.bounds[k]
                                       : t.bounds[k] == t.bounds[k] ? ctx->ring_bounds_all[k] : INFINITY;
             ctx->ring_bounds_all[k + 1] = t.bounds[k + 1] <= ctx->ring_bounds_all[k + 1] ? t.bounds[k + 1]
                                           : t.bounds[k + 1] == t.bounds[k + 1] ? ctx->ring_bounds_all[k + 1] : -INFINITY;
         }
-        for (int k = 0; k < 6; ++k) q[8 + k] = d.uni_ax[k];
-        // flags: bit 0 = axes uniform; bit 1 = the ring's period lies outside its table's period range
-        // (nearfield.py:302-305: then every evaluated sample of the ring reports); from bit 2, two
-        // bits per order = ox + 1 for the first 15 orders (what the simple-order kernels read
-        // instead of the order list: ox in {-1, 0, 1}, oy = 0)
-        int32_t flags = d.uniform ? 1 : 0;
-        if (ctx->h_ring_period[r] < t.bounds[4] || ctx->h_ring_period[r] > t.bounds[5]) flags |= 2;
-        for (int o = 0; o < std::min(t.n_orders, 15); ++o) {
-            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
-            flags |= (int32_t)((ox + 1) & 3) << (2 + 2 * o);
-        }
-        const int32_t i14[2] = {t.n0, t.n1}, i15[2] = {t.n_orders, flags};
-        const int32_t i17[2] = {ok_off[r], slot};
-        memcpy(q + 14, i14, 8);
-        memcpy(q + 15, i15, 8);
-        memcpy(q + 16, &tab_off[r], 8);
-        memcpy(q + 17, i17, 8);
-        q[18] = 2 * M_PI / ctx->h_ring_period[r];
-        q[19] = 2 * M_PI / ctx->h_ring_lateral[r];
     }
-    ML_TRY(h2d(ctx, ctx->ring_hdr, hdr.data(), hdr.size() * sizeof(double)));
+    ML_REQUIRE(tab_total < (1ull << 40), "ring tables of %zu elements: too large", tab_total);
+    for (int r = 0; r < ctx->n_rings; ++r) {
+        const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
+        double *q = rec.data() + (size_t)r * 4;
+        q[0] = ctx->h_ring_rc[r];
+        q[1] = ctx->h_ring_period[r];
+        q[2] = 2 * M_PI / ctx->h_ring_period[r];
+        long long bits = tab_off[r];
+        // the ring's period outside its table's period range: every evaluated sample of the ring
+        // reports (nearfield.py:302-305)
+        if (ctx->h_ring_period[r] < t.bounds[4] || ctx->h_ring_period[r] > t.bounds[5]) bits |= 1ll << 40;
+        memcpy(q + 3, &bits, 8);
+    }
+    ML_TRY(h2d(ctx, ctx->ring_rec, rec.data(), rec.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_tab, tab.data(), tab.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_tab_off, tab_off.data(), tab_off.size() * sizeof(long long)));
     ML_TRY(h2d(ctx, ctx->ring_ok, ok.data(), ok.size() * sizeof(double)));
@@ -490,7 +490,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     ctx->center.order_k.release();
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
-                      &ctx->ring_hdr, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
+                      &ctx->ring_rec, &ctx->ring_coll, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,
@@ -616,6 +616,27 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
     ctx->h_ring_rc.assign(r_center, r_center + n_rings);
     ctx->h_ring_lateral.assign(lateral, lateral + n_rings);
     ctx->h_ring_gc.assign(ring_gc, ring_gc + n_rings);
+    {
+        // the collections the rings use, numbered densely in slot order: what the geometry records
+        // carry and the field kernel's CollDesc array is indexed by
+        int dense_of[MAX_SLOTS];
+        for (int k = 0; k < MAX_SLOTS; ++k) dense_of[k] = -1;
+        for (int r = 0; r < n_rings; ++r) {
+            ML_REQUIRE(ring_gc[r] >= 0 && ring_gc[r] < MAX_SLOTS, "ring %d uses grating collection %d: 0 ... %d are supported",
+                       r, (int)ring_gc[r], MAX_SLOTS - 1);
+            dense_of[ring_gc[r]] = 0;
+        }
+        ctx->n_colls = 0;
+        for (int k = 0; k < MAX_SLOTS; ++k)
+            if (dense_of[k] == 0) {
+                ML_REQUIRE(ctx->n_colls < MAX_RING_COLLS, "the rings use more than %d grating collections", MAX_RING_COLLS);
+                ctx->coll_slot[ctx->n_colls] = k;
+                dense_of[k] = ctx->n_colls++;
+            }
+        std::vector<int32_t> ring_coll(n_rings);
+        for (int r = 0; r < n_rings; ++r) ring_coll[r] = dense_of[ring_gc[r]];
+        ML_TRY(h2d(ctx, ctx->ring_coll, ring_coll.data(), n_rings * sizeof(int32_t)));
+    }
 
     // uniform-in-r lookup for searchsorted(boundaries, r, 'left'):
     // lut[b] = number of boundaries strictly below the lower edge of bucket b

@@ -148,7 +148,9 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.lat_nb = ctx->lat_nb;
     a.tables = ctx->table_desc.as<TableDesc>();
     a.center_desc = ctx->h_center_desc;
-    a.ring_hdr = ctx->ring_hdr.as<double2>();
+    a.ring_rec = ctx->ring_rec.as<double2>();
+    a.ring_coll = ctx->ring_coll.as<int>();
+    for (int c = 0; c < MAX_RING_COLLS; ++c) a.coll[c] = ctx->h_coll[c];
     a.ring_tab = ctx->ring_tab.as<double2>();
     a.ring_tab_off = ctx->ring_tab_off.as<long long>();
     a.ring_ok = ctx->ring_ok.as<double>();

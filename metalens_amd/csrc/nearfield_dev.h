@@ -71,7 +71,9 @@ struct NfArgs {
     // per-ring tables for the fast kernel: period axis already interpolated, complex
     // [order][n0][n1][4] per ring at ring_tab + ring_tab_off[ring]; per-ring order
     // wavenumbers (ox*2*pi/period, oy*2*pi/lateral) at ring_ok + ring_ok_off[ring]
-    const double2 *ring_hdr;   // [n_rings][RING_HDR / 2], common.h
+    const double2 *ring_rec;   // [n_rings][2]: (r_center, period), (2 pi / period, bits) - common.h
+    const int *ring_coll;      // [n_rings]: dense number of the ring's grating collection
+    CollDesc coll[MAX_RING_COLLS];   // in the kernel arguments: read with scalar loads
     const double2 *ring_tab;
     const long long *ring_tab_off;
     const double *ring_ok;

@@ -351,7 +351,8 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 // Ring (nearfield.py:125-128), sector and rotated local coordinates (:169,200-201), nearest
 // centre cell (:363-367) depend on the sample grid and the layout only.  They are evaluated once
 // per (grid, layout, tie answers) into an 8-byte record per sample (stored patch by patch),
-//     geo_ix = (idx, index into the rotation table)     periphery, idx = ring + 1
+//     geo_ix = (idx | collection << 20, index into the rotation table)     periphery, idx = ring + 1,
+//                  collection = dense number of the ring's grating collection (ml_upload_layout)
 //              (cell type << 20, slot of the nearest cell; -1: no cells) centre: the cell's type
 //                  rides in the bits above the ring index (rings < 2^19) - one gather fewer
 //                  behind the record in kernel 2
@@ -396,7 +397,7 @@ __device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, doubl
     }
 }
 
-constexpr int REC_TYPE_SHIFT = 20;   // centre records: cell type above the ring index (rings < 2^19, ctx.hip)
+constexpr int REC_TYPE_SHIFT = 20;   // records: cell type (centre) / collection (rings) above the ring index (rings < 2^19, ctx.hip)
 
 __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs a) {
     const int lane = threadIdx.x & 63;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
         sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
         // patch-major: the 64 records of a wave are 512 contiguous bytes
         const size_t rec = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
-        const int type = (idx == 0 && aux >= 0) ? a.cwhich[aux] : 0;
+        const int type = (idx == 0 && aux >= 0) ? a.cwhich[aux] : (idx >= 1 && idx <= a.n_rings) ? a.ring_coll[idx - 1] : 0;
         a.geo_ix[rec] = make_int2(idx | (type << REC_TYPE_SHIFT), aux);
     }
     // patches with at least one sample inside the lens: the field kernel visits only these once
@@ -540,11 +541,12 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             typedef int int2v __attribute__((ext_vector_type(2)));
             const size_t rec = ((size_t)by * a.patches_x + bx) * 64 + lane;   // patch-major
             const int2v ix = reinterpret_cast<const int2v *>(a.geo_ix)[rec];
-            idx = ix.x;   // centre: the cell type above bit 20, split off below
+            idx = ix.x;   // cell type / collection above bit 20, split off below
             aux = ix.y;
         } else {
             sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
             if (idx == 0 && aux >= 0) idx = a.cwhich[aux] << REC_TYPE_SHIFT;
+            if (idx >= 1 && idx <= a.n_rings) idx |= a.ring_coll[idx - 1] << REC_TYPE_SHIFT;
         }
     }
     // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
         }
     }
     ML_MARK(1, idx + aux);
-    const int cell_type = idx >> REC_TYPE_SHIFT;
+    const int cell_type = idx >> REC_TYPE_SHIFT;   // (ring samples: the collection)
     idx &= (1 << REC_TYPE_SHIFT) - 1;
     const bool lens = idx <= a.n_rings;
     const bool peri = lens && idx >= 1;
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     const double *ok = a.ring_ok;
     const double2 *node00 = a.ring_tab;
     bool outside = false;
-    double2 h0 = {0, 0}, h8 = h0, cs = {1.0, 0.0}, h4 = h0, h5 = h0, h6 = h0, h7 = h0;
+    double2 r0 = {0, 0}, r1 = r0, cs = {1.0, 0.0};
     // periphery: order (0, 0)'s phasor x the propagation phasor, exp(i Gx x'), Gy y' (order_phasor)
     // (GEN: the propagation phasor alone in E0, the local coordinates x', y' in xp, yp)
     c2 E0 = {1.0, 0.0}, Ex1 = {1.0, 0.0};
@@ -761,47 +763,21 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
         }
 
-        // the ring's header and rotation, requested as soon as the record is there
-        // (behind the centre section, which a wave without centre samples skips: while it runs the
-        // registers are the centre's).  Of the 160-byte
-        // header: its first and last 16 bytes (it spans two cache lines, both then on their way) and,
-        // in the single-source kernel, the four entries behind the table cell and the staging
-        // address; the table bounds are read where they are used (batches have no registers to hold
-        // more than the two ends until then)
+        // the ring's record (common.h ring_rec) and rotation, requested as soon as the geometry record
+        // is there (behind the centre section, which a wave without centre samples skips: while it
+        // runs the registers are the centre's)
         if (peri) {
-            const double2 *h = a.ring_hdr + (size_t)(idx - 1) * (RING_HDR / 2);
-            h0 = h[0];
-            h8 = h[8];
+            const double2 *rr = a.ring_rec + (size_t)(idx - 1) * 2;
+            r0 = rr[0];
+            r1 = rr[1];
             cs = a.rot_table[aux];
-            if (NP == 1) {   // what the table cell and the staging address need: also on its way now
-                h4 = h[4];
-                h5 = h[5];
-                h6 = h[6];
-                h7 = h[7];
-            }
         }
         // ================= periphery: set-up =================
+        int i0 = 0, i1 = 0, n0 = 0, n1 = 0, flags = 0;
         if (peri) {
-            const int ring = idx - 1;
-            // everything that depends on the ring alone comes from ONE record (common.h RING_HDR),
-            // whose two cache lines were requested above
-            const double2 *h = a.ring_hdr + (size_t)ring * (RING_HDR / 2);
-            if (NP > 1) {
-                h4 = h[4];
-                h5 = h[5];
-                h6 = h[6];
-                h7 = h[7];
-            }
-            const double period = h0.y;
-            const int n0 = (int)(__double_as_longlong(h7.x) & 0xffffffffll), n1 = (int)(__double_as_longlong(h7.x) >> 32);
-            const int flags = (int)(__double_as_longlong(h7.y) >> 32);
-            const long long tab_off = __double_as_longlong(h8.x);
-            const int ok_off = (int)(__double_as_longlong(h8.y) & 0xffffffffll);
-            n_orders = (int)(__double_as_longlong(h7.y) & 0xffffffffll);
-            ok = a.ring_ok + ok_off;
             const double cosr = cs.x, sinr = cs.y;
             // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
-            xp = x * cosr + y * sinr - h0.x;
+            xp = x * cosr + y * sinr - r0.x;
             yp = -x * sinr + y * cosr;
             uxp = fma(ux, cosr, uy * sinr);
             uyp = fma(uy, cosr, -ux * sinr);
@@ -810,34 +786,55 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 Hw_y[m] = fma(Hx_i[m], cosr, Hy_i[m] * sinr);    // H along x' <-> y table
                 Hw_x[m] = fma(Hy_i[m], cosr, -Hx_i[m] * sinr);   // H along y' <-> x table
             }
-            int i0, i1;
-            if (flags & 1) {
-                // uniformly spaced axes (what characterize() produces): the cell by arithmetic, as
-                // locate_uv does; header = first0, step0, 1/step0, first1, step1, 1/step1
-                const double a0 = (uxp - h4.x) * h5.x, a1 = (uyp - h5.y) * h6.y;
-                const double f0 = fmin(fmax(floor(a0), 0.0), (double)(n0 - 2));
-                const double f1 = fmin(fmax(floor(a1), 0.0), (double)(n1 - 2));
-                i0 = (int)f0;
-                i1 = (int)f1;
-                t0 = (uxp - fma(f0, h4.y, h4.x)) * h5.x;
-                t1 = (uyp - fma(f1, h6.x, h5.y)) * h6.y;
-            } else {
-                const int slot = (int)(__double_as_longlong(h8.y) >> 32);
-                locate_uv(a.tables[slot], uxp, uyp, i0, t0, i1, t1);
+        }
+        // what depends on the ring's grating COLLECTION (table shape, axes, order list): one round
+        // per collection among the wave's ring samples - one, except on the few waves that straddle
+        // two collections - with the descriptor read by scalar loads from the kernel arguments
+        for (unsigned long long pm = __ballot(peri); pm;) {
+            const int c0 = __builtin_amdgcn_readlane(cell_type, __ffsll((long long)pm) - 1);
+            const bool mc = peri && cell_type == c0;
+            pm &= ~__ballot(mc);
+            const CollDesc &C = a.coll[c0];   // wave-uniform index: scalar loads
+            if (mc) {
+                n0 = C.n0;
+                n1 = C.n1;
+                n_orders = C.n_orders;
+                flags = C.flags;
+                if (flags & 1) {
+                    // uniformly spaced axes (what characterize() produces): the cell by arithmetic, as
+                    // locate_uv does; first0, step0, 1/step0, first1, step1, 1/step1
+                    const double a0 = (uxp - C.uni_ax[0]) * C.uni_ax[2], a1 = (uyp - C.uni_ax[3]) * C.uni_ax[5];
+                    const double f0 = fmin(fmax(floor(a0), 0.0), (double)(n0 - 2));
+                    const double f1 = fmin(fmax(floor(a1), 0.0), (double)(n1 - 2));
+                    i0 = (int)f0;
+                    i1 = (int)f1;
+                    t0 = (uxp - fma(f0, C.uni_ax[1], C.uni_ax[0])) * C.uni_ax[2];
+                    t1 = (uyp - fma(f1, C.uni_ax[4], C.uni_ax[3])) * C.uni_ax[5];
+                } else {
+                    locate_uv(a.tables[a.gc[idx - 1]], uxp, uyp, i0, t0, i1, t1);
+                }
             }
+        }
+        if (peri) {
+            const int ring = idx - 1;
+            const double cosr = cs.x, sinr = cs.y;
+            const double period = r0.y;
+            const long long bits = __double_as_longlong(r1.y);
+            const long long tab_off = bits & ((1ll << 40) - 1);
+            if (GEN) ok = a.ring_ok + a.ring_ok_off[ring];
             stride0 = n1 * 4;
             stride_o = n0 * n1 * 4;
             node00 = a.ring_tab + tab_off + i0 * stride0 + i1 * 4;
             // the table-bound tests do not depend on the order: evaluate them once, and only take
             // the reporting path (per order, in the reference's check order) on failure
             // (a sample inside the range EVERY ring table covers, on a ring whose period its table
-            // covers - flags bit 1 - cannot fail; only the others read their ring's own bounds)
+            // covers - bit 40 of the ring record - cannot fail; only the others read their table's bounds)
             outside = (int)(uxp < a.ring_bounds_all[0]) | (int)(uxp > a.ring_bounds_all[1]) |
-                      (int)(uyp < a.ring_bounds_all[2]) | (int)(uyp > a.ring_bounds_all[3]) | ((flags >> 1) & 1);
+                      (int)(uyp < a.ring_bounds_all[2]) | (int)(uyp > a.ring_bounds_all[3]) | (int)((bits >> 40) & 1);
             if (outside) {
-                const double2 h1 = h[1], h2 = h[2], h3 = h[3];
-                outside = (int)(uxp < h1.x) | (int)(uxp > h1.y) | (int)(uyp < h2.x) | (int)(uyp > h2.y) |
-                          (int)(period < h3.x) | (int)(period > h3.y);
+                const double *b = a.tables[a.gc[ring]].bounds;
+                outside = (int)(uxp < b[0]) | (int)(uxp > b[1]) | (int)(uyp < b[2]) | (int)(uyp > b[3]) |
+                          (int)(period < b[4]) | (int)(period > b[5]);
             }
             // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
             // block per lane (still correct, just not shared)
@@ -852,7 +849,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 double a0 = (p.kvac * uxp) * xp + (p.kvac * uyp) * yp;
                 int kq = 0;
                 if (!p.plane_wave) {
-                    const double rcen = h0.x;
+                    const double rcen = r0.x;
                     const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double r;
@@ -860,12 +857,12 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                     a0 = r + a0;
                 }
                 sincos_cw_q(a0, kq, E0.i, E0.r);
-                Gx = h[9].x;   // 2 pi / period: header slot 18
+                Gx = r1.x;   // 2 pi / period
                 order_codes = flags >> 2;
                 sincos_cw(Gx * xp, Ex1.i, Ex1.r);
             } else if (!p.plane_wave) {
                 // GEN: the propagation phasor on its own; every order evaluates its own argument
-                const double rcen = h0.x;
+                const double rcen = r0.x;
                 const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
                 const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                 sincos_cw(p.kvac * air, E0.i, E0.r);
@@ -977,7 +974,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
     if (peri) {
         // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
-        const double2 cs2 = (NP == 1 && GEN) ? cs : a.rot_table[aux];
+        const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
         const double cosr = cs2.x, sinr = cs2.y;
         // (the propagation phasor already rides in every order's phasor; what is left is the
         // far-field plan's input modulation, if the plan has one: re-read here, an L2 hit)
