@@ -776,6 +776,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
         int i0 = 0, i1 = 0, n0 = 0, n1 = 0, flags = 0;
         if (peri) {
             const double cosr = cs.x, sinr = cs.y;
+            ML_MARK(3, cosr + r0.x + r1.x);   // (ring waves: the ring's record and rotation have arrived)
             // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
             xp = x * cosr + y * sinr - r0.x;
             yp = -x * sinr + y * cosr;
@@ -873,6 +874,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     Acc pr[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    ML_MARK(9, E0.r + Ex1.i + t0);   // (ring waves: set-up arithmetic done, block matching and staging next)
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
         int myslot = -1, lead[NF_SLOTS];
@@ -904,13 +906,16 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 const int o = o0 + (lane >> 4), c = (lane >> 2) & 3, q = lane & 3;
 #pragma unroll
                 for (int s = 0; s < NF_SLOTS; ++s) {
-                    const int l = max(lead[s], 0);   // wave-uniform
+                    have[s] = false;
+                    val[s] = make_double2(0.0, 0.0);
+                    if (lead[s] < 0) continue;       // wave-uniform: the round has fewer blocks (2 - 3 as a rule)
+                    const int l = lead[s];
                     const unsigned long long bits = (unsigned long long)node00;
                     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, l);
                     const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), l);
                     const int so = __builtin_amdgcn_readlane(stride_o, l);
                     const int s0 = __builtin_amdgcn_readlane(stride0, l);
-                    const int no = lead[s] >= 0 ? __builtin_amdgcn_readlane(n_orders, l) : 0;
+                    const int no = __builtin_amdgcn_readlane(n_orders, l);
                     const double2 *base = reinterpret_cast<const double2 *>(((unsigned long long)hi << 32) | lo);
                     have[s] = o < no;
                     // 32-bit element offset from the wave-uniform block address (scalar base +
@@ -1010,7 +1015,6 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     stamp[8] = __builtin_amdgcn_s_memtime();
     const size_t wid = (size_t)by * a.patches_x + bx;   // patch id, whichever launch form
     if (lane == 0 && wid < PHASE_WAVES) {
-        stamp[9] = (unsigned long long)__ballot(true);
         for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = stamp[k];
     }
 #endif

@@ -28,8 +28,9 @@ n_waves = min(nb * nb, 1 << 18)
 buf = np.zeros((n_waves, 10), dtype=np.uint64)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 assert lib.ml_debug_phase_dump(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_waves)) == 0
-t = buf[:, :9].astype(np.int64)
-names = ['records arrive', 'incident field + power', 'centre: cell centre arrives', 'periphery: set-up + staging (loads, LDS, barrier) / centre: phasors',
+t = buf[:, :10].astype(np.int64)
+names = ['records arrive', 'incident field + power', 'ring record + rotation arrive / centre: cell centre arrives',
+         'ring: set-up + staging (loads, LDS, barrier) / centre: phasors',
          'orders', 'post (sincos, rotate)', 'stores issued', 'stores drained']
 by = np.arange(n_waves) // nb
 bx = np.arange(n_waves) % nb
@@ -49,3 +50,7 @@ for label, sel in (('periphery waves', (r > r_c * 1.1) & (r < R * 0.98)), ('cent
         cur = np.where(tt[:, k] > 0, tt[:, k], prev)
         print('   %-32s %8.0f  (%4.1f %%)' % (nm, (cur - prev).mean(), 100 * (cur - prev).mean() / life))
         prev = cur
+    su = tt[:, 9] - tt[:, 3]
+    ok = (tt[:, 9] > 0) & (tt[:, 3] > 0)
+    if ok.any():
+        print('   (of the set-up + staging: set-up arithmetic until the block matching starts %.0f cycles)' % su[ok].mean())
