@@ -2,7 +2,7 @@
 """Digest rocprofv3 CSV output (one --kernel-trace --stats run, optional --pmc FETCH_SIZE and
 --pmc WRITE_SIZE runs of the SAME command) into one small text summary for profiles/.
 
-    python tools/profile_summary.py STATS_DIR [FETCH_DIR] [WRITE_DIR] > profiles/rNN_summary.txt
+    python tools/profile_summary.py STATS_DIR [FETCH_DIR] [WRITE_DIR] [SQ_DIR] [LABEL=SQ_DIR ...] > profiles/rNN_summary.txt
 
 Counters are per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB (checked here: the near-field
 kernel's WRITE_SIZE equals its 64 B/sample of stores).  Per MI355X_MICROARCH.md §HBM, on gfx950
@@ -67,6 +67,29 @@ def main():
             avg = sum(v) / len(v)
             mb = avg * 1024 / 1e6 * (2 if label == 'FETCH_SIZE' else 1)
             out.append('%-46s %14s %6d %14.1f %14.2f' % (k, g, len(v), avg, mb))
+    # further directories: the SQ_* pass of the same command, then LABEL=DIR pairs of other configurations
+    for arg in sys.argv[4:]:
+        label, d = arg.split('=', 1) if '=' in arg else ('the same command', arg)
+        cc = find(d, '*counter_collection.csv')
+        if not cc:
+            continue
+        dur = collections.defaultdict(list)
+        kt2 = find(d, '*kernel_trace.csv')
+        if kt2:
+            for r in csv.DictReader(open(kt2)):
+                dur[(short(r['Kernel_Name']), r['Grid_Size'] if 'Grid_Size' in r else r['Grid_Size_X'])].append(
+                    (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(cc)):
+            acc[(short(r['Kernel_Name']), r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        out.append('')
+        out.append('== rocprofv3 --pmc SQ_* of %s (per dispatch; quad-cycle units for SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_*)' % label)
+        for (k, g), counters in sorted(acc.items()):
+            if not k.startswith('ml::'):
+                continue
+            out.append('%-46s grid %s' % (k, g))
+            for n, v in sorted(counters.items()):
+                out.append('    %-34s %14.0f' % (n, sum(v) / len(v)))
     print('\n'.join(out))
 
 
