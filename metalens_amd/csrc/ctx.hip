@@ -78,7 +78,7 @@ static int refresh_table_desc(ml_ctx *ctx) {
             const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI)), oy = std::lrint(t.h_order_k[2 * o + 1] / (2 * M_PI));
             if (ox < -1 || ox > 1 || oy != 0) ctx->simple_orders = false;
         }
-        if (t.n_orders > 15) ctx->simple_orders = false;   // (the ring headers hold 15 order codes)
+        if (t.n_orders > 15) ctx->simple_orders = false;   // (a collection descriptor holds 15 order codes)
         TableDesc &d = h[s];
         d.axis0 = t.axis0.as<double>();
         d.axis1 = t.axis1.as<double>();

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
     int key = -1, n_orders = 0, stride0 = 0, stride_o = 0, order_codes = 0;
-    double Gx = 0.0;   // simple orders: 2 pi / period; order o adds (code_o - 1) Gx to k ux' (codes: ring header flags)
+    double Gx = 0.0;   // simple orders: 2 pi / period; order o adds (code_o - 1) Gx to k ux' (codes: CollDesc.flags)
     double uxp = 0.0, uyp = 0.0, t0 = 0.0, t1 = 0.0, xp = 0.0, yp = 0.0;
     double Hw_x[NP], Hw_y[NP];
 #pragma unroll
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 // the order's grating vector one iteration ahead: its load (an L1 hit) is in
                 // flight during the previous order's arithmetic instead of in front of its own
                 // (general orders only; the simple-order kernels build the grating vector from the
-                // ring header: ox from its order codes, 2 pi / period - the same rounding as the
+                // ring record and the collection descriptor: ox from the order codes, 2 pi / period - the same rounding as the
                 // reference's ox*2*pi/grating_period for ox = -1, 0, 1 - and oy = 0)
                 typedef double double2v __attribute__((ext_vector_type(2)));
                 const double2v *ok2 = reinterpret_cast<const double2v *>(ok);   // per order: (kx, ky), (ox, oy)
