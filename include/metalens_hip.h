@@ -90,7 +90,9 @@ int ml_upload_table(ml_ctx *ctx, int slot,
  *   tie_table[rot_len][6]: for the sector boundary (k + 1/2)*dphi stored at the index of
  *   sector k: the angle, its cosine and its sine, each as (hi, lo) float64 pairs from an
  *   extended-precision evaluation; used to settle round(arctan2(y,x)/dphi) for samples
- *   that sit within 1e-9 of a tie (samples on the diagonals of a symmetric grid).       */
+ *   that sit within 1e-9 of a tie (samples on the diagonals of a symmetric grid).
+ * Limits (ML_EINVAL beyond them): fewer than 2^19 rings; the rings may use at most 16 different
+ * grating collections (slots 0 ... 31); cells[.][2], the HexGridSet index, in 0 ... 2047.      */
 int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *ring_boundaries,
                      const double *ring_r_center, const double *ring_period,
                      const double *ring_dphi, const double *ring_lateral,

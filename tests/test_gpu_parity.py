@@ -1251,6 +1251,29 @@ def test_centre_blocks_many_types_and_straddling_waves(ma, entries, pols):
             assert np.abs(gf - w).max() <= TOL * scale
 
 
+def test_layout_limits_are_refused(ma):
+    """what the geometry records cannot hold is refused at upload with a message, not truncated:
+    a HexGridSet index outside 0 ... 2047 (11 bits above the ring index) and rings that use more
+    than 16 different grating collections (the per-collection descriptors in the kernel arguments)"""
+    import copy
+    from metalens_amd import _lib, packing
+    lens = _synthetic_lens(80e-6, 0.4, 580e-9, switch_deg=9.0)
+    S, cells = lens['lens_periphery_summary'], np.array(lens['lens_center_summary'], dtype=float)
+    ctx = _lib.Context(0)
+    for bad in (2048.0, -1.0):
+        c = cells.copy()
+        c[5, 2] = bad
+        with pytest.raises(_lib.MetalensHipError, match='grating index'):
+            packing.upload_layout(ctx, S, c)
+    S17 = copy.copy(S)
+    n = len(S['r_center_list'])
+    assert n >= 17
+    S17['gratingcollection_index_here_list'] = [k % 17 for k in range(n)]
+    with pytest.raises(_lib.MetalensHipError, match='more than 16 grating collections'):
+        packing.upload_layout(ctx, S17, cells)
+    packing.upload_layout(ctx, S, cells)   # and the context still takes a good one
+
+
 @pytest.mark.parametrize('seed', [5, 6])
 def test_random_windows_sweep(ma, seed):
     """random windows, sources and polarisations on two lenses against the oracle
