@@ -309,7 +309,7 @@ struct ml_ctx {
     int32_t coll_slot[ml::MAX_RING_COLLS] = {0};               // dense collection number -> slot
     ml::CollDesc h_coll[ml::MAX_RING_COLLS] = {};
     std::vector<ml::TableDesc> h_table_desc;                   // host copy of table_desc
-    ml::DevBuf ring_tab, ring_tab_off, ring_ok, ring_ok_off;   // fast-kernel per-ring tables
+    ml::DevBuf ring_tab, ring_ok, ring_ok_off;   // fast-kernel per-ring tables (offsets into ring_tab: ring_rec)
     ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     ml::DevBuf ring_lutrec;          // fast kernel: coarser buckets that carry the boundaries

@@ -235,7 +235,6 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     }
     ML_TRY(h2d(ctx, ctx->ring_rec, rec.data(), rec.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_tab, tab.data(), tab.size() * sizeof(double)));
-    ML_TRY(h2d(ctx, ctx->ring_tab_off, tab_off.data(), tab_off.size() * sizeof(long long)));
     ML_TRY(h2d(ctx, ctx->ring_ok, ok.data(), ok.size() * sizeof(double)));
     ML_TRY(h2d(ctx, ctx->ring_ok_off, ok_off.data(), ok_off.size() * sizeof(int32_t)));
     // centre table for the fast kernel: [order][n0][n1][4][K] instead of [order][n0][n1][K][4],
@@ -490,7 +489,7 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     ctx->center.order_k.release();
     DevBuf *bufs[] = {&ctx->table_desc, &ctx->ring_boundaries, &ctx->ring_r_center,
                       &ctx->ring_period, &ctx->ring_dphi, &ctx->ring_lateral, &ctx->ring_gc,
-                      &ctx->ring_rec, &ctx->ring_coll, &ctx->ring_tab, &ctx->ring_tab_off, &ctx->ring_ok,
+                      &ctx->ring_rec, &ctx->ring_coll, &ctx->ring_tab, &ctx->ring_ok,
                       &ctx->ring_ok_off, &ctx->center_qmajor, &ctx->rot_table, &ctx->tie_table, &ctx->ring_rot_center,
                       &ctx->ring_rot_half, &ctx->ring_lut, &ctx->ring_lutrec, &ctx->cell_x, &ctx->cell_y,
                       &ctx->cell_xy, &ctx->cell_which, &ctx->cell_index, &ctx->bin_start,

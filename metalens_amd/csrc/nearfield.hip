@@ -152,7 +152,6 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.ring_coll = ctx->ring_coll.as<int>();
     for (int c = 0; c < MAX_RING_COLLS; ++c) a.coll[c] = ctx->h_coll[c];
     a.ring_tab = ctx->ring_tab.as<double2>();
-    a.ring_tab_off = ctx->ring_tab_off.as<long long>();
     a.ring_ok = ctx->ring_ok.as<double>();
     a.ring_ok_off = ctx->ring_ok_off.as<int>();
     a.geo_ix = ctx->geo_ix.as<int2>();

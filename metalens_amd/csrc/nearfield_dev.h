@@ -69,13 +69,12 @@ struct NfArgs {
     TableDesc center_desc;
     const TableDesc *tables;
     // per-ring tables for the fast kernel: period axis already interpolated, complex
-    // [order][n0][n1][4] per ring at ring_tab + ring_tab_off[ring]; per-ring order
-    // wavenumbers (ox*2*pi/period, oy*2*pi/lateral) at ring_ok + ring_ok_off[ring]
+    // [order][n0][n1][4] per ring at ring_tab + the offset in the ring's record; per-ring order
+    // wavenumbers (ox*2*pi/period, oy*2*pi/lateral) at ring_ok + ring_ok_off[ring] (general order sets)
     const double2 *ring_rec;   // [n_rings][2]: (r_center, period), (2 pi / period, bits) - common.h
     const int *ring_coll;      // [n_rings]: dense number of the ring's grating collection
     CollDesc coll[MAX_RING_COLLS];   // in the kernel arguments: read with scalar loads
     const double2 *ring_tab;
-    const long long *ring_tab_off;
     const double *ring_ok;
     const int *ring_ok_off;
     // per-sample geometry records (nearfield_fast.hip, kernel 1 writes, kernel 2 reads)
