@@ -312,6 +312,39 @@ __device__ __forceinline__ void order_common_types(OrderCommon &oc, const double
         }
 }
 
+// the single-source form: oc.ar[0] / ai[0] = U_fy, oc.ar[1] / ai[1] = U_fx (see order_apply), from the
+// staged block and the interpolation weights already multiplied by the two polarisation weights
+__device__ __forceinline__ void order_common_folded(OrderCommon &oc, const double2 *blk, const double *wfx,
+                                                    const double *wfy) {
+    oc.ar[0] = oc.ai[0] = oc.ar[1] = oc.ai[1] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double2 v0 = blk[c * 4 + 0], v1 = blk[c * 4 + 1], v2 = blk[c * 4 + 2], v3 = blk[c * 4 + 3];
+        oc.ar[0] = fma(wfx[c], v0.x, oc.ar[0]);
+        oc.ai[0] = fma(wfx[c], v0.y, oc.ai[0]);
+        oc.ar[1] = fma(wfx[c], v1.x, oc.ar[1]);
+        oc.ai[1] = fma(wfx[c], v1.y, oc.ai[1]);
+        oc.ar[0] = fma(wfy[c], v2.x, oc.ar[0]);
+        oc.ai[0] = fma(wfy[c], v2.y, oc.ai[0]);
+        oc.ar[1] = fma(wfy[c], v3.x, oc.ar[1]);
+        oc.ai[1] = fma(wfy[c], v3.y, oc.ai[1]);
+    }
+}
+
+__device__ __forceinline__ void order_apply_folded(Acc &acc, const OrderCommon &oc) {
+    const double ufy_r = oc.ar[0], ufy_i = oc.ai[0], ufx_r = oc.ar[1], ufx_i = oc.ai[1];
+    const double vy_r = fma(ufy_r, oc.cs, -ufy_i * oc.sn), vy_i = fma(ufy_r, oc.sn, ufy_i * oc.cs);
+    const double vx_r = fma(ufx_r, oc.cs, -ufx_i * oc.sn), vx_i = fma(ufx_r, oc.sn, ufx_i * oc.cs);
+    acc.Hx.r += vy_r;
+    acc.Hx.i += vy_i;
+    acc.Hy.r += vx_r;
+    acc.Hy.i += vx_i;
+    acc.Ex.r += fma(oc.cxy, vy_r, oc.cxx * vx_r);
+    acc.Ex.i += fma(oc.cxy, vy_i, oc.cxx * vx_i);
+    acc.Ey.r += fma(oc.cyy, vy_r, -oc.cxy * vx_r);
+    acc.Ey.i += fma(oc.cyy, vy_i, -oc.cxy * vx_i);
+}
+
 // one polarisation's share of the order (nearfield.py:313-327 rearranged, see the file header)
 __device__ __forceinline__ void order_apply(Acc &acc, const OrderCommon &oc, double Hw_x,
                                             double Hw_y) {
@@ -874,6 +907,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     Acc pr[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    constexpr bool FOLD = NP == 1 && !GEN;
     ML_MARK(9, E0.r + Ex1.i + t0);   // (ring waves: set-up arithmetic done, block matching and staging next)
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
@@ -934,6 +968,17 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             ML_MARK(4, s_tab[lane].x);
             if (myslot >= 0) {
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
+                // (one source: the interpolation weights times the two polarisation weights, worked out
+                // per pass - one as a rule - so that they are not live while the blocks are staged)
+                double wfx[4] = {0, 0, 0, 0}, wfy[4] = {0, 0, 0, 0};
+                if (FOLD) {
+                    const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        wfx[c] = w[c] * Hw_x[0];
+                        wfy[c] = w[c] * Hw_y[0];
+                    }
+                }
                 // the order's grating vector one iteration ahead: its load (an L1 hit) is in
                 // flight during the previous order's arithmetic instead of in front of its own
                 // (general orders only; the simple-order kernels build the grating vector from the
@@ -961,15 +1006,25 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                             check_bounds(a, a.tables[slot], slot, o, uxp, uyp, a.period[idx - 1], true);
                         }
                         OrderCommon oc;
-                        order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
-                        if (GEN)
-                            order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
-                                              kxp * xp + kyp * yp);
-                        else
+                        if (FOLD) {
+                            // one source: the two polarisation weights ride in the interpolation
+                            // weights (wfx = w Hw_x, wfy = w Hw_y, set up once per sample), so the
+                            // order yields U_fy, U_fx directly (order_apply's first eight operations)
+                            order_common_folded(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, wfx, wfy);
                             order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
                                           order_phasor(E0, Ex1, ox_here));
+                            order_apply_folded(pr[0], oc);
+                        } else {
+                            order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
+                            if (GEN)
+                                order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                                  kxp * xp + kyp * yp);
+                            else
+                                order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                              order_phasor(E0, Ex1, ox_here));
 #pragma unroll
-                        for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
+                            for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
+                        }
                     }
                 }
             }
