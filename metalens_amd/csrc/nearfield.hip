@@ -84,6 +84,7 @@ int power_flush(ml_ctx *ctx) {
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a) {
     a.p = p[0];
     a.n_pol = n;
+    a.e_from_h = p[0].Z0 * (1.0 / p[0].n_glass) * (1.0 / p[0].k_glass);
     a.n_partials = ((ny + 7) / 8) * ((nx + 7) / 8);
     for (int m = 0; m < MAX_POL; ++m) {
         const ml_nearfield_params &q = p[m < n ? m : 0];

@@ -22,6 +22,7 @@ struct NfArgs {
     // every member; member m writes field set m and power partials [m][n_partials]
     int n_pol, n_partials;
     double pol[MAX_POL][3], hcoef[MAX_POL], dmom[MAX_POL];
+    double e_from_h;   // Z0 / (n_glass k_glass): the source-independent part of the E-from-H factors
     const double *x_pts, *y_pts;
     int nx, ny;
     // rings

@@ -261,20 +261,20 @@ __device__ __forceinline__ c2 order_phasor(c2 E0, c2 Ex, int ox) {   // ox in {-
 }
 
 __device__ __forceinline__ void order_factors(OrderCommon &oc, double kx, double ky, double kz2,
-                                              double k_glass, double inv_n, double Z0, c2 ph);
+                                              double e_from_h, c2 ph);
 
 __device__ __forceinline__ void order_factors_arg(OrderCommon &oc, double kx, double ky, double kz2,
-                                                  double k_glass, double inv_n, double Z0, double arg) {
+                                                  double e_from_h, double arg) {
     c2 ph;
     sincos_cw(arg, ph.i, ph.r);
-    order_factors(oc, kx, ky, kz2, k_glass, inv_n, Z0, ph);
+    order_factors(oc, kx, ky, kz2, e_from_h, ph);
 }
 
 __device__ __forceinline__ void order_factors(OrderCommon &oc, double kx, double ky, double kz2,
-                                              double k_glass, double inv_n, double Z0, c2 ph) {
+                                              double e_from_h, c2 ph) {
     oc.cs = ph.r;
     oc.sn = ph.i;
-    const double g = Z0 * inv_n * recip(k_glass) * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
+    const double g = e_from_h * rsqrt_fast(kz2);   // Z0 / (n k_glass kz)
     oc.cxy = kx * ky * g;
     oc.cxx = fma(ky, ky, kz2) * g;
     oc.cyy = -fma(kx, kx, kz2) * g;
@@ -621,7 +621,6 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     idx &= (1 << REC_TYPE_SHIFT) - 1;
     const bool lens = idx <= a.n_rings;
     const bool peri = lens && idx >= 1;
-    const double inv_n = recip(p.n_glass);
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
     int key = -1, n_orders = 0, stride0 = 0, stride_o = 0, order_codes = 0;
@@ -745,10 +744,10 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                             OrderCommon oc;
                             order_common_types(oc, s_tab + (which - tb), c0, c1);
                             if (GEN)
-                                order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, a.e_from_h,
                                                   kx * ox_ + ky * oy_);
                             else
-                                order_factors(oc, kx, ky, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                order_factors(oc, kx, ky, p.k_glass2 - kt2, a.e_from_h,
                                               order_phasor(E0, Exc, T.center_ox[o]));
                             // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
 #pragma unroll
@@ -1011,16 +1010,16 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                             // weights (wfx = w Hw_x, wfy = w Hw_y, set up once per sample), so the
                             // order yields U_fy, U_fx directly (order_apply's first eight operations)
                             order_common_folded(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, wfx, wfy);
-                            order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                            order_factors(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h,
                                           order_phasor(E0, Ex1, ox_here));
                             order_apply_folded(pr[0], oc);
                         } else {
                             order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
                             if (GEN)
-                                order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h,
                                                   kxp * xp + kyp * yp);
                             else
-                                order_factors(oc, kxp, kyp, p.k_glass2 - kt2, p.k_glass, inv_n, p.Z0,
+                                order_factors(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h,
                                               order_phasor(E0, Ex1, ox_here));
 #pragma unroll
                             for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
