@@ -104,12 +104,12 @@ __device__ __forceinline__ double rsqrt_fast(double x) {
     return fma(y, e * fma(e, 0.375, 0.5), y);
 }
 
-// Accurate reciprocal: hardware estimate + two Newton steps (~1 ulp).
+// Accurate reciprocal (~1 ulp): hardware estimate (~2^-24) + one third-order step y (1 + e + e^2),
+// e = 1 - x y (three operations where two Newton steps take four).
 __device__ __forceinline__ double recip(double x) {
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return y;
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);
+    return fma(y, fma(e, e, e), y);
 }
 
 // arctan2(y, x) to ~2 ulp for finite (x, y) != (0, 0): atan(a) = a Q(a^2) on [0, 1] (degree-20
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 Hx_i[m] = -pol[1] * a.dmom[m] / p.Z0;
                 Hy_i[m] = pol[0] * a.dmom[m] / p.Z0;
             } else {
-                const double amp = a.hcoef[m] * sqrt(uz) * inv;
+                const double amp = a.hcoef[m] * (uz * rsqrt_fast(uz)) * inv;   // Lambert factor sqrt(uz), uz > 0
                 Hx_i[m] = (uy * pol[2] - uz * pol[1]) * amp;
                 Hy_i[m] = (uz * pol[0] - ux * pol[2]) * amp;
                 const double Hz_i = (ux * pol[1] - uy * pol[0]) * amp;
