@@ -388,10 +388,27 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
     return boundaries_below(a, r);
 }
 
-// incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream
+// v + (v of the lane the DPP control names; 0 where there is none or the row is masked off)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream.
+// The wave's sum by data-parallel-primitive moves (row_shr 1, 2, 4, 8, then row_bcast 15 and 31:
+// eighteen operations, the total in lane 63) - six rounds of __shfl_down are twelve trips through
+// the LDS crossbar, each waited for, in a kernel whose waves have nothing else to wait with.
 __device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int bx, int by, int member) {
-    for (int off = 32; off > 0; off >>= 1) power_here += __shfl_down(power_here, off, 64);
-    if ((threadIdx.x & 63) == 0)
+    power_here = dpp_add<0x111, 0xf>(power_here);
+    power_here = dpp_add<0x112, 0xf>(power_here);
+    power_here = dpp_add<0x114, 0xf>(power_here);
+    power_here = dpp_add<0x118, 0xf>(power_here);
+    power_here = dpp_add<0x142, 0xa>(power_here);
+    power_here = dpp_add<0x143, 0xc>(power_here);
+    if ((threadIdx.x & 63) == 63)
         a.partial_power[(size_t)member * a.n_partials + (size_t)by * a.patches_x + bx] = power_here;
     // (workgroup 0 exists in the full and in the listed grid alike; wave 0 of it clears the keys.
     // The bands of a banded synthesis each clear them again, which is harmless: nobody writes
