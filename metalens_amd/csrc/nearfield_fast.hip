@@ -621,19 +621,19 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     const bool peri = lens && idx >= 1;
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
-    int key = -1, n_orders = 0, stride0 = 0, stride_o = 0, order_codes = 0;
-    double Gx = 0.0;   // simple orders: 2 pi / period; order o adds (code_o - 1) Gx to k ux' (codes: CollDesc.flags)
-    double uxp = 0.0, uyp = 0.0, t0 = 0.0, t1 = 0.0, xp = 0.0, yp = 0.0;
+    // (set and read by ring samples only - lanes with key >= 0 - and deliberately left without initial
+    // values: every default costs a move per register and a select where the branches meet)
+    int key = -1, n_orders = 0, stride0, stride_o, order_codes;
+    double Gx;   // simple orders: 2 pi / period; order o adds (code_o - 1) Gx to k ux' (codes: CollDesc.flags)
+    double uxp, uyp, t0, t1, xp, yp;
     double Hw_x[NP], Hw_y[NP];
-#pragma unroll
-    for (int m = 0; m < NP; ++m) Hw_x[m] = Hw_y[m] = 0.0;
     const double *ok = a.ring_ok;
-    const double2 *node00 = a.ring_tab;
+    const double2 *node00;
     bool outside = false;
-    double2 r0 = {0, 0}, r1 = r0, cs = {1.0, 0.0};
+    double2 r0, r1, cs;
     // periphery: order (0, 0)'s phasor x the propagation phasor, exp(i Gx x'), Gy y' (order_phasor)
     // (GEN: the propagation phasor alone in E0, the local coordinates x', y' in xp, yp)
-    c2 E0 = {1.0, 0.0}, Ex1 = {1.0, 0.0};
+    c2 E0, Ex1;
     {
         const double x = x_ld, y = y_ld;
 #pragma unroll
