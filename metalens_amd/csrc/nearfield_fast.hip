@@ -664,8 +664,8 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             const int st1 = n2 * 4, st0 = T.n1 * n2 * 4;
             const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
             const int which = min(cell_type, n2 - 1);
-            double ccx = 0.0, ccy = 0.0, ox_ = 0.0, oy_ = 0.0;
-            c2 E0 = {1.0, 0.0}, Exc = {1.0, 0.0};
+            double ccx, ccy, ox_, oy_;   // (centre samples only; no defaults - see the ring samples' state above)
+            c2 E0, Exc;
             if (cen) {
                 // the record holds the cell's slot in the bin-sorted arrays
                 const double2 cc = a.cxy[aux];
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             cs = a.rot_table[aux];
         }
         // ================= periphery: set-up =================
-        int i0 = 0, i1 = 0, n0 = 0, n1 = 0, flags = 0;
+        int i0, i1, n0, n1, flags;
         if (peri) {
             const double cosr = cs.x, sinr = cs.y;
             ML_MARK(3, cosr + r0.x + r1.x);   // (ring waves: the ring's record and rotation have arrived)
