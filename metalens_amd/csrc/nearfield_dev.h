@@ -392,8 +392,14 @@ __device__ __forceinline__ int boundaries_below_fast(const NfArgs &a, double r) 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v) {
     const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    int lo, hi;
+    if (ROW_MASK == 0xf) {   // every row takes part: lanes without a source read 0 (bound_ctrl), nothing to preset
+        lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xf, 0xf, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, false);
+        hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    }
     return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 

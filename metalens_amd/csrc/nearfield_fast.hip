@@ -39,8 +39,8 @@ __device__ __forceinline__ double horner(double z, double p, double C) {
 __device__ __forceinline__ void sincos_cw(double x, double &s, double &c) {
     const double k = rint(x * 0.63661977236758138243);          // 2/pi
     double r = fma(-k, 1.57079632679489655800e+00, x);          // pi/2 hi
-    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid
-    r = fma(-k, -1.49738490485916983291e-33, r);                // pi/2 lo
+    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid (a third term, 1.5e-33 k, is
+                                                                // below 1e-27 for the |k| < 1e6 met here)
     const double z = r * r;
     double ps = horner(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     ps = horner(z, ps, 2.75573137070700676789e-06);
@@ -60,13 +60,12 @@ __device__ __forceinline__ void sincos_cw(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -b : b;
 }
 
-// x = r + k pi/2 with |r| <= pi/4 (three-constant Cody-Waite, as above); k fits an int for the
+// x = r + k pi/2 with |r| <= pi/4 (two-constant Cody-Waite, as above); k fits an int for the
 // |x| < ~1e9 this kernel meets
 __device__ __forceinline__ void reduce_pio2(double x, double &r, int &k) {
     const double kd = rint(x * 0.63661977236758138243);
     r = fma(-kd, 1.57079632679489655800e+00, x);
     r = fma(-kd, 6.12323399573676603587e-17, r);
-    r = fma(-kd, -1.49738490485916983291e-33, r);
     k = (int)kd;
 }
 
@@ -74,8 +73,8 @@ __device__ __forceinline__ void reduce_pio2(double x, double &r, int &k) {
 __device__ __forceinline__ void sincos_cw_q(double x, int kq, double &s, double &c) {
     const double k = rint(x * 0.63661977236758138243);          // 2/pi
     double r = fma(-k, 1.57079632679489655800e+00, x);          // pi/2 hi
-    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid
-    r = fma(-k, -1.49738490485916983291e-33, r);                // pi/2 lo
+    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid (a third term, 1.5e-33 k, is
+                                                                // below 1e-27 for the |k| < 1e6 met here)
     const double z = r * r;
     double ps = horner(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
     ps = horner(z, ps, 2.75573137070700676789e-06);
