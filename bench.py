@@ -95,10 +95,9 @@ def nearfield_roof(avg_ms, nf_bytes, pmc_nf):
     return roof
 
 
-def pmc_key(gpus, aperture, farfield, precision, method, zoom, pols, overlap):
-    key = ('gpus=%d,aperture=%d,farfield=%d,precision=%s,method=%s,zoom=%g,pols=%d'
-           % (gpus, aperture, farfield, precision, method, zoom, pols))
-    return key + (',overlap=%d' % overlap if overlap > 1 else '') + (',pipeline' if overlap == -1 else '')
+def pmc_key(gpus, aperture, farfield, precision, method, zoom, pols):
+    return ('gpus=%d,aperture=%d,farfield=%d,precision=%s,method=%s,zoom=%g,pols=%d'
+            % (gpus, aperture, farfield, precision, method, zoom, pols))
 
 
 def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0):
@@ -194,6 +193,36 @@ def cpu_reference_route(lens, x, wavelength, side, source):
                       % (side, side, t_nf, t_fft, t_pr)}
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher (no WORLD_SIZE in the environment): this process
+    starts the N ranks itself - one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set the way
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` sets them - passes rank 0's
+    stdout (the one JSON line) through and returns the worst exit code.  The ranks find each other
+    through the same environment either way (metalens_amd/dist.py)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                TORCHELASTIC_RUN_ID='bench%d' % os.getpid())
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = []
+    try:
+        for q in procs:
+            codes.append(q.wait())
+    except BaseException:
+        for q in procs:   # (exactly the processes started here)
+            if q.poll() is None:
+                q.kill()
+        raise
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -258,25 +287,15 @@ def main():
     ap.add_argument('--cold', type=int, default=1,
                     help='1: also time single steps on a sample grid the context has not seen '
                          '(ms_first_step_new_geometry); N = 1 only')
-    ap.add_argument('--pipeline', default='0',
-                    help="the pipelined sweep (metalens_hip.h ml_step_pipeline): '1' or '1,wpb,lean,per_cu' - "
-                         'consecutive steps overlap: the synthesis of step k + 1 runs beside the transform of '
-                         'step k on a second stream (two field buffers); N = 1 only')
-    ap.add_argument('--overlap', default='0',
-                    help="the banded step (metalens_hip.h ml_step_overlap): 'B' or 'B,wpb,lean,per_cu,same_stream' - "
-                         'B > 1 bands of aperture rows, the synthesis of band b + 1 runs beside the row '
-                         'transform of band b; wpb = waves per synthesis workgroup (1 | 4), lean = the '
-                         '<= 128-register row transform (0 | 1), per_cu = its workgroups per CU')
     args = ap.parse_args()
 
     from metalens_amd import _lib, dist
     from metalens_amd.pipeline import HotPath
 
     rank, local_rank, world = dist.env_rank()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))   # plain `python bench.py --gpus N`: start the ranks here
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with python -m torch.distributed.run '
-                     '--nproc-per-node %d' % (args.gpus, args.gpus))
         args.gpus = world
     ctx = _lib.Context(local_rank)
     dist.init_comm(ctx, rank, world)
@@ -314,14 +333,6 @@ def main():
                  precision=args.precision, reduce=args.reduce,
                  fuse_modulation=bool(args.fuse_modulation), method=args.method, sharding=args.sharding)
 
-    ov = [int(v) for v in args.overlap.split(',')]
-    ov = ov + [4, 1, 1, 0][len(ov) - 1:]
-    ctx.set_overlap(ov[0], ov[1], bool(ov[2]), ov[3], bool(ov[4]))
-    pl_ = [int(v) for v in args.pipeline.split(',')]
-    pl_ = pl_ + [4, 1, 1][len(pl_) - 1:]
-    if pl_[0]:
-        assert world == 1, '--pipeline is a single-GPU mode'
-        ctx.set_pipeline(True, pl_[1], bool(pl_[2]), pl_[3])
     n_pols = len(args.pols)
     if n_pols > 1:
         assert world == 1 and not args.pair_list, '--pols batches are a single-GPU tensor-grid mode'
@@ -460,7 +471,7 @@ def main():
                    'rings': int(len(lens['lens_periphery_summary']['r_center_list'])),
                    'centre_cells': int(len(lens['lens_center_summary'])),
                    'parallelism': par, 'sharding': hp.sharding, 'sources_per_step': n_pols,
-                   'overlap_bands': ov[0], 'pipelined_steps': bool(pl_[0]), 'replicas': replica_table,
+                   'replicas': replica_table,
                    'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]}},
         # the same K steps again, args.blocks times in all: spread of the measurement
         'ms_per_step_blocks': block_ms, 'ms_per_step_median': float(np.median(block_ms)),
@@ -479,7 +490,7 @@ def main():
                                    for k, v in prof.items() if v['launches']}
     line['kernel_timing'] = {'mode': args.profile, 'timed_every_n_steps': every}
     local_rows = hp.x_local.size
-    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols, -1 if pl_[0] else ov[0])
+    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols)
     line['config']['pmc_key'] = key
     pmc = load_pmc_table().get(key, {})
     roofs = {}

@@ -215,35 +215,6 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
 #define ML_METHOD_AUTO 0
 #define ML_METHOD_GEMM 1
 int ml_farfield_set_method(ml_ctx *ctx, int method);
-/* The banded step.  The two large kernels of a step answer to different pipes of a CU - the
- * synthesis (nearfield.py:208-477 per sample) to fp64 issue, the row transform on lattice grids
- * (the reference's fft2 along y, nearfield_farfield.py:18-20) to the LDS pipe - and run back to
- * back they each leave the other's pipe idle.  bands > 1 cuts the resident aperture rows into that
- * many bands of whole 8-row patch rows: ml_nearfield_async then queues one synthesis launch per
- * band and ml_farfield_transform*_async transforms band b on a second stream as soon as its
- * synthesis is through, beside the synthesis of band b + 1; the column pass follows when the last
- * band is done.  The fields are bit-identical to the unbanded step's; so is the far field with
- * fft_lean = 0, and with fft_lean = 1 it is equal to rounding (the lean kernel applies its stage-1
- * twiddles as two in-place products, an equivalent association).  Applies to single-source syntheses whose stage 1 is the pruned FFT; every
- * other case runs unbanded.  nf_waves_per_block: 1 or 4 waves per synthesis workgroup (4 lets a
- * four-wave transform workgroup in whenever one retires); fft_lean: the <= 128-register row
- * transform (fits beside three synthesis waves per SIMD); fft_per_cu: its workgroups per CU (1..4).
- * same_stream = 1 (a measurement aid) queues the banded launches back to back on the one stream,
- * so that the cost of the banding itself can be told from the effect of running side by side.
- * bands = 0 or 1 switches the banding off (default).                                            */
-int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu,
-                    int same_stream);
-/* The PIPELINED sweep: the same idea across steps instead of inside one.  The reference's use of
- * this path is a sweep over sources on one lens (nearfield.py:69-73); with on = 1 consecutive
- * ml_nearfield_async / ml_farfield_transform*_async / ml_farfield_project_async calls overlap:
- * syntheses stay on the context's stream and alternate between two field buffers, transforms and
- * projections are queued on a second stream, step k + 1's synthesis waits only for the transform
- * that last read its buffer (step k - 1's), step k's transform for step k's synthesis.  What the
- * host reads back (ml_farfield_project, ml_farfield_download, ml_fields_download, ml_nearfield_result,
- * ml_sync) is the LAST queued step's, complete - those entry points join the two streams; sums over
- * the sources of a sweep are taken on the GPU as before (ml_farfield_accumulate, queued behind each
- * projection).  Single GPU, single-source syntheses; switches the banded step off.               */
-int ml_step_pipeline(ml_ctx *ctx, int on, int nf_waves_per_block, int fft_lean, int fft_per_cu);
 /* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",
  * configs[4] "fp32 GEMM-cast MFMA path").  ML_PRECISION_F64 (default): fp64 matrix cores.
  * ML_PRECISION_F32_GEMM: the folded GEMMs of both stages round their operands to fp32 and

@@ -40,8 +40,8 @@ SYMBOLS = (
     'ml_nearfield_async', 'ml_farfield_transform_async', 'ml_farfield_transform_mirrored',
     'ml_farfield_transform_mirrored_async', 'ml_farfield_project_async',
     'ml_nearfield_result', 'ml_nearfield_ties', 'ml_nearfield_tie_answers',
-    'ml_farfield_plan_kernels', 'ml_farfield_set_method', 'ml_step_overlap',
-    'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async', 'ml_step_pipeline',
+    'ml_farfield_plan_kernels', 'ml_farfield_set_method',
+    'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_host_alloc', 'ml_host_free',
 )
@@ -128,8 +128,6 @@ def load():
     lib.ml_farfield_set_precision.argtypes = [c_void_p, c_int]
     lib.ml_farfield_plan_kernels.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int)]
     lib.ml_farfield_set_method.argtypes = [c_void_p, c_int]
-    lib.ml_step_overlap.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int]
-    lib.ml_step_pipeline.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.ml_farfield_interleave_block.argtypes = [c_void_p, c_int, POINTER(c_int)]
     lib.ml_farfield_transform_interleaved_async.argtypes = [c_void_p, c_int, c_int, c_int, c_int]
     lib.ml_farfield_project_reduce.argtypes = [c_void_p, c_double]
@@ -293,18 +291,6 @@ class Context:
         output-pruned FFTs, the others as GEMMs; 'gemm': GEMMs everywhere.  Applies to the
         next plan."""
         check(self.lib.ml_farfield_set_method(self.handle, {'auto': 0, 'gemm': 1}[method]))
-
-    def set_overlap(self, bands=0, nf_waves_per_block=4, fft_lean=True, fft_per_cu=1, same_stream=False):
-        """the banded step (metalens_hip.h ml_step_overlap): ``bands`` > 1 runs the synthesis of band
-        b + 1 beside the row transform of band b; 0 switches it off"""
-        check(self.lib.ml_step_overlap(self.handle, int(bands), int(nf_waves_per_block),
-                                       int(bool(fft_lean)), int(fft_per_cu), int(bool(same_stream))))
-
-    def set_pipeline(self, on=True, nf_waves_per_block=4, fft_lean=True, fft_per_cu=1):
-        """the pipelined sweep (metalens_hip.h ml_step_pipeline): consecutive steps overlap - the
-        synthesis of step k + 1 runs beside the transform of step k on a second stream"""
-        check(self.lib.ml_step_pipeline(self.handle, int(bool(on)), int(nf_waves_per_block),
-                                        int(bool(fft_lean)), int(fft_per_cu)))
 
     def plan_kernels(self):
         """(stage 1, stage 2) of the active plan: 'gemm', 'folded' or 'fft'"""

@@ -139,40 +139,7 @@ int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count, hipStream_t strea
     return allreduce_dev(ctx, buf, count, 0, stream);
 }
 
-int AuxStreamScope::enter(ml_ctx *c) {
-    ctx = c;
-    Overlap &ov = c->ov;
-    if (!ov.pipeline || !ov.aux) return ML_OK;
-    // whatever the main stream has queued so far (the synthesis, an upload) comes first
-    ML_HIP(hipEventRecord(ov.main_mark, c->stream));
-    ML_HIP(hipStreamWaitEvent(ov.aux, ov.main_mark, 0));
-    saved = c->stream;
-    c->stream = ov.aux;
-    ov.aux_busy = true;
-    on = true;
-    return ML_OK;
-}
-
-AuxStreamScope::~AuxStreamScope() {
-    if (on) ctx->stream = saved;
-}
-
-// the main stream (and the host, if `host`) waits for what a pipelined sweep left on the second stream
-static int pipeline_join(ml_ctx *ctx, bool host) {
-    Overlap &ov = ctx->ov;
-    if (!ov.aux_busy || !ov.aux) return ML_OK;
-    ML_HIP(hipEventRecord(ov.aux_mark, ov.aux));
-    if (host) {
-        ML_HIP(hipEventSynchronize(ov.aux_mark));
-        ov.aux_busy = false;
-    } else {
-        ML_HIP(hipStreamWaitEvent(ctx->stream, ov.aux_mark, 0));
-    }
-    return ML_OK;
-}
-
 int comm_join(ml_ctx *ctx, bool host) {
-    ML_TRY(pipeline_join(ctx, host));
     if (!ctx->reduce_in_flight) return ML_OK;
     // every reduction records reduce_done[slot] behind its power kernel; the latest one is
     // plan.amp_slot's, and the comm stream runs them in order
@@ -218,10 +185,7 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     ML_REQUIRE(ctx && id, "NULL argument");
     ML_REQUIRE(n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad rank %d of %d", rank, n_ranks);
     ML_HIP(hipSetDevice(ctx->device));
-    // the pipelined sweep is a single-GPU mode (its transforms run on the second stream, which is
-    // also where a reduction would go): a communicator switches it off
     ML_TRY(comm_join(ctx, true));
-    ctx->ov.pipeline = 0;
     comm_release(ctx);
     ctx->n_ranks = n_ranks;
     ctx->rank = rank;

@@ -118,6 +118,11 @@ struct TableDesc {
 // (ring_rec: two 16-byte loads per lane),
 //   r_center, period | 2 pi / period, bits: offset of the ring's table in ring_tab (bits 0-39),
 //   bit 40 = the period lies outside its table's period range (nearfield.py:302-305)
+// SIMPLE order sets (every table: ox in {-1, 0, 1}, oy = 0 - nearfield_simple.hip): ring_tab holds
+// CELL BLOCKS instead, complex [ring][i0 < n0 - 1][i1 < n1 - 1][order 3][node 2 x 2][amplitude 4] - the
+// 48 complex a sample in table cell (i0, i1) interpolates from, contiguous (768 bytes: one wave-wide
+// load stages a block), canonical order slots (an order the collection lacks is a block of zeros);
+// bits 0-31 of `bits` = the ring's first BLOCK, bit 32 = the period flag.
 // and about the ring's GRATING COLLECTION, which almost every wave shares among all its lanes: a
 // CollDesc per collection IN USE (dense numbering, ml_upload_layout), held in the kernel arguments
 // so that a wave reads it with scalar loads - the geometry records carry the dense number.
@@ -127,8 +132,21 @@ constexpr int MAX_RING_COLLS = 16;   // grating collections in use by the rings 
 struct CollDesc {
     double uni_ax[6];   // uniform (ux', uy') axes: first, step, 1 / step per axis (flags bit 0)
     int n0, n1, n_orders;
-    int flags;          // bit 0 = axes uniform; from bit 2, two bits per order = ox + 1 (simple order sets)
+    int flags;          // bit 0 = axes uniform
+    // simple order sets (nearfield_simple.hip; CANONICAL order o = 0: (0, 0), 1: (-1, 0), 2: (+1, 0)):
+    double lim0, lim1;  // n0 - 2, n1 - 2: the last table cell per axis
+    int present;        // bit o: canonical order o is in the collection's data
+    int order_of;       // 4 bits per canonical order: its index in the collection's own order list
+                        // (the `order` of a bound-violation report)
 };
+constexpr int SIMPLE_ORDERS = 3;                       // canonical orders of a simple order set
+constexpr int CELL_BLOCK = SIMPLE_ORDERS * 16;         // complex per (ring, table cell) block: [order][node 2 x 2][amplitude 4]
+// centre table, simple order sets: complex [order 3][i0 < n0 - 1][i1 < n1 - 1][group of 20 types][node 2 x 2][amplitude 4][20]
+// - per order, table cell and group of CENTER_GROUP cell types the 16 x 20 complex the samples of that
+// cell and group interpolate from, contiguous (5 KiB: five wave-wide loads stage a block); types past
+// the table's K are zeros
+constexpr int CENTER_GROUP = 20;                       // (the reference's default K, lens_center.py:28)
+constexpr int CENTER_BLOCK = 16 * CENTER_GROUP;        // complex per centre block
 
 struct TableSlot {
     bool present = false;
@@ -241,44 +259,6 @@ struct FarfieldPlan {
     double unfold_alpha[4] = {0, 0, 0, 0};
 };
 
-// The banded step (ml_step_overlap, nearfield.hip / farfield.hip): the aperture rows are cut
-// into `bands` bands of whole patch rows; the synthesis of band b + 1 (bound by fp64 issue) runs
-// beside the row transform of band b (bound by the LDS pipe and its barriers) on a second stream.
-struct Overlap {
-    int bands = 0;          // 0 / 1: off
-    int wpb = 4;            // waves per synthesis workgroup (1 or 4, nearfield_fast.hip)
-    int lean = 1;           // row transform: the <= 128-VGPR kernel
-    int fft_per_cu = 1;     // ... and its workgroups per CU
-    int same_stream = 0;    // measurement aid: the banded launches back to back on ONE stream
-    hipStream_t aux = nullptr;
-    std::vector<hipEvent_t> band_done;     // synthesis of band b is queued up to here
-    hipEvent_t s1_done = nullptr;
-    // band b = listed patches [first[b], first[b + 1]) = aperture rows [row[b], row[b + 1])
-    std::vector<int> first, row;
-    long key[6] = {-1, -1, -1, -1, -1, -1};   // geo_key + (bands, n_active) the table was built for
-    bool live = false;      // the resident fields were synthesised in bands (events valid)
-    int live_rows = 0;
-    // The PIPELINED sweep (ml_step_pipeline): consecutive steps overlap instead of the bands of one
-    // step.  Syntheses stay on the main stream and alternate between two field buffers; transforms
-    // and projections run on `aux`; step k + 1's synthesis waits for the transform that last read
-    // its buffer (two steps back), step k's transform for step k's synthesis.
-    int pipeline = 0;
-    int buf = 0;                               // buffer the last synthesis wrote
-    hipEvent_t main_mark = nullptr, aux_mark = nullptr, xf_done[2] = {nullptr, nullptr};
-    bool xf_valid[2] = {false, false};
-    bool aux_busy = false;                     // work queued on aux since the last host join
-};
-
-// transforms and projections of a pipelined sweep are queued on the second stream: everything
-// below the entry point launches on ctx->stream, so it is pointed there for the duration
-struct AuxStreamScope {
-    ml_ctx *ctx;
-    hipStream_t saved = nullptr;
-    bool on = false;
-    int enter(ml_ctx *c);
-    ~AuxStreamScope();
-};
-
 }  // namespace ml
 
 struct ml_ctx {
@@ -310,7 +290,8 @@ struct ml_ctx {
     ml::CollDesc h_coll[ml::MAX_RING_COLLS] = {};
     std::vector<ml::TableDesc> h_table_desc;                   // host copy of table_desc
     ml::DevBuf ring_tab, ring_ok, ring_ok_off;   // fast-kernel per-ring tables (offsets into ring_tab: ring_rec)
-    ml::DevBuf center_qmajor;                                  // fast-kernel centre table     // per-ring location on the table's period axis
+    ml::DevBuf center_qmajor;                                  // fast-kernel centre table [order][n0][n1][4][K]
+    int center_present = 0, center_order_of = 0;               // simple order sets: as CollDesc::present / order_of
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     ml::DevBuf ring_lutrec;          // fast kernel: coarser buckets that carry the boundaries
     int lutrec_buckets = 0;
@@ -325,9 +306,6 @@ struct ml_ctx {
     // batch); the far-field and download entry points work on set `field_set`
     int nx = 0, ny = 0, n_sets = 1, field_set = 0;
     ml::DevBuf fields;
-    // the other field buffer of a pipelined sweep and the zero_key that goes with it
-    ml::DevBuf fields_alt;
-    long zero_key_alt[6] = {0, -1, -1, -1, -1, -1};
     double *set_ptr() const {
         return reinterpret_cast<double *>(fields.p) + (size_t)field_set * 4 * nx * ny * 2;
     }
@@ -382,7 +360,6 @@ struct ml_ctx {
 
     ml::FarfieldPlan plan;
     ml::Profile prof;
-    ml::Overlap ov;
 
     // RCCL.  comm_stream carries the all-reduce of the projected amplitudes and the power kernel
     // behind it; amp_ready[s] / reduce_done[s] order it against the main stream per amplitude slot
@@ -454,7 +431,6 @@ struct ZfftCall {
     const int *kbin;
     double alpha[4];
     int alpha_rb, rows, accumulate;
-    int lean = 0, lean_per_cu = 1;   // pass 1 only: the <= 128-VGPR kernel, workgroups per CU
     int passes = 0;                  // > 1: the pass-split kernel (0: the library's default)
 };
 int zfft_split(int N_eff);   // sub-sequences a lattice of N_eff samples is transformed in (0: none)

@@ -164,6 +164,16 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     // (v[..., i2] * (1 - t2) + v[..., i2 + 1] * t2), complex [order][n0][n1][4], and the
     // per-ring order wavenumbers ox*2*pi/grating_period, oy*2*pi/lateral_period
     // (nearfield.py:268-269: per-sample expressions of per-ring constants).
+    // SIMPLE order sets: cell blocks (common.h) - per ring and table cell the 48 complex a sample in
+    // that cell interpolates from, contiguous, orders in canonical slots.  tab_off counts BLOCKS then.
+    const bool simple = ctx->simple_orders;
+    auto canon_slots = [](const TableSlot &t, int *slot_of) {   // canonical order -> index in t's list, -1: absent
+        slot_of[0] = slot_of[1] = slot_of[2] = -1;
+        for (int o = 0; o < t.n_orders; ++o) {
+            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
+            slot_of[ox == 0 ? 0 : ox < 0 ? 1 : 2] = o;
+        }
+    };
     std::vector<long long> tab_off(ctx->n_rings);
     std::vector<int32_t> ok_off(ctx->n_rings);
     size_t tab_total = 0, ok_total = 0;
@@ -171,16 +181,37 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
         tab_off[r] = (long long)tab_total;
         ok_off[r] = (int32_t)ok_total;
-        tab_total += (size_t)t.n_orders * t.n0 * t.n1 * 4;
+        tab_total += simple ? (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0)
+                            : (size_t)t.n_orders * t.n0 * t.n1 * 4;
         ok_total += (size_t)t.n_orders * 4;
     }
-    std::vector<double> tab(tab_total * 2), ok(ok_total);
+    if (simple) ML_REQUIRE(tab_total < (1ull << 31), "ring tables of %zu cell blocks: too large", tab_total);
+    std::vector<double> tab(tab_total * 2 * (simple ? CELL_BLOCK : 1)), ok(ok_total);
     for (int r = 0; r < ctx->n_rings; ++r) {
         const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
         const double w1 = t2[r], w0 = 1 - t2[r];
+        if (simple) {
+            int slot_of[SIMPLE_ORDERS];
+            canon_slots(t, slot_of);
+            double *dst = tab.data() + (size_t)tab_off[r] * CELL_BLOCK * 2;
+            for (int c0 = 0; c0 < t.n0 - 1; ++c0)
+                for (int c1 = 0; c1 < t.n1 - 1; ++c1)
+                    for (int oc = 0; oc < SIMPLE_ORDERS; ++oc)
+                        for (int nd = 0; nd < 4; ++nd) {
+                            const int a = (c0 + (nd >> 1)) * t.n1 + c1 + (nd & 1);
+                            if (slot_of[oc] < 0) {
+                                for (int q = 0; q < 8; ++q) *dst++ = 0.0;
+                                continue;
+                            }
+                            const double *lo = t.h_values.data() +
+                                               ((((size_t)slot_of[oc] * t.n0 * t.n1 + a) * t.n2 + i2[r]) * 4) * 2;
+                            const double *hi = lo + 8;
+                            for (int q = 0; q < 8; ++q) *dst++ = lo[q] * w0 + hi[q] * w1;
+                        }
+        }
         double *dst = tab.data() + (size_t)tab_off[r] * 2;
         for (int o = 0; o < t.n_orders; ++o) {
-            for (int a = 0; a < t.n0 * t.n1; ++a) {
+            for (int a = 0; !simple && a < t.n0 * t.n1; ++a) {
                 const double *lo = t.h_values.data() +
                                    ((((size_t)o * t.n0 * t.n1 + a) * t.n2 + i2[r]) * 4) * 2;
                 const double *hi = lo + 8;
@@ -209,9 +240,17 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         C.n1 = t.n1;
         C.n_orders = t.n_orders;
         C.flags = d.uniform ? 1 : 0;
-        for (int o = 0; o < std::min(t.n_orders, 15); ++o) {
-            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
-            C.flags |= (int32_t)((ox + 1) & 3) << (2 + 2 * o);
+        C.lim0 = t.n0 - 2;
+        C.lim1 = t.n1 - 2;
+        C.present = C.order_of = 0;
+        if (simple) {
+            int slot_of[SIMPLE_ORDERS];
+            canon_slots(t, slot_of);
+            for (int oc = 0; oc < SIMPLE_ORDERS; ++oc)
+                if (slot_of[oc] >= 0) {
+                    C.present |= 1 << oc;
+                    C.order_of |= slot_of[oc] << (4 * oc);
+                }
         }
         for (int k = 0; k < 4; k += 2) {   // a NaN bound leaves the range empty: every sample then reads its own
             ctx->ring_bounds_all[k] = t.bounds[k] >= ctx->ring_bounds_all[k] ? t.bounds[k]
@@ -230,7 +269,8 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         long long bits = tab_off[r];
         // the ring's period outside its table's period range: every evaluated sample of the ring
         // reports (nearfield.py:302-305)
-        if (ctx->h_ring_period[r] < t.bounds[4] || ctx->h_ring_period[r] > t.bounds[5]) bits |= 1ll << 40;
+        if (ctx->h_ring_period[r] < t.bounds[4] || ctx->h_ring_period[r] > t.bounds[5])
+            bits |= 1ll << (simple ? 32 : 40);
         memcpy(q + 3, &bits, 8);
     }
     ML_TRY(h2d(ctx, ctx->ring_rec, rec.data(), rec.size() * sizeof(double)));
@@ -240,8 +280,41 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     // centre table for the fast kernel: [order][n0][n1][4][K] instead of [order][n0][n1][K][4],
     // so that the K cell types of one amplitude are contiguous (lanes of a wave hold many
     // different cell types; this way one load instruction touches 3 cache lines, not 12)
+    // Simple order sets: CELL BLOCKS (common.h CENTER_BLOCK) - complex [order 3][i0][i1][group][node 4][amplitude 4][20]:
+    // orders in canonical slots (zeros for an order the set lacks), per table cell and group of 20 cell
+    // types the 320 complex its samples interpolate from, contiguous.
     std::vector<double> cq;
-    if (ctx->center.present) {
+    ctx->center_present = ctx->center_order_of = 0;
+    if (ctx->center.present && simple) {
+        const TableSlot &t = ctx->center;
+        int slot_of[SIMPLE_ORDERS];
+        canon_slots(t, slot_of);
+        const int groups = (t.n2 + CENTER_GROUP - 1) / CENTER_GROUP;
+        const size_t cells = (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0);
+        cq.assign((size_t)SIMPLE_ORDERS * cells * groups * CENTER_BLOCK * 2, 0.0);
+        for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
+            const int o = slot_of[oc];
+            if (o < 0) continue;
+            ctx->center_present |= 1 << oc;
+            ctx->center_order_of |= o << (4 * oc);
+            for (int c0 = 0; c0 < t.n0 - 1; ++c0)
+                for (int c1 = 0; c1 < t.n1 - 1; ++c1)
+                    for (int g = 0; g < groups; ++g) {
+                        double *blk = cq.data() + ((((size_t)oc * cells + (size_t)c0 * (t.n1 - 1) + c1) * groups + g) * CENTER_BLOCK) * 2;
+                        for (int nd = 0; nd < 4; ++nd) {
+                            const size_t node = ((size_t)o * t.n0 + c0 + (nd >> 1)) * t.n1 + c1 + (nd & 1);
+                            for (int q = 0; q < 4; ++q)
+                                for (int k = g * CENTER_GROUP; k < std::min(t.n2, (g + 1) * CENTER_GROUP); ++k) {
+                                    const double *src = t.h_values.data() + ((node * t.n2 + k) * 4 + q) * 2;
+                                    double *dst = blk + ((size_t)(nd * 4 + q) * CENTER_GROUP + (k - g * CENTER_GROUP)) * 2;
+                                    dst[0] = src[0];
+                                    dst[1] = src[1];
+                                }
+                        }
+                    }
+        }
+        ML_TRY(h2d(ctx, ctx->center_qmajor, cq.data(), cq.size() * sizeof(double)));
+    } else if (ctx->center.present) {
         const TableSlot &t = ctx->center;
         const size_t nodes = (size_t)t.n_orders * t.n0 * t.n1;
         cq.resize(nodes * t.n2 * 4 * 2);
@@ -469,14 +542,6 @@ void ml_ctx_destroy(ml_ctx *ctx) {
         }
         (void)hipStreamDestroy(ctx->comm_stream);
     }
-    if (ctx->ov.aux) {
-        (void)hipStreamSynchronize(ctx->ov.aux);
-        for (auto e : ctx->ov.band_done) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {ctx->ov.s1_done, ctx->ov.main_mark, ctx->ov.aux_mark, ctx->ov.xf_done[0], ctx->ov.xf_done[1]})
-            if (e) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(ctx->ov.aux);
-    }
-    ctx->fields_alt.release();
     for (auto &s : ctx->slots) {
         s.axis0.release();
         s.axis1.release();
@@ -811,23 +876,14 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
     ML_TRY(grid_axis(ctx->x_pts, ctx->h_x_pts, x_pts, nx));
     ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
-    if (ctx->ov.pipeline && n == 1) {
-        // pipelined sweep: this synthesis writes the OTHER field buffer, once the transform that
-        // read it two steps ago is through
-        Overlap &ov = ctx->ov;
-        std::swap(ctx->fields, ctx->fields_alt);
-        for (int k = 0; k < 6; ++k) std::swap(ctx->zero_key[k], ctx->zero_key_alt[k]);
-        ov.buf ^= 1;
-        if (ov.xf_valid[ov.buf]) ML_HIP(hipStreamWaitEvent(ctx->stream, ov.xf_done[ov.buf], 0));
-    }
     ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
     ctx->n_sets = n;
     ctx->field_set = 0;
-    // one power partial per wave (8 x 8 samples)
+    // four power partials per wave (8 x 8 samples: one per row of sixteen lanes, nearfield_dev.h wave_power)
     const int blocks = ((ny + 7) / 8) * ((nx + 7) / 8);
-    ML_TRY(ctx->partial_power.reserve((size_t)n * blocks * sizeof(double)));
+    ML_TRY(ctx->partial_power.reserve((size_t)n * blocks * 4 * sizeof(double)));
     ML_TRY(ctx->power.reserve((size_t)n * POWER_GROUPS * sizeof(double)));
     // two halves: each synthesis launch clears the one the next launch reports into
     const size_t viol_bytes = (size_t)2 * (MAX_SLOTS + 1) * MAX_ORDERS * 6 * sizeof(unsigned long long);
@@ -1044,7 +1100,6 @@ int ml_fields_upload(ml_ctx *ctx, int nx, int ny, const double *Ex, const double
     ctx->n_sets = 1;
     ctx->field_set = 0;
     ctx->zero_key[1] = -1;          // caller-supplied fields: nothing known about zeros
-    ctx->ov.live = false;           // ... nor are they a banded synthesis
     ctx->row_first_valid = false;
     return ML_OK;
 }

@@ -839,17 +839,6 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     }
     ML_REQUIRE(!accumulate || pl.have_vectors, "accumulate requested but nothing to add to");
     ML_HIP(hipSetDevice(ctx->device));
-    AuxStreamScope aux_scope;             // pipelined sweep: queued on the second stream
-    ML_TRY(aux_scope.enter(ctx));
-    struct BufferRelease {                // ... and the field buffer is free again once this is through
-        ml_ctx *c;
-        bool on;
-        ~BufferRelease() {
-            if (!on) return;
-            Overlap &ov = c->ov;
-            if (hipEventRecord(ov.xf_done[ov.buf], c->stream) == hipSuccess) ov.xf_valid[ov.buf] = true;
-        }
-    } release{ctx, aux_scope.on};
     // a deferred unfold of the previous transform: needed if this one adds to it, moot otherwise
     if (accumulate)
         ML_TRY(flush_unfold(ctx));
@@ -943,11 +932,6 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             for (int k = 0; k < 4; ++k) c.alpha[k] = 1.0;
             c.alpha_rb = c.rows;
             c.accumulate = 0;
-            Overlap &ov = ctx->ov;
-            if (ov.pipeline) {   // beside the next step's synthesis: the register-lean kernel
-                c.lean = ov.lean;
-                c.lean_per_cu = ov.fft_per_cu;
-            }
             if (split1 > 1) {
                 // two-level: sub-sequence i of every row adds its bins (zfft.hip zfft_split)
                 for (int i = 0; i < split1; ++i) {
@@ -956,35 +940,6 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
                     c.pj = pl.fft_y.pj.as<double>() + (size_t)i * my * 2;
                     c.accumulate = i > 0;
                     ML_TRY(zfft_run(ctx->stream, c));
-                }
-            } else if (ov.live && ov.live_rows == nxl && ov.bands > 1 && (int)ov.row.size() == ov.bands + 1) {
-                // the banded step: band b's rows as soon as its synthesis is through, on the second
-                // stream, beside the synthesis of the bands behind it (nearfield.hip banded_launch)
-                for (int b = 0; b < ov.bands; ++b) {
-                    const int r0 = ov.row[b], nb = ov.row[b + 1] - r0;
-                    if (nb <= 0) continue;
-                    hipStream_t s1 = ov.same_stream ? ctx->stream : ov.aux;
-                    if (!ov.same_stream) ML_HIP(hipStreamWaitEvent(ov.aux, ov.band_done[b], 0));
-                    ZfftCall cb = c;
-                    cb.in = ctx->set_ptr() + (size_t)r0 * ny * 2;
-                    cb.rows = 4 * nb;
-                    cb.in_rb = nb;
-                    cb.in_s1 = (int64_t)nxl * ny;
-                    cb.in_s2 = ny;
-                    cb.row_first = c.row_first ? c.row_first + r0 : nullptr;
-                    cb.rf_mod = nb;
-                    cb.out = pl.stage1.as<double>() + (size_t)r0 * my * 2;
-                    cb.out_rb = nb;
-                    cb.out_s1 = (int64_t)nxl * my;
-                    cb.out_s2 = my;
-                    cb.alpha_rb = cb.rows;
-                    cb.lean = ov.lean;
-                    cb.lean_per_cu = ov.fft_per_cu;
-                    ML_TRY(zfft_run(s1, cb));
-                }
-                if (!ov.same_stream) {
-                    ML_HIP(hipEventRecord(ov.s1_done, ov.aux));
-                    ML_HIP(hipStreamWaitEvent(ctx->stream, ov.s1_done, 0));
                 }
             } else {
                 ML_TRY(zfft_run(ctx->stream, c));
@@ -1212,8 +1167,6 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream =
         return ML_ESTATE;
     }
     ML_HIP(hipSetDevice(ctx->device));
-    AuxStreamScope aux_scope;             // pipelined sweep: behind its transform on the second stream
-    if (!stream) ML_TRY(aux_scope.enter(ctx));
     const int mx = pl.mx, my = pl.pair_list ? 1 : pl.my;
     const size_t n = (size_t)mx * my;
     ProjArgs a;
@@ -1474,59 +1427,6 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
     return ML_OK;
 }
 
-int ml_step_overlap(ml_ctx *ctx, int bands, int nf_waves_per_block, int fft_lean, int fft_per_cu,
-                    int same_stream) {
-    ML_REQUIRE(ctx, "ctx is NULL");
-    ML_REQUIRE(bands >= 0 && bands <= 256, "bands = %d (0 / 1 = off, at most 256)", bands);
-    ML_REQUIRE(nf_waves_per_block == 1 || nf_waves_per_block == 4, "synthesis workgroups have 1 or 4 waves");
-    ML_REQUIRE(fft_per_cu >= 1 && fft_per_cu <= 4, "1 to 4 transform workgroups per CU");
-    ML_HIP(hipSetDevice(ctx->device));
-    // a banded step in flight keeps using the old table: wait for it
-    ML_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->ov.aux) ML_HIP(hipStreamSynchronize(ctx->ov.aux));
-    if (bands > 1) {
-        ML_TRY(comm_join(ctx, true));
-        ctx->ov.pipeline = 0;
-    }
-    ctx->ov.bands = bands;
-    ctx->ov.wpb = nf_waves_per_block;
-    ctx->ov.lean = fft_lean ? 1 : 0;
-    ctx->ov.fft_per_cu = fft_per_cu;
-    ctx->ov.same_stream = same_stream ? 1 : 0;
-    ctx->ov.live = false;
-    return ML_OK;
-}
-
-int ml_step_pipeline(ml_ctx *ctx, int on, int nf_waves_per_block, int fft_lean, int fft_per_cu) {
-    ML_REQUIRE(ctx, "ctx is NULL");
-    ML_REQUIRE(nf_waves_per_block == 1 || nf_waves_per_block == 4, "synthesis workgroups have 1 or 4 waves");
-    ML_REQUIRE(fft_per_cu >= 1 && fft_per_cu <= 4, "1 to 4 transform workgroups per CU");
-    ML_REQUIRE(!on || (!ctx->comm && !ctx->comm_file), "the pipelined sweep is a single-GPU mode");
-    ML_HIP(hipSetDevice(ctx->device));
-    ML_TRY(comm_join(ctx, true));
-    ML_HIP(hipStreamSynchronize(ctx->stream));
-    Overlap &ov = ctx->ov;
-    if (on && !ov.aux) {
-        ML_HIP(hipStreamCreateWithFlags(&ov.aux, hipStreamNonBlocking));
-        ML_HIP(hipEventCreateWithFlags(&ov.s1_done, hipEventDisableTiming));
-    }
-    if (on && !ov.main_mark) {
-        ML_HIP(hipEventCreateWithFlags(&ov.main_mark, hipEventDisableTiming));
-        ML_HIP(hipEventCreateWithFlags(&ov.aux_mark, hipEventDisableTiming));
-        for (int k = 0; k < 2; ++k) ML_HIP(hipEventCreateWithFlags(&ov.xf_done[k], hipEventDisableTiming));
-    }
-    ov.pipeline = on ? 1 : 0;
-    if (on) {
-        ov.bands = 0;
-        ov.wpb = nf_waves_per_block;
-        ov.lean = fft_lean ? 1 : 0;
-        ov.fft_per_cu = fft_per_cu;
-    }
-    ov.live = false;
-    ov.xf_valid[0] = ov.xf_valid[1] = false;
-    return ML_OK;
-}
-
 int ml_farfield_set_method(ml_ctx *ctx, int method) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_REQUIRE(method == ML_METHOD_AUTO || method == ML_METHOD_GEMM, "unknown method %d", method);
@@ -1548,14 +1448,9 @@ int ml_farfield_set_precision(ml_ctx *ctx, int precision) {
     return ML_OK;
 }
 
-int ml_farfield_download_impl(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly);
 int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_TRY(comm_join(ctx, false));
-    return ml_farfield_download_impl(ctx, Nx, Ny, Lx, Ly);
-}
-int ml_farfield_download_impl(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double *Ly) {
-    ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready || !pl.have_vectors) {
         set_error("no radiation vectors to download");

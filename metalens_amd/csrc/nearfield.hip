@@ -19,10 +19,6 @@
 
 namespace ml {
 
-#ifndef NF_MODE_DEFAULT
-#define NF_MODE_DEFAULT 0
-#endif
-
 // Per aperture row: how far from the row's two ends the first sample inside the lens is,
 // min(j, ny-1-j).  Samples outside the lens are exactly zero, so the far-field GEMM skips that
 // outer part of each row (zfold.hip).  Inside-the-lens is the kernels' own test
@@ -85,12 +81,18 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.p = p[0];
     a.n_pol = n;
     a.e_from_h = p[0].Z0 * (1.0 / p[0].n_glass) * (1.0 / p[0].k_glass);
-    a.n_partials = ((ny + 7) / 8) * ((nx + 7) / 8);
+    a.n_partials = 4 * ((ny + 7) / 8) * ((nx + 7) / 8);   // four per 8 x 8 patch (wave_power)
     for (int m = 0; m < MAX_POL; ++m) {
         const ml_nearfield_params &q = p[m < n ? m : 0];
         for (int k = 0; k < 3; ++k) a.pol[m][k] = q.pol[k];
         a.hcoef[m] = q.H_coef;
         a.dmom[m] = q.dipole_moment;
+        // nearfield.py:225-228, the reference's own expressions (this file is compiled without contraction)
+        const double Ex_i = q.pol[0] * q.dipole_moment, Ey_i = q.pol[1] * q.dipole_moment;
+        a.pw_Hx[m] = -q.pol[1] * q.dipole_moment / q.Z0;
+        a.pw_Hy[m] = q.pol[0] * q.dipole_moment / q.Z0;
+        a.pw_power[m] = Ex_i * a.pw_Hy[m] - Ey_i * a.pw_Hx[m];
+        a.pcoef[m] = q.Z0 * q.H_coef * q.H_coef;
     }
     a.x_pts = ctx->x_pts.as<double>();
     a.y_pts = ctx->y_pts.as<double>();
@@ -163,6 +165,8 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.n_active = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;
+    a.center_present = ctx->center_present;
+    a.center_order_of = ctx->center_order_of;
     for (int k = 0; k < 4; ++k) a.ring_bounds_all[k] = ctx->ring_bounds_all[k];
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();
@@ -176,48 +180,6 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
                         pl.fold_has_E && pl.ny == ny;
     a.premod = premod ? pl.fold_E.as<double2>() : nullptr;
     ctx->fields_premod_serial = premod ? pl.serial : -1;
-}
-
-// The synthesis half of the banded step (common.h Overlap): one launch per band of patch rows on
-// the main stream, an event behind each; farfield.hip's stage 1 picks the events up on the second
-// stream.  The band table (where each band starts in the list of active patches) is read back
-// once per (geometry, band count): the list is in patch order.
-static int banded_launch(ml_ctx *ctx, const NfArgs &a, int nx, int ny, const long *geo_key) {
-    Overlap &ov = ctx->ov;
-    const int B = ov.bands, P = (nx + 7) / 8;
-    if (!ov.aux) {
-        ML_HIP(hipStreamCreateWithFlags(&ov.aux, hipStreamNonBlocking));
-        ML_HIP(hipEventCreateWithFlags(&ov.s1_done, hipEventDisableTiming));
-    }
-    while ((int)ov.band_done.size() < B) {
-        hipEvent_t e;
-        ML_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        ov.band_done.push_back(e);
-    }
-    const long key[6] = {geo_key[0], geo_key[1], geo_key[2], geo_key[3], B, a.n_active};
-    if (memcmp(key, ov.key, sizeof key) != 0) {
-        std::vector<int2> list((size_t)a.n_active);
-        ML_HIP(hipMemcpyAsync(list.data(), a.active_list, list.size() * sizeof(int2), hipMemcpyDeviceToHost,
-                              ctx->stream));
-        ML_HIP(hipStreamSynchronize(ctx->stream));
-        ov.first.assign(B + 1, 0);
-        ov.row.assign(B + 1, 0);
-        size_t at = 0;
-        for (int b = 0; b <= B; ++b) {
-            const int pr = (int)((long long)P * b / B);   // first patch row of band b
-            while (at < list.size() && list[at].y < pr) ++at;
-            ov.first[b] = b == B ? a.n_active : (int)at;
-            ov.row[b] = std::min(8 * pr, nx);
-        }
-        memcpy(ov.key, key, sizeof key);
-    }
-    for (int b = 0; b < B; ++b) {
-        ML_TRY(nearfield_band_launch(ctx->stream, a, ov.first[b], ov.first[b + 1] - ov.first[b], ov.wpb));
-        ML_HIP(hipEventRecord(ov.band_done[b], ctx->stream));
-    }
-    ov.live = true;
-    ov.live_rows = nx;
-    return ML_OK;
 }
 
 int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny) {
@@ -236,11 +198,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     // the per-sample records depend on the grid, the layout and the tie answers: rebuilt when one
     // of them changes (the samples the kernel cannot settle are counted from zero each time)
     const long geo_key[4] = {ctx->grid_serial, ctx->layout_serial, ctx->ovr_serial, (long)nx * ny};
-    static const int nf_mode = diag_int("ML_NF_MODE", NF_MODE_DEFAULT);   // 0 records, 1 fused
-    if (nf_mode == 1) {
-        a.geo_ix = nullptr;
-        ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
-    } else if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
+    if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
         ProfScope scope(ctx, ML_K_TWIDDLE);
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
         ML_TRY(nearfield_geometry_launch(ctx, a));
@@ -254,7 +212,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     const long zero_key[6] = {(long)(intptr_t)ctx->fields.p, (long)ctx->fields.bytes, n, (long)nx * ny,
                               ctx->grid_serial, ctx->layout_serial};
     a.outside_is_zero = !plan_cache_disabled() && memcmp(zero_key, ctx->zero_key, sizeof zero_key) == 0;
-    if (a.outside_is_zero && nf_mode != 1) {
+    if (a.outside_is_zero) {
         // ... and then only the patches that hold lens samples are launched at all.  Their
         // number comes back from the GPU once per geometry (a 4-byte copy, one synchronisation);
         // the power partials of the others stay at the zeros written here.
@@ -271,19 +229,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     }
     {
         ProfScope scope(ctx, ML_K_NEARFIELD);
-        if (a.use_active && n == 1 && ctx->ov.pipeline && nf_mode != 1) {
-            // pipelined sweep: the listed patches as four-wave workgroups (they let the transform of
-            // the previous step, which runs beside this launch, into the CUs - nearfield_fast.hip)
-            ctx->ov.live = false;
-            ML_TRY(nearfield_band_launch(ctx->stream, a, 0, a.n_active, ctx->ov.wpb));
-            n_partials = a.n_partials;
-        } else if (a.use_active && n == 1 && ctx->ov.bands > 1 && nf_mode != 1) {
-            ML_TRY(banded_launch(ctx, a, nx, ny, geo_key));
-            n_partials = a.n_partials;
-        } else {
-            ctx->ov.live = false;
-            ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
-        }
+        ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
     }
     memcpy(ctx->zero_key, zero_key, sizeof zero_key);
     ML_HIP(hipGetLastError());
@@ -292,9 +238,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     ctx->power_pending = true;
     // a batch sums the partials of all its members now (the projection kernel's spare block,
     // which does it for free in the single-source pipeline, knows one set only)
-    // ... and so does a pipelined sweep: the next synthesis overwrites the partials while this
-    // step's projection is still waiting on the second stream
-    if (n > 1 || ctx->ov.pipeline) ML_TRY(power_flush(ctx));
+    if (n > 1) ML_TRY(power_flush(ctx));
     return ML_OK;
 }
 

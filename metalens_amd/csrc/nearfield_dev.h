@@ -14,6 +14,7 @@ __device__ __forceinline__ c2 cmul(c2 a, c2 b) {
 }
 __device__ __forceinline__ c2 scale(c2 a, double s) { return {a.r * s, a.i * s}; }
 
+constexpr int REC_TYPE_SHIFT = 20;   // geometry records: cell type (centre) / collection (rings) above the ring index (rings < 2^19, ctx.hip)
 constexpr int MAX_POL = 3;   // members of a polarisation batch (three span every orientation)
 
 struct NfArgs {
@@ -23,6 +24,10 @@ struct NfArgs {
     int n_pol, n_partials;
     double pol[MAX_POL][3], hcoef[MAX_POL], dmom[MAX_POL];
     double e_from_h;   // Z0 / (n_glass k_glass): the source-independent part of the E-from-H factors
+    // per member, worked out on the host (nearfield_simple.hip):
+    //   plane wave (nearfield.py:223-228): incident H along x, y and Ex Hy - Ey Hx, constants of the launch;
+    //   dipole: Z0 H_coef^2, the constant of the incident power density Z0 uz |H|^2
+    double pw_Hx[MAX_POL], pw_Hy[MAX_POL], pw_power[MAX_POL], pcoef[MAX_POL];
     const double *x_pts, *y_pts;
     int nx, ny;
     // rings
@@ -88,6 +93,7 @@ struct NfArgs {
     // every table of the lens holds orders ox = -1, 0, 1 with oy = 0 only: the kernels that build
     // an order's phasor by one product run (nearfield_fast.hip order_phasor), else the general ones
     int simple_orders;
+    int center_present, center_order_of;   // centre table, simple order sets: as CollDesc::present / order_of
     // the (ux', uy') range every ring table covers (intersection of their bounds: lo0, hi0, lo1, hi1);
     // a sample inside it cannot trip a table bound, and only the others read their ring's own bounds
     double ring_bounds_all[4];
@@ -403,22 +409,20 @@ __device__ __forceinline__ double dpp_add(double v) {
     return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-// incident power: one partial per wave (= per workgroup), no barrier; fixed order downstream.
-// The wave's sum by data-parallel-primitive moves (row_shr 1, 2, 4, 8, then row_bcast 15 and 31:
-// eighteen operations, the total in lane 63) - six rounds of __shfl_down are twelve trips through
-// the LDS crossbar, each waited for, in a kernel whose waves have nothing else to wait with.
+// incident power: FOUR partials per wave (= per 8 x 8 patch), one per row of sixteen lanes, no
+// barrier; fixed order downstream.  The row sums by data-parallel-primitive moves (row_shr 1, 2,
+// 4, 8: twelve operations, the sums in lanes 15, 31, 47, 63, which store them side by side) -
+// the two row_bcast steps that would make one number of them cost ten operations more per wave
+// than the spare block of the projection kernel pays for summing four times as many partials.
 __device__ __forceinline__ void wave_power(const NfArgs &a, double power_here, int bx, int by, int member) {
     power_here = dpp_add<0x111, 0xf>(power_here);
     power_here = dpp_add<0x112, 0xf>(power_here);
     power_here = dpp_add<0x114, 0xf>(power_here);
     power_here = dpp_add<0x118, 0xf>(power_here);
-    power_here = dpp_add<0x142, 0xa>(power_here);
-    power_here = dpp_add<0x143, 0xc>(power_here);
-    if ((threadIdx.x & 63) == 63)
-        a.partial_power[(size_t)member * a.n_partials + (size_t)by * a.patches_x + bx] = power_here;
-    // (workgroup 0 exists in the full and in the listed grid alike; wave 0 of it clears the keys.
-    // The bands of a banded synthesis each clear them again, which is harmless: nobody writes
-    // the other half during this launch)
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 15)
+        a.partial_power[(size_t)member * a.n_partials + ((size_t)by * a.patches_x + bx) * 4 + (lane >> 4)] = power_here;
+    // (workgroup 0 exists in the full and in the listed grid alike; wave 0 of it clears the keys)
     if (blockIdx.x == 0 && blockIdx.y == 0 && member == 0 && threadIdx.x < 64)
         for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
 }
@@ -440,8 +444,8 @@ __device__ __forceinline__ void store_fields(const NfArgs &a, int member, int i,
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a);
 // writes the number of per-block power partials it produces to *n_partials
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
-// one band of the banded step (hotpath.hip): listed patches [first, first + count)
-int nearfield_band_launch(hipStream_t stream, const NfArgs &a, int first, int count, int wpb);
+// nearfield_simple.hip: the kernels of the round lens' order set (ox in {-1, 0, 1}, oy = 0)
+int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid);
 // the source-independent records of the current (grid, layout, tie answers)
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a);
 

@@ -21,95 +21,10 @@
 //   * use one reciprocal per sample and a branch-free Cody-Waite sin/cos.
 #include <algorithm>
 
-#include "nearfield_dev.h"
+#include "nearfield_math.h"
 
 namespace ml {
 
-// sin and cos of x for |x| < ~1e9: three-constant Cody-Waite reduction with FMA (each step
-// rounds once, relative to the already small remainder), fdlibm kernel polynomials.
-// Horner step p = z * p + C with the constant in a SCALAR register pair: written as plain C++ the
-// compiler materialises every fp64 coefficient with two v_mov_b32 in front of a v_fmac (3 vector
-// instructions per step, ~100 extra per sample over the four sincos of a sample); an SGPR
-// operand costs two scalar moves instead, which issue beside the vector stream.
-__device__ __forceinline__ double horner(double z, double p, double C) {
-    asm("v_fma_f64 %0, %1, %0, %2" : "+v"(p) : "v"(z), "s"(C));
-    return p;
-}
-
-__device__ __forceinline__ void sincos_cw(double x, double &s, double &c) {
-    const double k = rint(x * 0.63661977236758138243);          // 2/pi
-    double r = fma(-k, 1.57079632679489655800e+00, x);          // pi/2 hi
-    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid (a third term, 1.5e-33 k, is
-                                                                // below 1e-27 for the |k| < 1e6 met here)
-    const double z = r * r;
-    double ps = horner(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = horner(z, ps, 2.75573137070700676789e-06);
-    ps = horner(z, ps, -1.98412698298579493134e-04);
-    ps = horner(z, ps, 8.33333333332248946124e-03);
-    ps = horner(z, ps, -1.66666666666666324348e-01);
-    const double sn = fma(z * r, ps, r);
-    double pc = horner(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = horner(z, pc, -2.75573143513906633035e-07);
-    pc = horner(z, pc, 2.48015872894767294178e-05);
-    pc = horner(z, pc, -1.38888888888741095749e-03);
-    pc = horner(z, pc, 4.16666666666666019037e-02);
-    const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
-    const int q = (int)k & 3;
-    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
-    s = (q & 2) ? -a : a;
-    c = ((q + 1) & 2) ? -b : b;
-}
-
-// x = r + k pi/2 with |r| <= pi/4 (two-constant Cody-Waite, as above); k fits an int for the
-// |x| < ~1e9 this kernel meets
-__device__ __forceinline__ void reduce_pio2(double x, double &r, int &k) {
-    const double kd = rint(x * 0.63661977236758138243);
-    r = fma(-kd, 1.57079632679489655800e+00, x);
-    r = fma(-kd, 6.12323399573676603587e-17, r);
-    k = (int)kd;
-}
-
-// sin and cos of x + kq pi/2 (kq = quadrants already split off a larger angle by reduce_pio2)
-__device__ __forceinline__ void sincos_cw_q(double x, int kq, double &s, double &c) {
-    const double k = rint(x * 0.63661977236758138243);          // 2/pi
-    double r = fma(-k, 1.57079632679489655800e+00, x);          // pi/2 hi
-    r = fma(-k, 6.12323399573676603587e-17, r);                 // pi/2 mid (a third term, 1.5e-33 k, is
-                                                                // below 1e-27 for the |k| < 1e6 met here)
-    const double z = r * r;
-    double ps = horner(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = horner(z, ps, 2.75573137070700676789e-06);
-    ps = horner(z, ps, -1.98412698298579493134e-04);
-    ps = horner(z, ps, 8.33333333332248946124e-03);
-    ps = horner(z, ps, -1.66666666666666324348e-01);
-    const double sn = fma(z * r, ps, r);
-    double pc = horner(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = horner(z, pc, -2.75573143513906633035e-07);
-    pc = horner(z, pc, 2.48015872894767294178e-05);
-    pc = horner(z, pc, -1.38888888888741095749e-03);
-    pc = horner(z, pc, 4.16666666666666019037e-02);
-    const double cs = fma(z * z, pc, fma(z, -0.5, 1.0));
-    const int q = ((int)k + kq) & 3;
-    const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
-    s = (q & 2) ? -a : a;
-    c = ((q + 1) & 2) ? -b : b;
-}
-
-// 1 / sqrt(x) to ~1 ulp for well-scaled x (no denormal / overflow handling): hardware estimate
-// (~2^-24) + ONE third-order step, y (1 + e/2 + 3 e^2 / 8) with e = 1 - x y^2 (error ~e^3: five
-// operations where two Newton steps take eight).  Amplitude-type quantities only.
-__device__ __forceinline__ double rsqrt_fast(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-x * y, y, 1.0);
-    return fma(y, e * fma(e, 0.375, 0.5), y);
-}
-
-// Accurate reciprocal (~1 ulp): hardware estimate (~2^-24) + one third-order step y (1 + e + e^2),
-// e = 1 - x y (three operations where two Newton steps take four).
-__device__ __forceinline__ double recip(double x) {
-    const double y = __builtin_amdgcn_rcp(x);
-    const double e = fma(-x, y, 1.0);
-    return fma(y, fma(e, e, e), y);
-}
 
 // arctan2(y, x) to ~2 ulp for finite (x, y) != (0, 0): atan(a) = a Q(a^2) on [0, 1] (degree-20
 // least-squares-at-Chebyshev-nodes fit, 2.6e-17 from atan with these rounded coefficients),
@@ -237,26 +152,6 @@ struct OrderCommon {
     double cxy, cxx, cyy;    // Z0 / (n k_glass kz) x (kx ky, ky^2 + kz^2, -(kx^2 + kz^2))
 };
 
-// The phasor of order (ox, oy) at a sample (nearfield.py:268-269,291 periphery, :391-409 centre):
-//     exp(i ((k u_x' + ox Gx) x' + (k u_y' + oy Gy) y'))  =  E0 * Ex^ox * exp(i oy Gy y')
-// with E0 = exp(i k (u_x' x' + u_y' y')) - the order-(0,0) phase, into which the caller has also
-// folded the propagation phase from the source (one sincos for both) - and Ex = exp(i Gx x').
-// This is the form of the kernels instantiated with GEN = false, chosen when every table of the
-// lens holds orders ox = -1, 0, +1 with oy = 0 only (every order of a round lens' rings that
-// propagates in air): an order then costs at most ONE phasor product instead of a sincos, and a
-// sample two sincos in all instead of one per order + one for the propagation.  Any other order
-// set (|ox| <= 5 in general, grating.lua:406-423; oy != 0 enters with the lateral period) runs the
-// GEN = true kernels, which evaluate every order's argument the reference's way
-// (order_factors_arg) - a sincos inside the order loop costs registers the fast form does not have.
-__device__ __forceinline__ c2 cmulf(c2 a, c2 b) {   // product of two phasors, fused (4 operations)
-    return {fma(a.r, b.r, -(a.i * b.i)), fma(a.r, b.i, a.i * b.r)};
-}
-
-__device__ __forceinline__ c2 order_phasor(c2 E0, c2 Ex, int ox) {   // ox in {-1, 0, 1}
-    const c2 sx = {ox ? Ex.r : 1.0, ox == 0 ? 0.0 : ox < 0 ? -Ex.i : Ex.i};
-    return cmulf(E0, sx);
-}
-
 __device__ __forceinline__ void order_factors(OrderCommon &oc, double kx, double ky, double kz2,
                                               double e_from_h, c2 ph);
 
@@ -307,39 +202,6 @@ __device__ __forceinline__ void order_common_types(OrderCommon &oc, const double
             oc.ar[q] = fma(w[c], v.x, oc.ar[q]);
             oc.ai[q] = fma(w[c], v.y, oc.ai[q]);
         }
-}
-
-// the single-source form: oc.ar[0] / ai[0] = U_fy, oc.ar[1] / ai[1] = U_fx (see order_apply), from the
-// staged block and the interpolation weights already multiplied by the two polarisation weights
-__device__ __forceinline__ void order_common_folded(OrderCommon &oc, const double2 *blk, const double *wfx,
-                                                    const double *wfy) {
-    oc.ar[0] = oc.ai[0] = oc.ar[1] = oc.ai[1] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const double2 v0 = blk[c * 4 + 0], v1 = blk[c * 4 + 1], v2 = blk[c * 4 + 2], v3 = blk[c * 4 + 3];
-        oc.ar[0] = fma(wfx[c], v0.x, oc.ar[0]);
-        oc.ai[0] = fma(wfx[c], v0.y, oc.ai[0]);
-        oc.ar[1] = fma(wfx[c], v1.x, oc.ar[1]);
-        oc.ai[1] = fma(wfx[c], v1.y, oc.ai[1]);
-        oc.ar[0] = fma(wfy[c], v2.x, oc.ar[0]);
-        oc.ai[0] = fma(wfy[c], v2.y, oc.ai[0]);
-        oc.ar[1] = fma(wfy[c], v3.x, oc.ar[1]);
-        oc.ai[1] = fma(wfy[c], v3.y, oc.ai[1]);
-    }
-}
-
-__device__ __forceinline__ void order_apply_folded(Acc &acc, const OrderCommon &oc) {
-    const double ufy_r = oc.ar[0], ufy_i = oc.ai[0], ufx_r = oc.ar[1], ufx_i = oc.ai[1];
-    const double vy_r = fma(ufy_r, oc.cs, -ufy_i * oc.sn), vy_i = fma(ufy_r, oc.sn, ufy_i * oc.cs);
-    const double vx_r = fma(ufx_r, oc.cs, -ufx_i * oc.sn), vx_i = fma(ufx_r, oc.sn, ufx_i * oc.cs);
-    acc.Hx.r += vy_r;
-    acc.Hx.i += vy_i;
-    acc.Hy.r += vx_r;
-    acc.Hy.i += vx_i;
-    acc.Ex.r += fma(oc.cxy, vy_r, oc.cxx * vx_r);
-    acc.Ex.i += fma(oc.cxy, vy_i, oc.cxx * vx_i);
-    acc.Ey.r += fma(oc.cyy, vy_r, -oc.cxy * vx_r);
-    acc.Ey.i += fma(oc.cyy, vy_i, -oc.cxy * vx_i);
 }
 
 // one polarisation's share of the order (nearfield.py:313-327 rearranged, see the file header)
@@ -427,7 +289,6 @@ __device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, doubl
     }
 }
 
-constexpr int REC_TYPE_SHIFT = 20;   // records: cell type (centre) / collection (rings) above the ring index (rings < 2^19, ctx.hip)
 
 __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs a) {
     const int lane = threadIdx.x & 63;
@@ -514,42 +375,22 @@ constexpr int NF_CHUNK = 4;                  // orders per staging pass (64 lane
 constexpr int NF_PITCH = NF_CHUNK * 16 + 1;  // +1: blocks start in different 16-byte bank slots
 static_assert(16 * CENTER_TYPES <= NF_SLOTS * NF_PITCH && CENTER_TYPES % 4 == 0, "the centre block must fit the ring slots");
 
-// WPB = waves (patches) per workgroup.  1: one wave per workgroup (the stand-alone synthesis).
-// 4: the banded step (hotpath.hip), where the transform of the previous band of rows runs beside
-// this kernel: a four-wave workgroup gives back one wave slot on EVERY SIMD when it retires, which
-// is what a four-wave transform workgroup needs to be admitted - single-wave workgroups refill
-// each slot the moment it frees and starve it.  The waves of a workgroup never meet: each has
-// its own LDS blocks and synchronises with itself only (wave_lds_sync).
-template <int WPB>
-__device__ __forceinline__ void wave_lds_sync() {
-    if (WPB == 1) {
-        __syncthreads();
-    } else {
-        // one wave's LDS accesses are served in order; this only stops the compiler moving them
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 #ifndef ML_NF_WAVES
 #define ML_NF_WAVES 4   // waves per SIMD the single-source kernel is compiled for (A/B builds: 5)
 #endif
-template <bool RECORDS, int NP, int WPB, bool GEN>
-__global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field_kernel(const NfArgs a) {
-    __shared__ double2 s_tab_all[WPB * NF_SLOTS * NF_PITCH];
-    double2 *s_tab = s_tab_all + (WPB == 1 ? 0 : (threadIdx.x >> 6) * (NF_SLOTS * NF_PITCH));
+// The kernels of GENERAL order sets (|ox| up to 5, oy != 0: grating.lua:406-423): every order
+// evaluates its own phase argument the reference's way (nearfield.py:268-269,291; order_factors_arg).
+// Lenses whose tables hold ox in {-1, 0, 1}, oy = 0 only - every order of a round lens' rings that
+// propagates in air - run nearfield_simple.hip instead.
+template <int NP>
+__global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field_kernel(const NfArgs a) {
+    __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];
     const int lane = threadIdx.x & 63;
     const ml_nearfield_params &p = a.p;
     // patch of this wave: the whole grid, or (once the zeros outside the lens are in place) the
     // list of patches that hold lens samples
     int bx = blockIdx.x, by = blockIdx.y;
-    if (WPB > 1) {   // always a listed launch
-        const int pi = blockIdx.x * WPB + (threadIdx.x >> 6);
-        if (pi >= a.n_active) return;   // (no workgroup barriers in this form)
-        const int2 pb = a.active_list[pi];
-        bx = pb.x;
-        by = pb.y;
-    } else if (a.use_active) {
+    if (a.use_active) {
         const int2 pb = a.active_list[blockIdx.x];
         bx = pb.x;
         by = pb.y;
@@ -557,7 +398,6 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     const int i = by * 8 + (lane >> 3);                       // x index
     const int j = bx * 8 + (lane & 7);                        // y index (fastest in memory)
     const bool inb = j < a.ny && i < a.nx;
-    const size_t at = (size_t)i * a.ny + j;
     int idx = a.n_rings + 1, aux = -1;
 #ifdef ML_PHASE_TIMERS
     unsigned long long stamp[PHASE_SLOTS] = {0};
@@ -566,18 +406,11 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     // the sample's coordinates do not wait for its record
     const double x_ld = a.x_pts[min(i, a.nx - 1)], y_ld = a.y_pts[min(j, a.ny - 1)];
     if (inb) {
-        if (RECORDS) {
-            // streamed: read once per launch, must not push the ring tables out of the L2
-            typedef int int2v __attribute__((ext_vector_type(2)));
-            const size_t rec = ((size_t)by * a.patches_x + bx) * 64 + lane;   // patch-major
-            const int2v ix = reinterpret_cast<const int2v *>(a.geo_ix)[rec];
-            idx = ix.x;   // cell type / collection above bit 20, split off below
-            aux = ix.y;
-        } else {
-            sample_geometry(a, a.x_pts[i], a.y_pts[j], (long long)at, idx, aux);
-            if (idx == 0 && aux >= 0) idx = a.cwhich[aux] << REC_TYPE_SHIFT;
-            if (idx >= 1 && idx <= a.n_rings) idx |= a.ring_coll[idx - 1] << REC_TYPE_SHIFT;
-        }
+        typedef int int2v __attribute__((ext_vector_type(2)));
+        const size_t rec = ((size_t)by * a.patches_x + bx) * 64 + lane;   // patch-major
+        const int2v ix = reinterpret_cast<const int2v *>(a.geo_ix)[rec];
+        idx = ix.x;   // cell type / collection above bit 20, split off below
+        aux = ix.y;
     }
     // ---- incidence direction (shared) and incident field per polarisation (amplitude-type
     // arithmetic).  They need the sample's coordinates and the source only, so they are worked
@@ -622,17 +455,15 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     // registers are what limits this kernel to four waves per SIMD)
     // (set and read by ring samples only - lanes with key >= 0 - and deliberately left without initial
     // values: every default costs a move per register and a select where the branches meet)
-    int key = -1, n_orders = 0, stride0, stride_o, order_codes;
-    double Gx;   // simple orders: 2 pi / period; order o adds (code_o - 1) Gx to k ux' (codes: CollDesc.flags)
+    int key = -1, n_orders = 0, stride0, stride_o;
     double uxp, uyp, t0, t1, xp, yp;
     double Hw_x[NP], Hw_y[NP];
     const double *ok = a.ring_ok;
     const double2 *node00;
     bool outside = false;
     double2 r0, r1, cs;
-    // periphery: order (0, 0)'s phasor x the propagation phasor, exp(i Gx x'), Gy y' (order_phasor)
-    // (GEN: the propagation phasor alone in E0, the local coordinates x', y' in xp, yp)
-    c2 E0, Ex1;
+    // periphery: the propagation phasor exp(i k |grating centre - source|) (nearfield.py:337-341)
+    c2 E0;
     {
         const double x = x_ld, y = y_ld;
 #pragma unroll
@@ -664,7 +495,6 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             const size_t st_o = (size_t)T.n0 * T.n1 * n2 * 4;
             const int which = min(cell_type, n2 - 1);
             double ccx, ccy, ox_, oy_;   // (centre samples only; no defaults - see the ring samples' state above)
-            c2 E0, Exc;
             if (cen) {
                 // the record holds the cell's slot in the bin-sorted arrays
                 const double2 cc = a.cxy[aux];
@@ -674,24 +504,6 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 ox_ = x - ccx;
                 oy_ = y - ccy;
                 ML_MARK(3, ox_ + oy_);   // (centre waves: the cell centre has arrived)
-                // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
-                // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
-                // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
-                // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
-                if (!GEN) {
-                    double a0 = (p.kvac * ux) * ox_ + (p.kvac * uy) * oy_;
-                    int kq = 0;
-                    if (!p.plane_wave) {
-                        const double gx = ccx - p.source_x, gy = ccy - p.source_y;
-                        const double air = sqrt(gx * gx + gy * gy + p.source_z2);
-                        double r;
-                        reduce_pio2(p.kvac * air, r, kq);
-                        a0 = r + a0;
-                    }
-                    sincos_cw_q(a0, kq, E0.i, E0.r);
-                    sincos_cw(T.center_g[0] * ox_, Exc.i, Exc.r);
-                }
-                ML_MARK(4, E0.r + Exc.i);   // (centre waves: phasors done, order loop next)
             }
             // lane (row, column group) of the staged block [node c][amplitude q][CENTER_TYPES]:
             // row c * 4 + q = lane / 4, columns lane % 4 + 4 m - a quad of lanes reads 64 contiguous
@@ -706,32 +518,16 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 const bool mine = cen && i0 == i0u && i1 == i1u && which >= tb && which < tb + CENTER_TYPES;
                 todo &= ~__ballot(mine);
                 const int kc = min(CENTER_TYPES, n2 - tb);
-                // (single source, simple orders: the next order's block is requested before this
-                // order's arithmetic and waits in registers - the other instantiations have none to
-                // spare - and replaces the block in LDS once every lane is done with this one)
-                constexpr bool AHEAD = NP == 1 && !GEN && WPB == 1;
                 const double2 *src = a.center_tab + (size_t)i0u * st0 + (size_t)i1u * st1 + tb + row_off + scol;
                 double2 val[CENTER_TYPES / 4];
-                if (AHEAD) {
+                for (int o = 0; o < T.n_orders; ++o) {   // wave-uniform
 #pragma unroll
                     for (int m = 0; m < CENTER_TYPES / 4; ++m)
-                        val[m] = scol + 4 * m < kc ? src[4 * m] : make_double2(0.0, 0.0);
-                }
-                for (int o = 0; o < T.n_orders; ++o) {   // wave-uniform
-                    if (!AHEAD) {
-#pragma unroll
-                        for (int m = 0; m < CENTER_TYPES / 4; ++m)
-                            val[m] = scol + 4 * m < kc ? src[o * st_o + 4 * m] : make_double2(0.0, 0.0);
-                    }
+                        val[m] = scol + 4 * m < kc ? src[o * st_o + 4 * m] : make_double2(0.0, 0.0);
 #pragma unroll
                     for (int m = 0; m < CENTER_TYPES / 4; ++m)
                         s_tab[srow * CENTER_TYPES + scol + 4 * m] = val[m];
-                    wave_lds_sync<WPB>();
-                    if (AHEAD && o + 1 < T.n_orders) {
-#pragma unroll
-                        for (int m = 0; m < CENTER_TYPES / 4; ++m)
-                            val[m] = scol + 4 * m < kc ? src[(o + 1) * st_o + 4 * m] : make_double2(0.0, 0.0);
-                    }
+                    __syncthreads();
                     if (mine) {
                         const double kx = fma(p.kvac, ux, T.center_kx[o]);
                         const double ky = fma(p.kvac, uy, T.center_ky[o]);
@@ -740,29 +536,24 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                             if (out_c) check_bounds(a, T, MAX_SLOTS, o, ux, uy, 0.0, false);
                             OrderCommon oc;
                             order_common_types(oc, s_tab + (which - tb), c0, c1);
-                            if (GEN)
-                                order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, a.e_from_h,
-                                                  kx * ox_ + ky * oy_);
-                            else
-                                order_factors(oc, kx, ky, p.k_glass2 - kt2, a.e_from_h,
-                                              order_phasor(E0, Exc, T.center_ox[o]));
+                            order_factors_arg(oc, kx, ky, p.k_glass2 - kt2, a.e_from_h, kx * ox_ + ky * oy_);
                             // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
 #pragma unroll
                             for (int m = 0; m < NP; ++m) order_apply(acc[m], oc, Hy_i[m], Hx_i[m]);
                         }
                     }
-                    wave_lds_sync<WPB>();   // the next order (or round) overwrites the block
+                    __syncthreads();   // the next order (or round) overwrites the block
                 }
             }
             if (cen) {
-                // input modulation of the far-field plan's stage 1, applied here for free (NfArgs);
-                // GEN: and the phase-critical propagation from the cell centre (nearfield.py:453-461)
+                // input modulation of the far-field plan's stage 1, applied here for free (NfArgs), and
+                // the phase-critical propagation from the cell centre (nearfield.py:453-461)
                 c2 e = {1.0, 0.0};
                 if (a.premod) {
                     const double2 t2 = a.premod[j];
                     e = {t2.x, t2.y};
                 }
-                if (GEN && !p.plane_wave) {
+                if (!p.plane_wave) {
                     const double gx = ccx - p.source_x, gy = ccy - p.source_y;
                     const double air = sqrt(gx * gx + gy * gy + p.source_z2);
                     double sn, cn;
@@ -770,7 +561,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                     const c2 prop = {cn, sn};
                     e = a.premod ? cmul(prop, e) : prop;
                 }
-                if (a.premod || (GEN && !p.plane_wave)) {
+                if (a.premod || !p.plane_wave) {
 #pragma unroll
                     for (int m = 0; m < NP; ++m) {
                         acc[m].Ex = cmul(acc[m].Ex, e);
@@ -851,7 +642,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             const double period = r0.y;
             const long long bits = __double_as_longlong(r1.y);
             const long long tab_off = bits & ((1ll << 40) - 1);
-            if (GEN) ok = a.ring_ok + a.ring_ok_off[ring];
+            ok = a.ring_ok + a.ring_ok_off[ring];
             stride0 = n1 * 4;
             stride_o = n0 * n1 * 4;
             node00 = a.ring_tab + tab_off + i0 * stride0 + i1 * 4;
@@ -869,29 +660,9 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
             // rings < 2^19; table axes of up to 64 nodes share blocks exactly, longer ones get a
             // block per lane (still correct, just not shared)
             key = (n0 > 64 || n1 > 64) ? 0x7fffffff - lane : (ring << 12) | (i0 << 6) | i1;
-            // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
-            // nearfield.py:268-269,291 with ox = oy = 0) times the phase-critical propagation phasor
-            // from the grating centre (:337-341, exact argument), through ONE sincos: the large
-            // angle k |r| is reduced to [-pi/4, pi/4] + quadrants first and the small one added
-            // to the remainder.  Ex = exp(i Gx x').  Evaluated HERE so that the arithmetic runs
-            // while the table blocks are on their way.
-            if (!GEN) {
-                double a0 = (p.kvac * uxp) * xp + (p.kvac * uyp) * yp;
-                int kq = 0;
-                if (!p.plane_wave) {
-                    const double rcen = r0.x;
-                    const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
-                    const double air = sqrt(gx * gx + gy * gy + p.source_z2);
-                    double r;
-                    reduce_pio2(p.kvac * air, r, kq);
-                    a0 = r + a0;
-                }
-                sincos_cw_q(a0, kq, E0.i, E0.r);
-                Gx = r1.x;   // 2 pi / period
-                order_codes = flags >> 2;
-                sincos_cw(Gx * xp, Ex1.i, Ex1.r);
-            } else if (!p.plane_wave) {
-                // GEN: the propagation phasor on its own; every order evaluates its own argument
+            // the propagation phasor on its own (phase-critical: exact argument, nearfield.py:337-341);
+            // every order evaluates its own argument
+            if (!p.plane_wave) {
                 const double rcen = r0.x;
                 const double gx = rcen * cosr - p.source_x, gy = rcen * sinr - p.source_y;
                 const double air = sqrt(gx * gx + gy * gy + p.source_z2);
@@ -903,8 +674,7 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
     Acc pr[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    constexpr bool FOLD = NP == 1 && !GEN;
-    ML_MARK(9, E0.r + Ex1.i + t0);   // (ring waves: set-up arithmetic done, block matching and staging next)
+    ML_MARK(9, E0.r + t0);   // (ring waves: set-up arithmetic done, block matching and staging next)
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
         int myslot = -1, lead[NF_SLOTS];
@@ -960,39 +730,18 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                 for (int s = 0; s < NF_SLOTS; ++s)
                     if (have[s]) s_tab[s * NF_PITCH + lane] = val[s];
             }
-            wave_lds_sync<WPB>();
+            __syncthreads();
             ML_MARK(4, s_tab[lane].x);
             if (myslot >= 0) {
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
-                // (one source: the interpolation weights times the two polarisation weights, worked out
-                // per pass - one as a rule - so that they are not live while the blocks are staged)
-                double wfx[4] = {0, 0, 0, 0}, wfy[4] = {0, 0, 0, 0};
-                if (FOLD) {
-                    const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        wfx[c] = w[c] * Hw_x[0];
-                        wfy[c] = w[c] * Hw_y[0];
-                    }
-                }
                 // the order's grating vector one iteration ahead: its load (an L1 hit) is in
                 // flight during the previous order's arithmetic instead of in front of its own
-                // (general orders only; the simple-order kernels build the grating vector from the
-                // ring record and the collection descriptor: ox from the order codes, 2 pi / period - the same rounding as the
-                // reference's ox*2*pi/grating_period for ox = -1, 0, 1 - and oy = 0)
                 typedef double double2v __attribute__((ext_vector_type(2)));
                 const double2v *ok2 = reinterpret_cast<const double2v *>(ok);   // per order: (kx, ky), (ox, oy)
-                double2v k_next = (GEN && NP == 1) ? ok2[2 * o0] : (double2v){0.0, 0.0};
+                double2v k_next = NP == 1 ? ok2[2 * o0] : (double2v){0.0, 0.0};
                 for (int o = o0; o < o1; ++o) {
-                    double2v k_here;
-                    int ox_here = 0;
-                    if (GEN) {
-                        k_here = NP == 1 ? k_next : ok2[2 * o];
-                        if (NP == 1) k_next = ok2[2 * min(o + 1, o1 - 1)];
-                    } else {
-                        ox_here = ((order_codes >> (2 * o)) & 3) - 1;
-                        k_here = (double2v){(double)ox_here * Gx, 0.0};
-                    }
+                    const double2v k_here = NP == 1 ? k_next : ok2[2 * o];
+                    if (NP == 1) k_next = ok2[2 * min(o + 1, o1 - 1)];
                     const double kxp = fma(p.kvac, uxp, k_here.x);
                     const double kyp = fma(p.kvac, uyp, k_here.y);
                     const double kt2 = fma(kxp, kxp, kyp * kyp);
@@ -1002,29 +751,14 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
                             check_bounds(a, a.tables[slot], slot, o, uxp, uyp, a.period[idx - 1], true);
                         }
                         OrderCommon oc;
-                        if (FOLD) {
-                            // one source: the two polarisation weights ride in the interpolation
-                            // weights (wfx = w Hw_x, wfy = w Hw_y, set up once per sample), so the
-                            // order yields U_fy, U_fx directly (order_apply's first eight operations)
-                            order_common_folded(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, wfx, wfy);
-                            order_factors(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h,
-                                          order_phasor(E0, Ex1, ox_here));
-                            order_apply_folded(pr[0], oc);
-                        } else {
-                            order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
-                            if (GEN)
-                                order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h,
-                                                  kxp * xp + kyp * yp);
-                            else
-                                order_factors(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h,
-                                              order_phasor(E0, Ex1, ox_here));
+                        order_common_lds(oc, s_tab + myslot * NF_PITCH + (o - o0) * 16, t0, t1);
+                        order_factors_arg(oc, kxp, kyp, p.k_glass2 - kt2, a.e_from_h, kxp * xp + kyp * yp);
 #pragma unroll
-                            for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
-                        }
+                        for (int m = 0; m < NP; ++m) order_apply(pr[m], oc, Hw_x[m], Hw_y[m]);
                     }
                 }
             }
-            wave_lds_sync<WPB>();   // the next pass overwrites the blocks
+            __syncthreads();   // the next pass overwrites the blocks
         }
     }
     ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
@@ -1032,18 +766,18 @@ __global__ __launch_bounds__(64 * WPB, NP == 1 ? ML_NF_WAVES : 3) void nearfield
         // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
         const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
         const double cosr = cs2.x, sinr = cs2.y;
-        // (the propagation phasor already rides in every order's phasor; what is left is the
-        // far-field plan's input modulation, if the plan has one: re-read here, an L2 hit)
+        // the propagation phasor and the far-field plan's input modulation, if the plan has one
+        // (re-read here, an L2 hit)
         c2 e = {1.0, 0.0};
         if (a.premod) {
             const double2 t2 = a.premod[j];
             e = {t2.x, t2.y};
         }
-        if (GEN && !p.plane_wave) e = a.premod ? cmul(E0, e) : E0;
+        if (!p.plane_wave) e = a.premod ? cmul(E0, e) : E0;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             Acc &q = pr[m];
-            if (a.premod || (GEN && !p.plane_wave)) {
+            if (a.premod || !p.plane_wave) {
                 q.Ex = cmul(q.Ex, e);
                 q.Ey = cmul(q.Ey, e);
                 q.Hx = cmul(q.Hx, e);
@@ -1098,52 +832,15 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     // stores drain under the next patch's arithmetic was tried: the loop costs registers the
     // kernel does not have (spills) and ran 25-40 % slower.
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
-    *n_partials = (int)(full.x * full.y);
+    *n_partials = (int)(full.x * full.y) * 4;   // four power partials per patch (wave_power)
     const dim3 grid = a.use_active ? dim3(a.n_active) : full;
-#ifdef ML_DIAG
-    if (!a.geo_ix) {   // diagnostic build only: decisions inline, no records
-        hipLaunchKernelGGL((nearfield_field_kernel<false, 1, 1, true>), grid, dim3(64), 0, ctx->stream, a);
-        ML_HIP(hipGetLastError());
-        return ML_OK;
-    }
-#endif
-#ifdef ML_FORCE_GEN
-    const bool gen = true;   // A/B builds only: the general kernels whatever the order sets
-#else
-    const bool gen = !a.simple_orders;
-#endif
-    if (a.n_pol == 1 && gen)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, true>), grid, dim3(64), 0, ctx->stream, a);
-    else if (a.n_pol == 1)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, false>), grid, dim3(64), 0, ctx->stream, a);
-    else if (a.n_pol == 2 && gen)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 2, 1, true>), grid, dim3(64), 0, ctx->stream, a);
+    if (a.simple_orders) return nearfield_simple_launch(ctx, a, grid);
+    if (a.n_pol == 1)
+        hipLaunchKernelGGL((nearfield_field_kernel<1>), grid, dim3(64), 0, ctx->stream, a);
     else if (a.n_pol == 2)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 2, 1, false>), grid, dim3(64), 0, ctx->stream, a);
-    else if (gen)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 3, 1, true>), grid, dim3(64), 0, ctx->stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<2>), grid, dim3(64), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 3, 1, false>), grid, dim3(64), 0, ctx->stream, a);
-    ML_HIP(hipGetLastError());
-    return ML_OK;
-}
-
-// The banded step's synthesis of one band: the listed patches [first, first + count) as
-// workgroups of `wpb` waves (1 or 4), single source, queued on `stream`.
-int nearfield_band_launch(hipStream_t stream, const NfArgs &a0, int first, int count, int wpb) {
-    if (count <= 0) return ML_OK;
-    NfArgs a = a0;
-    a.use_active = 1;
-    a.active_list = a0.active_list + first;
-    a.n_active = count;
-    if (wpb == 4 && a.simple_orders)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 4, false>), dim3((count + 3) / 4), dim3(256), 0, stream, a);
-    else if (wpb == 4)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 4, true>), dim3((count + 3) / 4), dim3(256), 0, stream, a);
-    else if (a.simple_orders)
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, false>), dim3(count), dim3(64), 0, stream, a);
-    else
-        hipLaunchKernelGGL((nearfield_field_kernel<true, 1, 1, true>), dim3(count), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL((nearfield_field_kernel<3>), grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

@@ -1,0 +1,630 @@
+// Near-field synthesis for the order set of a round lens (reference nearfield.py:208-477 per
+// aperture sample): every table of the lens - ring collections and centre - holds diffraction
+// orders ox in {-1, 0, 1}, oy = 0 only, i.e. every order of a round lens' rings that propagates in
+// air.  Any other order set runs the general kernels of nearfield_fast.hip; the source-independent
+// decisions of a sample (ring, sector, nearest cell) come from the records of
+// nearfield_geometry_kernel either way.
+//
+// What the restricted order set buys (the kernel is bound by fp64 vector ISSUE: every vector
+// instruction holds its SIMD for four cycles, so the budget is instructions per sample):
+//   * CANONICAL order slots 0: (0,0), 1: (-1,0), 2: (+1,0) in every table (ctx.hip; an order a
+//     collection lacks is a block of zeros): the order loop is three straight-line copies with
+//     the order known at compile time - no order codes, selects or loop control;
+//   * the phasor of order (ox, 0) at a sample is exp(i ((k u_x' + ox G) x' + k u_y' y'))
+//     (nearfield.py:268-269,291; centre :391-409) = E0 * X^ox with E0 the order-(0,0) phasor - into
+//     which the propagation phasor exp(i k |grating centre - source|) is folded, its exact ~1e4 rad
+//     argument reduced to [-pi/4, pi/4] + quadrants first - and X = exp(i G x'): two sincos per
+//     sample, the +-1 orders one product each;
+//   * k_x' of order (ox, 0) = k u_x' + ox (2 pi / period), the reference's own expression
+//     (ox*2*pi/grating_period is exactly +-(2 pi / period) for ox = +-1);
+//   * CELL BLOCKS (common.h): the 48 complex a sample in table cell (i0, i1) of its ring
+//     interpolates from are contiguous, so a (ring, cell) block is named by ONE 32-bit number -
+//     the key the lanes of a patch are matched by, and, read back from the lead lane, the scalar
+//     base of the one wave-wide load that stages the block through LDS (lane l < 48 fetches
+//     element l): no per-slot stride / order-count read-backs, no per-lane address arithmetic;
+//   * one source (NP = 1): the two polarisation weights ride in the interpolation weights.
+// Amplitude-type arithmetic (direction cosines, incident amplitudes, interpolation, the 2 x 2
+// polarisation algebra, small-argument sin / cos) is accurate to a few ulp; what feeds LARGE phases
+// - x', y', the propagation distance and k * distance - follows the reference operation by
+// operation (this file is compiled with -ffp-contract=off; every fma() here is deliberate).
+#include "nearfield_math.h"
+
+namespace ml {
+
+constexpr int SK_SLOTS = 6;                     // distinct (ring, cell) blocks staged per round
+constexpr int SK_PITCH = CELL_BLOCK + 1;        // +1: blocks start in different 16-byte bank slots
+constexpr int SK_TYPES = 20;                    // centre: cell types per staged block (the reference's default K, lens_center.py:28)
+static_assert(SK_TYPES == CENTER_GROUP, "the centre table's cell blocks hold groups of SK_TYPES types");
+
+struct AccS {
+    double Exr, Exi, Eyr, Eyi, Hxr, Hxi, Hyr, Hyi;
+};
+
+// what the three orders of a sample share: k u_x', 2 pi / period, k u_y', (k u_y')^2, (k u_y')^2 - k_glass^2,
+// the order-(0,0) phasor (x the propagation phasor) and exp(i G x')
+struct OrderShared {
+    double kx0, G, ky, ky2, cY;
+    c2 E0, X;
+};
+
+// E-from-H factors of one order (nearfield.py:313-327 rearranged, nearfield_fast.hip header):
+//   Ex += Z0 g (kx ky U_fy + (ky^2 + kz^2) U_fx) ph,  Ey += Z0 g (-(kx^2 + kz^2) U_fy - kx ky U_fx) ph,
+//   g = 1 / (k_glass kz n_glass), with ky^2 + kz^2 = k_glass^2 - kx^2 and kx^2 + kz^2 = k_glass^2 - ky^2
+struct OrderFactors {
+    double cxy, cxx, cyy;
+    c2 ph;
+};
+
+template <int OX>
+__device__ __forceinline__ bool order_setup(const OrderShared &S, const ml_nearfield_params &p, double e_from_h,
+                                            double &kx, double &kt2) {
+    kx = OX == 0 ? S.kx0 : OX > 0 ? S.kx0 + S.G : S.kx0 - S.G;
+    kt2 = kx * kx + S.ky2;
+    return kt2 <= p.kvac2;   // propagating in air (nearfield.py:279-280, 398)
+}
+
+template <int OX>
+__device__ __forceinline__ void order_factors_s(OrderFactors &f, const OrderShared &S, const ml_nearfield_params &p,
+                                                double e_from_h, double kx, double kt2) {
+    const double g = e_from_h * rsqrt_fast(p.k_glass2 - kt2);   // Z0 / (n k_glass kz)
+    f.cxy = (kx * S.ky) * g;
+    f.cxx = (p.k_glass2 - kx * kx) * g;
+    f.cyy = S.cY * g;
+    f.ph = OX == 0 ? S.E0 : OX > 0 ? cmulf(S.E0, S.X) : cmulf_conj(S.E0, S.X);
+}
+
+// V = U ph; H += V; E += factors x V (U_fy <-> H along x', U_fx <-> H along y')
+__device__ __forceinline__ void order_accumulate(AccS &acc, const OrderFactors &f, double ufy_r, double ufy_i,
+                                                 double ufx_r, double ufx_i) {
+    const double vy_r = fma(ufy_r, f.ph.r, -(ufy_i * f.ph.i)), vy_i = fma(ufy_r, f.ph.i, ufy_i * f.ph.r);
+    const double vx_r = fma(ufx_r, f.ph.r, -(ufx_i * f.ph.i)), vx_i = fma(ufx_r, f.ph.i, ufx_i * f.ph.r);
+    acc.Hxr += vy_r;
+    acc.Hxi += vy_i;
+    acc.Hyr += vx_r;
+    acc.Hyi += vx_i;
+    acc.Exr = fma(f.cxx, vx_r, fma(f.cxy, vy_r, acc.Exr));
+    acc.Exi = fma(f.cxx, vx_i, fma(f.cxy, vy_i, acc.Exi));
+    acc.Eyr = fma(-f.cxy, vx_r, fma(f.cyy, vy_r, acc.Eyr));
+    acc.Eyi = fma(-f.cxy, vx_i, fma(f.cyy, vy_i, acc.Eyi));
+}
+
+// One order of one sample from a block staged in LDS: blk[(node c) * 4 + amplitude q] (element stride
+// STRIDE: 1 for a ring block, SK_TYPES for the centre's type-major block), c = 2 (i0 step) + (i1 step),
+// amplitudes q = (x, ampfy) (x, ampfx) (y, ampfy) (y, ampfx).
+// NP = 1: wa = w Hw_x, wb = w Hw_y (interpolation weights x the two polarisation weights: incident H
+// along y' <-> x table, along x' <-> y table), so that the interpolation yields
+// U_fy = sum_p Hw_p a_fy,p and U_fx = sum_p Hw_p a_fx,p directly.  NP > 1: wa = the interpolation
+// weights, the members' polarisation weights in Hwx / Hwy.
+template <int OX, int NP, int STRIDE>
+__device__ __forceinline__ void order_simple(AccS *acc, const double2 *blk, const double *wa, const double *wb,
+                                             const double *Hwx, const double *Hwy, const OrderShared &S,
+                                             const ml_nearfield_params &p, double e_from_h) {
+    double kx, kt2;
+    if (!order_setup<OX>(S, p, e_from_h, kx, kt2)) return;
+    OrderFactors f;
+    order_factors_s<OX>(f, S, p, e_from_h, kx, kt2);
+    if (NP == 1) {
+        double ufy_r, ufy_i, ufx_r, ufx_i;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double2 v0 = blk[(c * 4 + 0) * STRIDE], v1 = blk[(c * 4 + 1) * STRIDE];
+            const double2 v2 = blk[(c * 4 + 2) * STRIDE], v3 = blk[(c * 4 + 3) * STRIDE];
+            if (c == 0) {
+                ufy_r = wa[0] * v0.x;
+                ufy_i = wa[0] * v0.y;
+                ufx_r = wa[0] * v1.x;
+                ufx_i = wa[0] * v1.y;
+            } else {
+                ufy_r = fma(wa[c], v0.x, ufy_r);
+                ufy_i = fma(wa[c], v0.y, ufy_i);
+                ufx_r = fma(wa[c], v1.x, ufx_r);
+                ufx_i = fma(wa[c], v1.y, ufx_i);
+            }
+            ufy_r = fma(wb[c], v2.x, ufy_r);
+            ufy_i = fma(wb[c], v2.y, ufy_i);
+            ufx_r = fma(wb[c], v3.x, ufx_r);
+            ufx_i = fma(wb[c], v3.y, ufx_i);
+            // (two nodes' reads in flight at a time: with all sixteen - 64 registers - something spills)
+            if (c == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        order_accumulate(acc[0], f, ufy_r, ufy_i, ufx_r, ufx_i);
+    } else {
+        double ar[4], ai[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double2 v = blk[(c * 4 + q) * STRIDE];
+                ar[q] = c == 0 ? wa[0] * v.x : fma(wa[c], v.x, ar[q]);
+                ai[q] = c == 0 ? wa[0] * v.y : fma(wa[c], v.y, ai[q]);
+            }
+#pragma unroll
+        for (int m = 0; m < NP; ++m)
+            order_accumulate(acc[m], f, fma(Hwx[m], ar[0], Hwy[m] * ar[2]), fma(Hwx[m], ai[0], Hwy[m] * ai[2]),
+                             fma(Hwx[m], ar[1], Hwy[m] * ar[3]), fma(Hwx[m], ai[1], Hwy[m] * ai[3]));
+    }
+}
+
+// the (ux, uy) table cell of uniformly spaced axes by arithmetic: first, step, 1 / step per axis in
+// ax[6], the last cell per axis in lim0 / lim1.  A sample within an ulp of a node may land in the
+// neighbouring cell; the bilinear interpolant is continuous across cells, so the value is the same
+// to rounding.  t = fractional position in the cell.
+__device__ __forceinline__ void locate_uniform(const double *ax, double lim0, double lim1, double u, double v,
+                                               int &i0, double &t0, int &i1, double &t1) {
+    const double a0 = (u - ax[0]) * ax[2], a1 = (v - ax[3]) * ax[5];
+    const double f0 = fmin(fmax(floor(a0), 0.0), lim0), f1 = fmin(fmax(floor(a1), 0.0), lim1);
+    i0 = (int)f0;
+    i1 = (int)f1;
+    t0 = a0 - f0;
+    t1 = a1 - f1;
+}
+
+// cell of a short ascending axis: largest i with axis[i] <= x, clamped to [0, n-2] (tables whose
+// axes are not uniformly spaced; characterize() produces uniform ones)
+__device__ __forceinline__ void locate_axis(const double *axis, int n, double x, int &i, double &t) {
+    i = 0;
+    for (int a = 1; a < n - 1; ++a) i = (axis[a] <= x) ? a : i;
+    const double lo = axis[i], hi = axis[i + 1];
+    t = (x - lo) * recip(hi - lo);
+}
+
+// the bound reports of a sample outside its table, per order in the reference's check order
+// (nearfield.py:294-305, 412-419): rare path, entered by the whole wave only if some lane needs it
+template <bool RING>
+__device__ __forceinline__ void report_orders(const NfArgs &a, double kx0, double G, double ky, int present,
+                                              int order_of, int slot, double u, double v, double period) {
+    const ml_nearfield_params &p = a.p;
+    const TableDesc &T = RING ? a.tables[slot] : a.center_desc;
+    const double ky2 = ky * ky;
+#pragma unroll
+    for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
+        const double kx = oc == 0 ? kx0 : oc == 2 ? kx0 + G : kx0 - G;
+        if (((present >> oc) & 1) && kx * kx + ky2 <= p.kvac2)
+            check_bounds(a, T, slot, (order_of >> (4 * oc)) & 15, u, v, period, RING);
+    }
+}
+
+// incidence direction at a sample (nearfield.py:172-184): unit vector from the source, 1 / distance
+__device__ __forceinline__ void incidence(const ml_nearfield_params &p, double x, double y, double &ux, double &uy,
+                                          double &uz, double &inv) {
+    const double dx = x - p.source_x, dy = y - p.source_y;
+    inv = rsqrt_fast(fma(dx, dx, fma(dy, dy, p.dz2)));
+    ux = dx * inv;
+    uy = dy * inv;
+    uz = p.dz * inv;
+}
+
+// direction cosines in the grating's frame (rotation cs = (cos, sin), nearfield.py:195-196)
+__device__ __forceinline__ void rotate_dir(double ux, double uy, double2 cs, double &uxp, double &uyp) {
+    uxp = fma(ux, cs.x, uy * cs.y);
+    uyp = fma(uy, cs.x, -(ux * cs.y));
+}
+
+// A staged block: N16 wave-wide 16-byte global -> LDS loads (global_load_lds_dwordx4: scalar source
+// base + lane x 16 bytes -> LDS base in M0 + lane x 16 bytes, no registers in between) of
+// consecutive KiB.  Written as inline assembly, and waited for by staged_wait() below: the compiler
+// puts s_waitcnt vmcnt(0) in front of the first LDS read that follows a __builtin_amdgcn_global_load_lds
+// (any LDS read may alias the pending write for all it knows), which serialises the centre's two
+// buffers.  Loads the compiler does not know about can only make its own vmcnt(N) waits wait for
+// more (vector-memory loads return in order), never for less.
+__device__ __forceinline__ unsigned lds_address(const double2 *p) {
+    return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char *)(const char *)p;
+}
+template <int N16>
+__device__ __forceinline__ void stage_block(const double2 *src, const double2 *lds, unsigned lane_off) {
+    const char *base = reinterpret_cast<const char *>(src);   // wave-uniform
+    const unsigned dst = lds_address(lds);
+#pragma unroll
+    for (int m = 0; m < N16; ++m)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(lane_off), "s"(base + m * 1024), "s"(dst + m * 1024)
+                     : "memory", "m0");
+}
+
+// the wave's global -> LDS loads have landed except the newest LEFT of them (a workgroup is one
+// wave: nobody else to wait for); the compiler may not move LDS reads in front of this
+template <int LEFT>
+__device__ __forceinline__ void staged_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEFT) : "memory");
+}
+
+constexpr int CB = CENTER_BLOCK;   // complex per staged centre block
+
+template <int NP>
+__global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a) {
+    // two buffers: the centre stages order o + 1 while order o is evaluated; ring blocks use the first
+    __shared__ double2 s_tab[CB], s_tab1[CB];
+    static_assert(SK_SLOTS * SK_PITCH <= CB, "the ring blocks of a round fit one buffer");
+    const int lane = threadIdx.x;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    const ml_nearfield_params &p = a.p;
+    // patch of this wave: the whole grid, or (once the zeros outside the lens are in place) the
+    // list of patches that hold lens samples
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.use_active) {
+        const int2 pb = a.active_list[blockIdx.x];
+        bx = pb.x;
+        by = pb.y;
+    }
+    const int i = by * 8 + (lane >> 3);   // x index
+    const int j = bx * 8 + (lane & 7);    // y index (fastest in memory)
+    const bool inb = j < a.ny && i < a.nx;
+    // the sample's coordinates do not wait for its record
+    const double x = a.x_pts[min(i, a.nx - 1)], y = a.y_pts[min(j, a.ny - 1)];
+    typedef int int2v __attribute__((ext_vector_type(2)));
+    const int2v *recs = reinterpret_cast<const int2v *>(a.geo_ix + ((size_t)by * a.patches_x + bx) * 64);   // patch-major
+    int idx = a.n_rings + 1, aux = -1;
+    if (inb) {
+        const int2v ix = recs[lane];
+        idx = ix.x;   // cell type / collection above bit 20, split off below
+        aux = ix.y;
+    }
+    // ---- incidence direction (shared) and incident field per polarisation (nearfield.py:172-228;
+    // amplitude-type arithmetic).  They need the sample's coordinates and the source only, so they
+    // are worked out for every lane while the record is on its way and masked by it afterwards.
+    // Incident power density (:474-477): Ex Hy - Ey Hx with E = Z0 H x u and H = (u x p) amp is
+    // Z0 u_z |H|^2 = (Z0 H_coef^2) (u_z / d)^2 |u x p|^2  (amp = H_coef sqrt(u_z) / d, the Lambert factor).
+    double ux = 0.0, uy = 0.0, uz = 1.0;
+    double Hx_i[NP], Hy_i[NP], power_in[NP];
+    if (p.plane_wave) {
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            Hx_i[m] = a.pw_Hx[m];
+            Hy_i[m] = a.pw_Hy[m];
+            power_in[m] = a.pw_power[m];
+        }
+    } else {
+        double inv;
+        incidence(p, x, y, ux, uy, uz, inv);
+        const double t = uz * inv, rs = rsqrt_fast(uz);   // uz > 0
+        const double t2 = t * t;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const double *pol = a.pol[m];
+            const double amp = (a.hcoef[m] * rs) * t;   // H_coef sqrt(uz) / d
+            const double hx = fma(uy, pol[2], -(uz * pol[1]));
+            const double hy = fma(uz, pol[0], -(ux * pol[2]));
+            const double hz = fma(ux, pol[1], -(uy * pol[0]));
+            Hx_i[m] = hx * amp;
+            Hy_i[m] = hy * amp;
+            power_in[m] = (a.pcoef[m] * t2) * fma(hx, hx, fma(hy, hy, hz * hz));
+        }
+    }
+    const int cell_type = idx >> REC_TYPE_SHIFT;   // (ring samples: the collection)
+    idx &= (1 << REC_TYPE_SHIFT) - 1;
+    const bool lens = idx <= a.n_rings;
+    const bool peri = lens && idx >= 1;
+#pragma unroll
+    for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
+
+    if (__ballot(lens && !peri)) {   // wave-uniform: some lane is a centre sample
+        // ================= centre: the record holds the nearest hexagonal cell =================
+        // The lanes of a patch sit in ~50 cells of up to K types, and (the direction of incidence
+        // hardly changes over 2 um) almost always in ONE (ux, uy) cell of the centre table.  Per
+        // order the wave stages that cell's block - four nodes x four amplitudes x a group of
+        // SK_TYPES types, contiguous in the centre table's cell-block form (common.h) - through LDS
+        // and every lane picks its type's sixteen values from there; order o + 1's block is on its
+        // way into the other buffer while order o is evaluated.  A round serves the lanes of one
+        // (table cell, group of types); a wave that straddles a table cell, or a table of more
+        // types, takes more rounds.
+        const bool cen = lens && !peri && aux >= 0;
+        AccS acc[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) acc[m] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const TableDesc &T = a.center_desc;
+        int i0, i1;
+        double t0, t1;
+        if (T.uniform) {   // (every lane: ux, uy are defined for all of them)
+            locate_uniform(T.uni_ax, (double)(T.n0 - 2), (double)(T.n1 - 2), ux, uy, i0, t0, i1, t1);
+        } else {
+            locate_axis(T.axis0, T.n0, ux, i0, t0);
+            locate_axis(T.axis1, T.n1, uy, i1, t1);
+        }
+        const bool out_c = (int)(ux < T.bounds[0]) | (int)(ux > T.bounds[1]) | (int)(uy < T.bounds[2]) |
+                           (int)(uy > T.bounds[3]);
+        const int n2 = T.n2, groups = (n2 + SK_TYPES - 1) / SK_TYPES;
+        const int which = min(cell_type, n2 - 1);
+        const int grp = which / SK_TYPES;
+        const int cblk = (i0 * (T.n1 - 1) + i1) * groups + grp;   // the sample's block of order 0
+        const size_t order_blocks = (size_t)(T.n0 - 1) * (T.n1 - 1) * groups;
+        OrderShared S;   // (centre samples only; no defaults: each costs a move and a select)
+        double wa[4], wb[4];
+        if (cen) {
+            // the record holds the cell's slot in the bin-sorted arrays
+            const double2 cc = a.cxy[aux];
+            // phase-critical: offset from the cell centre (nearfield.py:408-409)
+            const double ox_ = x - cc.x, oy_ = y - cc.y;
+            // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
+            // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
+            // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
+            // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
+            S.kx0 = p.kvac * ux;
+            S.ky = p.kvac * uy;
+            double a0 = S.kx0 * ox_ + S.ky * oy_;
+            int kq = 0;
+            if (!p.plane_wave) {
+                const double gx = cc.x - p.source_x, gy = cc.y - p.source_y;
+                const double air = sqrt_exact(gx * gx + gy * gy + p.source_z2);
+                double r;
+                reduce_pio2(p.kvac * air, r, kq);
+                a0 = r + a0;
+            }
+            sincos_cw_q(a0, kq, S.E0.i, S.E0.r);
+            S.G = T.center_g[0];
+            sincos_cw(S.G * ox_, S.X.i, S.X.r);
+            S.ky2 = S.ky * S.ky;
+            S.cY = S.ky2 - p.k_glass2;
+            const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+                wa[c] = NP == 1 ? w[c] * Hy_i[0] : w[c];
+                wb[c] = NP == 1 ? w[c] * Hx_i[0] : 0.0;
+            }
+        }
+        const int mine_off = which - grp * SK_TYPES;
+        unsigned long long todo = __ballot(cen);
+        while (todo) {
+            const int kl = __builtin_amdgcn_readlane(cblk, __ffsll((long long)todo) - 1);
+            const bool mine = cen && cblk == kl;
+            todo &= ~__ballot(mine);
+            const double2 *src = a.center_tab + (size_t)(unsigned)kl * CB;
+            stage_block<CB / 64>(src, s_tab, lane_off);
+#pragma unroll
+            for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
+                if (oc + 1 < SIMPLE_ORDERS) {
+                    stage_block<CB / 64>(src + (oc + 1) * order_blocks * CB, ((oc + 1) & 1) ? s_tab1 : s_tab, lane_off);
+                    staged_wait<CB / 64>();
+                } else {
+                    staged_wait<0>();
+                }
+                if (mine) {
+                    OrderShared R = S;
+                    asm volatile("" : "+v"(R.kx0));   // (see the ring samples' order loop)
+                    const double2 *blk = ((oc & 1) ? s_tab1 : s_tab) + mine_off;
+                    if (oc == 0) order_simple<0, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, p, a.e_from_h);
+                    if (oc == 1) order_simple<-1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, p, a.e_from_h);
+                    if (oc == 2) order_simple<1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, p, a.e_from_h);
+                }
+                // (every LDS read of this order has come back - its values were used - before the
+                // load that overwrites its buffer is issued, one iteration on)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (__ballot(cen && out_c)) {
+            if (cen && out_c)
+                report_orders<false>(a, p.kvac * ux, T.center_g[0], p.kvac * uy, a.center_present, a.center_order_of,
+                                     MAX_SLOTS, ux, uy, 0.0);
+        }
+        if (cen && a.premod) {
+            // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
+            const double2 t2 = a.premod[j];
+            const c2 e = {t2.x, t2.y};
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                AccS &q = acc[m];
+                const c2 Ex = cmulf({q.Exr, q.Exi}, e), Ey = cmulf({q.Eyr, q.Eyi}, e);
+                const c2 Hx = cmulf({q.Hxr, q.Hxi}, e), Hy = cmulf({q.Hyr, q.Hyi}, e);
+                q = {Ex.r, Ex.i, Ey.r, Ey.i, Hx.r, Hx.i, Hy.r, Hy.i};
+            }
+        }
+        if (lens && !peri) {
+#pragma unroll
+            for (int m = 0; m < NP; ++m)
+                store_fields(a, m, i, j, {acc[m].Exr, acc[m].Exi}, {acc[m].Eyr, acc[m].Eyi},
+                             {acc[m].Hxr, acc[m].Hxi}, {acc[m].Hyr, acc[m].Hyi});
+        }
+    }
+    if (inb && !lens && !a.outside_is_zero) {
+        const c2 zero = {0.0, 0.0};
+#pragma unroll
+        for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
+    }
+    if (!__ballot(peri)) return;
+
+    // ================= periphery =================
+    // the ring's record (common.h ring_rec) and rotation, requested as soon as the geometry record is
+    // there (behind the centre section, which a wave without centre samples skips: while it runs
+    // the registers are the centre's).  State of ring samples only, deliberately without defaults.
+    double2 r0, r1, cs;
+    if (peri) {
+        const double2 *rr = a.ring_rec + (size_t)(idx - 1) * 2;
+        r0 = rr[0];
+        r1 = rr[1];
+        cs = a.rot_table[aux];
+    }
+    double uxp, uyp, t0, t1, xp, yp;
+    int cell = 0;
+    if (peri) {
+        // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
+        xp = x * cs.x + y * cs.y - r0.x;
+        yp = -x * cs.y + y * cs.x;
+        rotate_dir(ux, uy, cs, uxp, uyp);
+    }
+    // what depends on the ring's grating COLLECTION (table shape and axes): one round per collection
+    // among the wave's ring samples - one, except on the few waves that straddle two collections -
+    // with the descriptor read by scalar loads from the kernel arguments
+    for (unsigned long long pm = __ballot(peri); pm;) {
+        const int c0 = __builtin_amdgcn_readlane(cell_type, __ffsll((long long)pm) - 1);
+        const bool mc = peri && cell_type == c0;
+        pm &= ~__ballot(mc);
+        const CollDesc &C = a.coll[c0];   // wave-uniform index: scalar loads
+        if (mc) {
+            int i0, i1;
+            if (C.flags & 1) {
+                locate_uniform(C.uni_ax, C.lim0, C.lim1, uxp, uyp, i0, t0, i1, t1);
+            } else {
+                const TableDesc &T = a.tables[a.gc[idx - 1]];
+                locate_axis(T.axis0, T.n0, uxp, i0, t0);
+                locate_axis(T.axis1, T.n1, uyp, i1, t1);
+            }
+            cell = i0 * (C.n1 - 1) + i1;
+        }
+    }
+    // the sample's (ring, table cell) block: what the lanes of the wave are matched by
+    const int blk = peri ? (int)(__double_as_longlong(r1.y) & 0x7fffffffll) + cell : -1;
+    // ---- LDS-staged cell blocks.  The 64 samples of a patch fall into 2-4 rings and almost always
+    // one table cell: the wave finds its distinct blocks and fetches each ONCE - block number from
+    // the lead lane -> scalar base, lane l < 48 loads element l straight into LDS - and every lane
+    // reads its block from there (equal addresses broadcast: a wave-wide 16-byte read costs 4 cycles
+    // instead of the 16 of a gather through the vector memory path).  A round = SK_SLOTS distinct
+    // blocks; one round unless a wave spans many rings.
+    unsigned long long todo = __ballot(blk >= 0);
+    int myslot;
+    auto match_and_stage = [&]() {
+        myslot = -1;
+        int lead[SK_SLOTS];
+        unsigned long long rest = todo;
+#pragma unroll
+        for (int s = 0; s < SK_SLOTS; ++s) {
+            lead[s] = -1;
+            if (rest) {   // wave-uniform
+                const int kl = __builtin_amdgcn_readlane(blk, __ffsll((long long)rest) - 1);
+                // every lane with this block is served now (so no served lane can match a later
+                // lead, whose block differs) and kl >= 0 excludes the lanes without a block
+                const bool mine = blk == kl;
+                if (mine) myslot = s;
+                rest &= ~__ballot(mine);
+                lead[s] = kl;
+            }
+        }
+        todo = rest;
+        if (lane < CELL_BLOCK) {
+#pragma unroll
+            for (int s = 0; s < SK_SLOTS; ++s)
+                if (lead[s] >= 0)
+                    stage_block<1>(a.ring_tab + (size_t)(unsigned)lead[s] * CELL_BLOCK, s_tab + s * SK_PITCH, lane_off);
+        }
+    };
+    match_and_stage();   // the first round's blocks are on their way during the arithmetic below
+    bool outside = false;
+    OrderShared S;
+    double wa[4], wb[4], Hw_x[NP], Hw_y[NP];
+    if (peri) {
+        const long long bits = __double_as_longlong(r1.y);
+        // the table-bound tests do not depend on the order: evaluated once; only a failure takes the
+        // reporting path (per order, in the reference's check order).  A sample inside the range
+        // EVERY ring table covers, on a ring whose period its table covers (bit 32 of the ring record),
+        // cannot fail; only the others read their table's bounds.
+        outside = (int)(uxp < a.ring_bounds_all[0]) | (int)(uxp > a.ring_bounds_all[1]) |
+                  (int)(uyp < a.ring_bounds_all[2]) | (int)(uyp > a.ring_bounds_all[3]) | (int)((bits >> 32) & 1);
+        if (outside) {
+            const double *b = a.tables[a.gc[idx - 1]].bounds;
+            const double period = r0.y;
+            outside = (int)(uxp < b[0]) | (int)(uxp > b[1]) | (int)(uyp < b[2]) | (int)(uyp > b[3]) |
+                      (int)(period < b[4]) | (int)(period > b[5]);
+        }
+        // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
+        // nearfield.py:268-269,291 with ox = oy = 0) times the phase-critical propagation phasor
+        // from the grating centre (:337-341, exact argument), through ONE sincos: the large angle
+        // k |r| is reduced to [-pi/4, pi/4] + quadrants first and the small one added to the
+        // remainder.  X = exp(i G x').
+        S.kx0 = p.kvac * uxp;
+        S.ky = p.kvac * uyp;
+        double a0 = S.kx0 * xp + S.ky * yp;
+        int kq = 0;
+        if (!p.plane_wave) {
+            const double rcen = r0.x;
+            const double gx = rcen * cs.x - p.source_x, gy = rcen * cs.y - p.source_y;
+            const double air = sqrt_exact(gx * gx + gy * gy + p.source_z2);
+            double r;
+            reduce_pio2(p.kvac * air, r, kq);
+            a0 = r + a0;
+        }
+        sincos_cw_q(a0, kq, S.E0.i, S.E0.r);
+        S.G = r1.x;   // 2 pi / period
+        sincos_cw(S.G * xp, S.X.i, S.X.r);
+        S.ky2 = S.ky * S.ky;
+        S.cY = S.ky2 - p.k_glass2;
+        // interpolation weights; one source: times the two polarisation weights
+        const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            Hw_y[m] = fma(Hx_i[m], cs.x, Hy_i[m] * cs.y);      // H along x' <-> y table
+            Hw_x[m] = fma(Hy_i[m], cs.x, -(Hx_i[m] * cs.y));   // H along y' <-> x table
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            wa[c] = NP == 1 ? w[c] * Hw_x[0] : w[c];
+            wb[c] = NP == 1 ? w[c] * Hw_y[0] : 0.0;
+        }
+    }
+    AccS pr[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) pr[m] = {0, 0, 0, 0, 0, 0, 0, 0};
+    while (true) {
+        staged_wait<0>();
+        if (myslot >= 0) {
+            const double2 *b = s_tab + myslot * SK_PITCH;
+            // (nothing below changes from round to round, and the compiler would hoist the three
+            // orders' factors in front of the loop - sixty live registers - if it knew)
+            OrderShared R = S;
+            asm volatile("" : "+v"(R.kx0));
+            // (the three orders one after the other: scheduled together, all 48 LDS reads are put in
+            // flight at once and what they displace is spilled)
+            order_simple<0, NP, 1>(pr, b, wa, wb, Hw_x, Hw_y, R, p, a.e_from_h);
+            __builtin_amdgcn_sched_barrier(0);
+            order_simple<-1, NP, 1>(pr, b + 16, wa, wb, Hw_x, Hw_y, R, p, a.e_from_h);
+            __builtin_amdgcn_sched_barrier(0);
+            order_simple<1, NP, 1>(pr, b + 32, wa, wb, Hw_x, Hw_y, R, p, a.e_from_h);
+        }
+        if (!todo) break;   // wave-uniform
+        __builtin_amdgcn_sched_barrier(0);   // (this round's LDS reads are done before the next round's loads go out)
+        match_and_stage();
+    }
+    if (__ballot(outside)) {
+        if (outside) {
+            // rare path: everything it reports is worked out again (nothing kept live for it)
+            const int2v ix = recs[lane];
+            const int ring = (ix.x & ((1 << REC_TYPE_SHIFT) - 1)) - 1;
+            const CollDesc *C = a.coll + (ix.x >> REC_TYPE_SHIFT);   // (per-lane index: ordinary loads from the kernel arguments)
+            double vx = 0.0, vy = 0.0, vz, vinv, vxp, vyp;
+            if (!p.plane_wave) incidence(p, x, y, vx, vy, vz, vinv);
+            rotate_dir(vx, vy, a.rot_table[ix.y], vxp, vyp);
+            const double2 *rr = a.ring_rec + (size_t)ring * 2;
+            report_orders<true>(a, p.kvac * vxp, rr[1].x, p.kvac * vyp, C->present, C->order_of, a.gc[ring], vxp, vyp,
+                                rr[0].y);
+        }
+    }
+    if (peri) {
+        // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
+        const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
+        const double cosr = cs2.x, sinr = cs2.y;
+        // (the propagation phasor already rides in every order's phasor; what is left is the
+        // far-field plan's input modulation, if the plan has one: re-read here, an L2 hit)
+        c2 e = {1.0, 0.0};
+        if (a.premod) {
+            const double2 t2 = a.premod[j];
+            e = {t2.x, t2.y};
+        }
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            AccS q = pr[m];
+            if (a.premod) {
+                const c2 Ex = cmulf({q.Exr, q.Exi}, e), Ey = cmulf({q.Eyr, q.Eyi}, e);
+                const c2 Hx = cmulf({q.Hxr, q.Hxi}, e), Hy = cmulf({q.Hyr, q.Hyi}, e);
+                q = {Ex.r, Ex.i, Ey.r, Ey.i, Hx.r, Hx.i, Hy.r, Hy.i};
+            }
+            // back to the lab frame (nearfield.py:351-354)
+            const c2 Ex = {fma(q.Exr, cosr, -(q.Eyr * sinr)), fma(q.Exi, cosr, -(q.Eyi * sinr))};
+            const c2 Ey = {fma(q.Exr, sinr, q.Eyr * cosr), fma(q.Exi, sinr, q.Eyi * cosr)};
+            const c2 Hx = {fma(q.Hxr, cosr, -(q.Hyr * sinr)), fma(q.Hxi, cosr, -(q.Hyi * sinr))};
+            const c2 Hy = {fma(q.Hxr, sinr, q.Hyr * cosr), fma(q.Hxi, sinr, q.Hyi * cosr)};
+            store_fields(a, m, i, j, Ex, Ey, Hx, Hy);
+        }
+    }
+}
+
+int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid) {
+    if (a.n_pol == 1)
+        hipLaunchKernelGGL((nearfield_simple_kernel<1>), grid, dim3(64), 0, ctx->stream, a);
+    else if (a.n_pol == 2)
+        hipLaunchKernelGGL((nearfield_simple_kernel<2>), grid, dim3(64), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((nearfield_simple_kernel<3>), grid, dim3(64), 0, ctx->stream, a);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+}  // namespace ml

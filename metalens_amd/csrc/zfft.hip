@@ -16,8 +16,7 @@
 //
 // Kernels in this file:
 //   zfft_kernel<R3, ...>       the one-level transform, 256 ... 8192 samples (R3 = 1 ... 32), with a
-//                              register prefetch of the next row; <..., LEAN>: <= 128 VGPRs, no prefetch
-//                              (overlap experiments only); sub_s / sub_i: one of s interleaved sub-
+//                              register prefetch of the next row; sub_s / sub_i: one of s interleaved sub-
 //                              sequences of a longer lattice (two-level, up to 65536 samples)
 //   zfft_pass_kernel           the same row in two passes over groups of R3 / 2 residues, half the LDS:
 //                              8192-sample lattices (two workgroups per CU instead of one) and 16384-
@@ -102,36 +101,13 @@ __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int
     }
 }
 
-// the same for the lean kernel (pass 1 only: one resident run starting at sample 0): a scalar
-// window [lo, hi) per row and a scalar base per load, so that the 16 loads share ONE lane offset
-// instead of sixteen 64-bit lane addresses (the registers the lean kernel does not have)
-template <int R3T>
-__device__ __forceinline__ void load_row_lean(const FftArgs &a, const zf::Geo &g, int row, int tid, cd *v) {
-    const int NT = 16 * g.R3;
-    const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2;   // wave-uniform
-    const int first = a.row_first ? a.row_first[row % a.rf_mod] : 0;
-    const int lo = first, hi = min(a.h0, g.n_valid - first);
-    typedef double double2v __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int n2 = 0; n2 < 16; ++n2) {
-        const double2v *base = reinterpret_cast<const double2v *>(src + NT * n2);   // uniform
-        const int n = tid + NT * n2;
-        double2v t = {0.0, 0.0};
-        if (n >= lo && n < hi) t = __builtin_nontemporal_load(base + tid);
-        v[n2] = zf::mk(t.x, t.y);
-    }
-}
-
 // R3T > 0: residues known at compile time (the div / mod by R3 become shifts), R3T == 0: any R3.
 // The next row's loads are issued before the current row's arithmetic (its 16 values wait in a
 // second register set), so a workgroup always has a row in flight; the stage-1 twiddles live in
 // LDS ([k2][n1]: the lanes of a 16-lane group read neighbouring or equal slots) to pay for it.
 // PASS (1: rows of the aperture, 2: columns of stage 1's result) only names the instantiation, so
 // that a profile lists the two passes separately.
-// LEAN: no second register set for the next row (the loads of a row are issued when its turn
-// comes): <= 128 VGPRs, so that a 256-thread workgroup leaves three quarters of every SIMD's
-// register file to co-resident synthesis waves (the banded step, ctx.hip ml_hotpath_step_async).
-template <int R3T, int NTMAX, int MINW, int PASS, bool LEAN = false>
+template <int R3T, int NTMAX, int MINW, int PASS>
 __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
     cd *lds = reinterpret_cast<cd *>(zfft_lds_raw);
@@ -144,27 +120,21 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     // from LDS per row (W^(4 a + b) is one product): 3 LDS reads per row instead of 15
     cd tb[4];
     tb[0] = zf::mk(1.0, 0.0);
-    if (!LEAN) {
 #pragma unroll
-        for (int b = 1; b < 4; ++b) tb[b] = a.tw1[n1 * 16 + b];
-    }
+    for (int b = 1; b < 4; ++b) tb[b] = a.tw1[n1 * 16 + b];
     // the (up to two) bins this thread evaluates in stage 3 are the same for every row
     const int bin0 = tid, bin1 = tid + NT;
     const bool own0 = bin0 < g.M, own1 = bin1 < g.M, few = g.M <= 2 * NT;
     cd w0 = zf::mk(0, 0), p0 = w0, w1 = w0, p1 = w0;
     int k0 = 0, k1 = 0;
     if (own0) {
-        if (!LEAN) {
-            w0 = a.wk[bin0];
-            p0 = a.pj[bin0];
-        }
+        w0 = a.wk[bin0];
+        p0 = a.pj[bin0];
         k0 = a.kbin[bin0];
     }
     if (own1) {
-        if (!LEAN) {
-            w1 = a.wk[bin1];
-            p1 = a.pj[bin1];
-        }
+        w1 = a.wk[bin1];
+        p1 = a.pj[bin1];
         k1 = a.kbin[bin1];
     }
     // bins 256 apart differ in k0 only and sum the same LDS values: one pass for both
@@ -174,18 +144,13 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
     int idx = blockIdx.x >> 3;
     int row = xcd * a.chunk + idx;   // block-uniform
-    cd v[16], nx[LEAN ? 1 : 16];
-    if (!LEAN && idx < a.chunk && row < a.rows) load_row<R3T, PASS == 1>(a, g, row, tid, v);
+    cd v[16], nx[16];
+    if (idx < a.chunk && row < a.rows) load_row<R3T, PASS == 1>(a, g, row, tid, v);
     while (idx < a.chunk && row < a.rows) {
         const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
         const bool more = idx_n < a.chunk && row_n < a.rows;
-        if (LEAN)
-            load_row_lean<R3T>(a, g, row, tid, v);
-        else if (more)
-            load_row<R3T, PASS == 1>(a, g, row_n, tid, nx);
-        if (LEAN) {
-            zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
-        } else {
+        if (more) load_row<R3T, PASS == 1>(a, g, row_n, tid, nx);
+        {
             cd ta[4];
             ta[0] = tb[0];
 #pragma unroll
@@ -199,16 +164,6 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
         const double al = a.alpha[row / a.alpha_rb];
-        if (LEAN) {   // per-bin constants re-read per row (L1 hits) instead of living in registers
-            if (own0) {
-                w0 = a.wk[bin0];
-                p0 = a.pj[bin0];
-            }
-            if (own1) {
-                w1 = a.wk[bin1];
-                p1 = a.pj[bin1];
-            }
-        }
         if (few && pair) {
             // the two bins share their LDS operands
             cd xa, xb;
@@ -255,10 +210,8 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
             }
         }
         __syncthreads();   // the next row's stage 1 overwrites the buffer
-        if (!LEAN) {
 #pragma unroll
-            for (int n2 = 0; n2 < 16; ++n2) v[n2] = nx[n2];
-        }
+        for (int n2 = 0; n2 < 16; ++n2) v[n2] = nx[n2];
         idx = idx_n;
         row = row_n;
     }
@@ -670,9 +623,9 @@ int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, i
     return ML_OK;
 }
 
-template <int R3T, int NTMAX, int MINW, int PASS, bool LEAN = false>
+template <int R3T, int NTMAX, int MINW, int PASS>
 static int launch_one(hipStream_t stream, const FftArgs &a, int grid, size_t lds_bytes) {
-    auto kern = zfft_kernel<R3T, NTMAX, MINW, PASS, LEAN>;
+    auto kern = zfft_kernel<R3T, NTMAX, MINW, PASS>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         ML_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -751,7 +704,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
 #define ML_FFT_PASSES_R32 2
 #endif
         const int P = c.passes > 0 ? c.passes : (R3 == 32 ? ML_FFT_PASSES_R32 : 1);
-        if (P > 1 && R3 % P == 0 && !(c.lean && c.in_es == 1 && R3 <= 32)) {
+        if (P > 1 && R3 % P == 0) {
             const int R3P = R3 / P, NTp = 16 * R3P, M = a.g.M;
             FftArgs ap = a;
             zfft_choose_pads(c.N_eff / P, M, c.j0, &ap.g.pad1, &ap.g.pad2);
@@ -772,18 +725,6 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
         }
     }
     ML_REQUIRE(a.g.R3 <= 32, "a lattice of %d samples does not fit one workgroup (%d wanted bins)", c.N_eff, c.M);
-    if (c.lean && c.in_es == 1 && a.sub_s == 1) {
-        // co-resident form (banded step): one workgroup per CU is what fits beside the synthesis
-        grid = std::min(256 * std::max(1, c.lean_per_cu), a.chunk * 8);
-        grid = (grid + 7) / 8 * 8;
-        switch (a.g.R3) {
-            case 4: return launch_one<4, 64, 4, 1, true>(stream, a, grid, lds_bytes);
-            case 8: return launch_one<8, 128, 4, 1, true>(stream, a, grid, lds_bytes);
-            case 16: return launch_one<16, 256, 4, 1, true>(stream, a, grid, lds_bytes);
-            case 32: return launch_one<32, 512, 4, 1, true>(stream, a, grid, lds_bytes);
-            default: break;   // other lattices: the ordinary kernel
-        }
-    }
     if (c.in_es == 1) switch (a.g.R3) {   // pass 1: contiguous rows
             case 4: return launch_one<4, 64, 2, 1>(stream, a, grid, lds_bytes);
             case 8: return launch_one<8, 128, 2, 1>(stream, a, grid, lds_bytes);

@@ -140,7 +140,7 @@ ZF_HD void stage1_regs(const Geo &g, int t, cd *v, const cd *ta, const cd *tb, c
 }
 // the same with the twiddles applied IN PLACE in two steps, W^(4a) then W^b (two products per
 // element instead of one product of two tabulated values and one per element - the same 24
-// complex multiplications per thread, no temporaries): the form of the lean kernel, whose
+// complex multiplications per thread, no temporaries): the form of the multi-row and interleaved kernels, whose
 // register budget has no room for the nine products.  tw = the [k2][n1] twiddle table in LDS.
 ZF_HD void stage1_inplace(const Geo &g, int t, cd *v, const cd *tw, int n1, cd *lds) {
     dft16(v);

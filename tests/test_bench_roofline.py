@@ -27,6 +27,6 @@ def test_nearfield_roof_without_a_profile_falls_back_to_hbm():
 
 def test_pmc_key_names_the_configuration():
     import bench
-    assert bench.pmc_key(1, 4096, 512, 'f64', 'auto', 1.0, 1, 0) == \
+    assert bench.pmc_key(1, 4096, 512, 'f64', 'auto', 1.0, 1) == \
         'gpus=1,aperture=4096,farfield=512,precision=f64,method=auto,zoom=1,pols=1'
-    assert bench.pmc_key(1, 4096, 512, 'f64', 'auto', 1.0, 3, 8).endswith('pols=3,overlap=8')
+    assert bench.pmc_key(1, 4096, 512, 'f64', 'auto', 1.0, 3).endswith('pols=3')
