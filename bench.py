@@ -65,33 +65,40 @@ def load_pmc_table():
         return {}
 
 
-def nearfield_roof(avg_ms, nf_bytes, pmc_nf):
-    """roofline object of the synthesis kernel: by fp64 vector issue where the configuration has a
-    counter profile (SQ_INSTS_VALU per launch in ``pmc_nf``), with the HBM figure of the compulsory
-    stores beside it; the HBM figure alone otherwise"""
+def kernel_source_id():
+    """sha256 over the kernel sources the counter table was recorded with (tools/pmc_table.py stores it):
+    a table recorded for other kernels is reported as stale instead of silently quoted"""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'metalens_amd', 'csrc')
+    for name in sorted(os.listdir(src)):
+        if name.endswith(('.hip', '.h')) or name == 'Makefile':
+            with open(os.path.join(src, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+    return h.hexdigest()[:16]
+
+
+def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False):
+    """roofline object of the synthesis: ALGORITHMIC bytes per step (64 B per sample and source: the
+    four complex fields written once) / the launch time, against the 8 TB/s of HBM, with the counter
+    traffic beside it; and, where the configuration has a counter profile, what
+    actually bounds the kernel: vector-instruction issue (``valu``)."""
     hbm_gbs = nf_bytes / (avg_ms * 1e-3) / 1e9
     insts = pmc_nf.get('SQ_INSTS_VALU')
     roof = {
-        'kernel': 'nearfield_field_kernel', 'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-        'hbm_achieved': hbm_gbs, 'hbm_peak': HBM_PEAK_GBS, 'hbm_frac': hbm_gbs / HBM_PEAK_GBS,
-        'traffic': pmc_nf.get('traffic_bytes'), 'valu_insts': insts}
+        'bound': 'hbm', 'kernel': 'nearfield_ring_kernel + nearfield_centre_kernel (one synthesis)',
+        'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
+        'traffic': pmc_nf.get('traffic_bytes'), 'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
+        'note': 'achieved = 64 B per aperture sample (Ex, Ey, Hx, Hy written once; SURVEY.md 8(d)) / the '
+                'HIP-event time of the synthesis launches of a step; traffic = FETCH_SIZE x 2 + WRITE_SIZE '
+                'of the same launches (profiles/pmc_table.json).  The kernel is not bound by HBM but by '
+                'vector-instruction issue and the latency of its dependent loads: see `valu`'}
     if insts:
-        # THE ROOF THAT BINDS: vector-instruction issue.  SQ_INSTS_VALU wave-instructions per
-        # launch (counter, profiles/pmc_table.json) x 4 cycles each / (1024 SIMDs x 2.4 GHz) is
-        # the time the launch needs if every SIMD issues back to back
+        # SQ_INSTS_VALU wave-instructions per launch (counter) x 4 cycles / (1024 SIMDs x 2.4 GHz) = the
+        # time the launch needs if every SIMD issues back to back
         issue_ms = insts * CYCLES_PER_VALU / (SIMDS * CLOCK_HZ) * 1e3
-        roof.update({'bound': 'valu_fp64', 'achieved': insts / (avg_ms * 1e-3) / 1e9,
-                     'peak': VALU_PEAK_GINST, 'unit': 'G wave-instructions/s',
-                     'frac': issue_ms / avg_ms, 'valu_issue_ms': issue_ms})
-        roof['note'] = ('bound by fp64 vector issue, not HBM: frac = (SQ_INSTS_VALU x 4 cycles / '
-                        '(1024 SIMDs x 2.4 GHz)) / launch time; hbm_frac = the 64 B/sample of '
-                        'compulsory stores / launch time / 8 TB/s (DESIGN.md 4.1, 5)')
-    else:
-        roof.update({'bound': 'hbm', 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': hbm_gbs / HBM_PEAK_GBS})
-        roof['note'] = ('no counter profile for this configuration (profiles/pmc_table.json): the HBM '
-                        'figure of the compulsory 64 B/sample of stores; the kernel is bound by fp64 '
-                        'vector issue where it has been profiled (DESIGN.md 4.1)')
+        roof['valu'] = {'insts': insts, 'issue_ms': issue_ms, 'issue_frac': issue_ms / avg_ms,
+                        'peak_ginst_per_s': VALU_PEAK_GINST, 'stale': bool(stale)}
     return roof
 
 
@@ -271,9 +278,11 @@ def main():
                     help="with --profile main: time every n-th step's two kernels (a sample of the "
                          'timed region at 1/n of the instrumentation cost); --profile all times '
                          'every launch')
-    ap.add_argument('--reduce', choices=('amplitudes', 'vectors'), default='amplitudes',
-                    help='multi-GPU: all-reduce the 2 projected amplitudes (default) or the 4 '
-                         'radiation vectors')
+    ap.add_argument('--reduce', choices=('amplitudes', 'amplitudes-allreduce', 'vectors', 'none'), default='amplitudes',
+                    help='multi-GPU: reduce-scatter the 2 projected amplitudes over blocks of direction rows, '
+                         'each rank taking the power of its block (default); the same by an all-reduce; '
+                         'all-reduce the 4 radiation vectors; none = the same shards with NO collective '
+                         '(what the decomposition alone costs; the far field is then a per-rank partial)')
     ap.add_argument('--precision', choices=('f64', 'f32'), default='f64',
                     help="arithmetic of the far-field GEMMs: f64 (BASELINE metric, 1e-12) or f32 "
                          "(fp32 matrix cores, 1e-4; near field, storage and projection stay fp64)")
@@ -362,7 +371,22 @@ def main():
     for _ in range(prime):
         hp.step()
     hp.sync()
+    # ... and then until two consecutive K-step blocks agree to 3 % (at most eight more): `value` comes
+    # from the FIRST timed block, which must not be the one that is still warming up
+    last = None
+    for _ in range(8):
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hp.step()
+        hp.sync()
+        dt = float(dist.allreduce_host(ctx, [time.perf_counter() - t0], 'max')[0])
+        prime += args.steps
+        settled = last is not None and abs(dt - last) <= 0.03 * last
+        last = dt
+        if settled:
+            break
     every = max(1, min(args.profile_every, args.steps)) if args.profile == 'main' else 1
+    timed_kernels = ('nearfield', 'zgemm_stage1') + (('comm_wait', 'collective') if world > 1 and not replicas else ())
     block_ms = []
     prof = None
     for block in range(max(1, args.blocks)):
@@ -371,7 +395,7 @@ def main():
             for _ in range(args.warmup):
                 hp.step()
             ctx.profile(args.profile != 'none',
-                        kernels=('nearfield', 'zgemm_stage1') if args.profile == 'main' else None,
+                        kernels=timed_kernels if args.profile == 'main' else None,
                         every=every)
             ctx.profile_reset()       # synchronises the stream
         dist.barrier(ctx)
@@ -392,6 +416,34 @@ def main():
         hp.step = one_step
         hp.step()
         hp.sync()
+    # ---- multi-GPU diagnostics: the same shards WITHOUT the collective (what the decomposition alone
+    # costs), every rank's kernel sums, what the main stream waited for the collective
+    no_coll_ms = None
+    if world > 1 and not replicas and args.reduce != 'none':
+        hp_nc = HotPath(source, wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                        lens['hexgridset'], x, x, ux, uy, ctx=ctx, pair_list=bool(args.pair_list), rank=rank,
+                        world=world, precision=args.precision, reduce='none',
+                        fuse_modulation=bool(args.fuse_modulation), method=args.method, sharding=args.sharding)
+        for _ in range(2):
+            hp_nc.step()
+        dist.barrier(ctx)
+        hp_nc.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hp_nc.step()
+        hp_nc.sync()
+        dist.barrier(ctx)
+        no_coll_ms = 1e3 * float(dist.allreduce_host(ctx, [time.perf_counter() - t0], 'max')[0]) / args.steps
+        hp.step()      # (the far field fetched below is the reduced one again)
+        hp.sync()
+    per_rank = None
+    if world > 1 and not replicas:
+        names = ('nearfield', 'zgemm_stage1', 'zgemm_stage2', 'project', 'comm_wait', 'collective')
+        mine = np.zeros((world, len(names)))
+        mine[rank] = [prof[k]['total_ms'] / prof[k]['launches'] if prof[k]['launches'] else -1.0 for k in names]
+        allv = dist.allreduce_host(ctx, mine.ravel(), 'sum').reshape(world, len(names))
+        per_rank = [{'rank': r, **{k: (float(allv[r, c]) if allv[r, c] >= 0 else None) for c, k in enumerate(names)}}
+                    for r in range(world)]
     res = hp.results()
     if args.dump and rank == 0:
         np.savez(args.dump, P=res['P'], a_theta=res['a_theta'], a_phi=res['a_phi'])
@@ -455,9 +507,12 @@ def main():
                    '%d listed directions' % args.pair_list if args.pair_list else
                    '%dx%d far-field directions (bins of the aperture FFT lattice x %g)'
                    % (u.size, u.size, args.zoom)))
-        par = ('aperture rows (%s) sharded over %d GPU(s), 1 RCCL all-reduce of the %s'
-               % (hp.sharding, world, 'two projected amplitudes' if args.reduce == 'amplitudes'
-                  else 'four radiation vectors'))
+        par = ('aperture rows (%s) sharded over %d GPU(s), %s'
+               % (hp.sharding, world,
+                  {'amplitudes': '1 RCCL reduce-scatter of the two projected amplitudes over blocks of direction rows',
+                   'amplitudes-allreduce': '1 RCCL all-reduce of the two projected amplitudes',
+                   'vectors': '1 RCCL all-reduce of the four radiation vectors',
+                   'none': 'NO collective (per-rank partial far fields)'}[args.reduce]))
     line = {
         'metric': 'aperture x far-field pair-evals/sec',
         'value': pairs * args.steps / elapsed,
@@ -493,6 +548,9 @@ def main():
     key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols)
     line['config']['pmc_key'] = key
     pmc = load_pmc_table().get(key, {})
+    # counters recorded for other kernel sources are quoted with a flag, not silently
+    stale = bool(pmc) and pmc.get('source_id') != kernel_source_id()
+    line['config']['pmc_stale'] = stale
     roofs = {}
     s1 = prof['zgemm_stage1']
     if s1['launches']:
@@ -510,6 +568,7 @@ def main():
                 # zeros and are not read, so this is the kernel's real HBM rate)
                 'traffic_gbs': traffic / (avg_ms * 1e-3) / 1e9 if traffic else None,
                 'traffic_frac': traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
+                'traffic_stale': stale,
                 'avg_launch_ms': avg_ms, 'bytes_per_launch': nbytes,
                 'note': 'algorithmic bytes = every aperture sample read once (4 fields x 16 B) + the '
                         'row transforms written; samples outside the lens circle are known zeros '
@@ -546,7 +605,7 @@ def main():
     if nf['launches']:
         # one field set (4 complex128 planes) per member of a polarisation batch
         nf_bytes = 64.0 * local_rows * side * n_pols
-        roofs['nearfield'] = nearfield_roof(nf['total_ms'] / nf['launches'], nf_bytes, pmc.get('nearfield', {}))
+        roofs['nearfield'] = nearfield_roof(nf['total_ms'] / nf['launches'], nf_bytes, pmc.get('nearfield', {}), stale)
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
@@ -558,6 +617,23 @@ def main():
         line['roofline']['step_hbm_frac'] = step_bytes / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)
         line['roofline']['step_bytes'] = step_bytes
         line['roofline']['step_traffic'] = pmc.get('step_traffic_bytes')
+    if world > 1 and not replicas:
+        n_ranks, rk, backend = _lib.c_int(0), _lib.c_int(0), _lib.c_int(0)
+        _lib.check(ctx.lib.ml_comm_info(ctx.handle, _lib.byref(n_ranks), _lib.byref(rk), _lib.byref(backend)))
+        amp_bytes = 2 * 16.0 * n_dir                       # two complex128 amplitude planes
+        line['multi_gpu'] = {
+            'backend': ('none', 'rccl', 'file (test communicator: timings mean nothing)')[backend.value],
+            'ranks_reported_by_backend': n_ranks.value, 'reduce': args.reduce,
+            'bytes_sent_per_rank_per_step': ({'amplitudes': (world - 1) / world * amp_bytes,
+                                              'amplitudes-allreduce': 2 * (world - 1) / world * amp_bytes,
+                                              'vectors': 2 * (world - 1) / world * 2 * amp_bytes,
+                                              'none': 0.0}[args.reduce]),
+            # per timed launch, HIP events: every rank's kernels, what its main stream waited for a
+            # reduction that still held the amplitude slot (comm_wait), the collective on its own stream
+            'per_rank_ms': per_rank,
+            'ms_per_step_no_collective': no_coll_ms,
+            'note': 'ms_per_step - ms_per_step_no_collective = what the collective costs a step; per_rank_ms '
+                    'tells a slow rank (decomposition) from a slow link (collective / comm_wait)'}
     if rel_err is not None:
         line['rel_err'] = rel_err
     # ---- what a single call on a NEW sample grid costs (rows a1 / a5 of the scope table are plan-like:

@@ -244,6 +244,21 @@ int ml_comm_unique_id(uint8_t id[128]);
 int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank);
 int ml_comm_allreduce_host(ml_ctx *ctx, double *values, int count, int op);
 int ml_comm_barrier(ml_ctx *ctx);
+/* ranks of the communicator as the backend itself reports them (RCCL: ncclCommCount), this rank,
+ * and the backend: 0 none (single process), 1 RCCL, 2 the file communicator of the tests          */
+int ml_comm_info(ml_ctx *ctx, int *n_ranks, int *rank, int *backend);
+/* How ml_farfield_project_reduce sums the ranks' amplitudes.  ML_REDUCE_SCATTER (default): a
+ * reduce-scatter over blocks of direction rows - rank r ends up with the sum of block r and takes the
+ * power of that block; (G - 1) / G of the payload crosses the links per rank, half of what an
+ * all-reduce moves; ml_farfield_gather completes every rank's picture when the host wants the
+ * whole map.  ML_REDUCE_ALL: the all-reduce (every rank holds everything after every step); also
+ * what runs when the direction rows do not divide by the rank count.                              */
+#define ML_REDUCE_SCATTER 0
+#define ML_REDUCE_ALL 1
+int ml_comm_set_reduce(ml_ctx *ctx, int mode);
+/* all-gather of the reduced amplitude blocks and power rows (collective: every rank calls it);
+ * a no-op when every rank already holds everything                                                */
+int ml_farfield_gather(ml_ctx *ctx);
 
 /* ---- measurement -----------------------------------------------------------------------
  * Per-kernel HIP-event timing on the context's stream.  Kernel ids: */
@@ -255,7 +270,11 @@ enum {
     ML_K_PROJECT = 4,
     ML_K_LATTICE_POWER = 5,
     ML_K_COLDOT = 6,
-    ML_K_COUNT = 7
+    /* multi-GPU steps (ml_farfield_project_reduce): what the main stream waits for a reduction
+     * that still holds the amplitude slot it wants, and the collective itself on its own stream */
+    ML_K_COMM_WAIT = 7,
+    ML_K_COLLECTIVE = 8,
+    ML_K_COUNT = 9
 };
 int ml_profile_enable(ml_ctx *ctx, int on);
 /* which kernels are timed while profiling is on: bit k = kernel id k (default: all).  Every

@@ -24,7 +24,7 @@ TIE_CAPACITY = 1048576   # ML_TIE_CAPACITY
 
 K_NEARFIELD, K_TWIDDLE, K_ZGEMM_STAGE1, K_ZGEMM_STAGE2, K_PROJECT, K_LATTICE_POWER, K_COLDOT = range(7)
 KERNEL_NAMES = ('nearfield', 'twiddle', 'zgemm_stage1', 'zgemm_stage2', 'project',
-                'lattice_power', 'coldot')
+                'lattice_power', 'coldot', 'comm_wait', 'collective')
 
 # every symbol include/metalens_hip.h declares (tests/test_cabi_symbols.py checks the header
 # against this list and the built library)
@@ -44,6 +44,7 @@ SYMBOLS = (
     'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_host_alloc', 'ml_host_free',
+    'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather',
 )
 
 
@@ -138,6 +139,11 @@ def load():
     lib.ml_comm_init.argtypes = [c_void_p, POINTER(c_uint8), c_int, c_int]
     lib.ml_comm_allreduce_host.argtypes = [c_void_p, _dp, c_int, c_int]
     lib.ml_comm_barrier.argtypes = [c_void_p]
+    # (A/B timing against an older build of the library, METALENS_HIP_LIB: it may lack the newest entries)
+    if hasattr(lib, 'ml_comm_info'):
+        lib.ml_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
+        lib.ml_comm_set_reduce.argtypes = [c_void_p, c_int]
+        lib.ml_farfield_gather.argtypes = [c_void_p]
     lib.ml_profile_enable.argtypes = [c_void_p, c_int]
     lib.ml_profile_reset.argtypes = [c_void_p]
     lib.ml_profile_get.argtypes = [c_void_p, c_int, POINTER(c_int64), _dp]

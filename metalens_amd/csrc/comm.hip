@@ -24,6 +24,10 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
                               ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
+                                  ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -52,6 +56,9 @@ static int load_rccl() {
     ML_SYM(GetUniqueId, "ncclGetUniqueId")
     ML_SYM(CommInitRank, "ncclCommInitRank")
     ML_SYM(AllReduce, "ncclAllReduce")
+    ML_SYM(ReduceScatter, "ncclReduceScatter")
+    ML_SYM(AllGather, "ncclAllGather")
+    ML_SYM(CommCount, "ncclCommCount")
     ML_SYM(CommDestroy, "ncclCommDestroy")
     ML_SYM(GetErrorString, "ncclGetErrorString")
 #undef ML_SYM
@@ -88,6 +95,8 @@ static std::string comm_file_name(const ml_ctx *ctx, long seq, int rank) {
     return b;
 }
 
+// op: 0 sum, 1 max (all-reduce of the whole buffer); 2 reduce-scatter (sum, only this rank's chunk of
+// count / n_ranks doubles is summed and written back); 3 all-gather (chunk r from rank r)
 static int allreduce_file(ml_ctx *ctx, double *buf, size_t count, int op, hipStream_t stream) {
     ML_HIP(hipStreamSynchronize(stream));
     std::vector<double> mine(count), other(count), acc(count);
@@ -116,8 +125,18 @@ static int allreduce_file(ml_ctx *ctx, double *buf, size_t count, int op, hipStr
             ML_REQUIRE(ok, "short read from %s", name.c_str());
             src = other.data();
         }
+        if (op == 3) {
+            const size_t chunk = count / ctx->n_ranks;
+            for (size_t k = r * chunk; k < (r + 1) * chunk; ++k) acc[k] = src[k];
+            continue;
+        }
         for (size_t k = 0; k < count; ++k)
             acc[k] = r == 0 ? src[k] : (op == 1 ? (src[k] > acc[k] ? src[k] : acc[k]) : acc[k] + src[k]);
+    }
+    if (op == 2) {
+        const size_t chunk = count / ctx->n_ranks, at = ctx->rank * chunk;
+        ML_HIP(hipMemcpy(buf + at, acc.data() + at, chunk * sizeof(double), hipMemcpyHostToDevice));
+        return ML_OK;
     }
     ML_HIP(hipMemcpy(buf, acc.data(), count * sizeof(double), hipMemcpyHostToDevice));
     return ML_OK;
@@ -137,6 +156,30 @@ static int allreduce_dev(ml_ctx *ctx, double *buf, size_t count, int op, hipStre
 
 int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count, hipStream_t stream) {
     return allreduce_dev(ctx, buf, count, 0, stream);
+}
+
+int comm_reduce_scatter_sum(ml_ctx *ctx, double *buf, size_t chunk, hipStream_t stream) {
+    if (ctx->comm_file) return allreduce_file(ctx, buf, chunk * ctx->n_ranks, 2, stream);
+    if (ctx->n_ranks <= 1 && !ctx->comm) return ML_OK;
+    if (!ctx->comm) {
+        set_error("ml_comm_init has not been called");
+        return ML_ESTATE;
+    }
+    // in place: the received chunk lands where this rank's own chunk of the send buffer is
+    ML_NCCL(g_rccl.ReduceScatter(buf, buf + (size_t)ctx->rank * chunk, chunk, ncclDouble, ncclSum,
+                                 (ncclComm_t)ctx->comm, stream));
+    return ML_OK;
+}
+
+int comm_allgather(ml_ctx *ctx, double *buf, size_t chunk, hipStream_t stream) {
+    if (ctx->comm_file) return allreduce_file(ctx, buf, chunk * ctx->n_ranks, 3, stream);
+    if (ctx->n_ranks <= 1 && !ctx->comm) return ML_OK;
+    if (!ctx->comm) {
+        set_error("ml_comm_init has not been called");
+        return ML_ESTATE;
+    }
+    ML_NCCL(g_rccl.AllGather(buf + (size_t)ctx->rank * chunk, buf, chunk, ncclDouble, (ncclComm_t)ctx->comm, stream));
+    return ML_OK;
 }
 
 int comm_join(ml_ctx *ctx, bool host) {
@@ -202,6 +245,11 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     }
     const char *force = getenv("ML_FORCE_RCCL");
     if (n_ranks == 1 && !(force && atoi(force))) return ML_OK;
+    // The step's collective (a few MB per rank) runs on its own stream BESIDE the next step's synthesis,
+    // whose waves fill every SIMD's register file: each CU a collective kernel occupies is a CU the
+    // synthesis loses.  Four channels carry the payload in well under a step; RCCL's default
+    // takes several times as many workgroups.  The caller's own NCCL_MAX_NCHANNELS wins.
+    setenv("NCCL_MAX_NCHANNELS", "4", 0);
     ML_TRY(load_rccl());
     ncclUniqueId u;
     memcpy(&u, id, 128);
@@ -255,6 +303,22 @@ int ml_comm_allreduce_host(ml_ctx *ctx, double *values, int count, int op) {
     ML_HIP(hipMemcpyAsync(values, ctx->comm_scratch.p, count * sizeof(double),
                           hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
+    return ML_OK;
+}
+
+int ml_comm_set_reduce(ml_ctx *ctx, int mode) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(mode == ML_REDUCE_SCATTER || mode == ML_REDUCE_ALL, "unknown reduction mode %d", mode);
+    ctx->reduce_by_allreduce = mode == ML_REDUCE_ALL;
+    return ML_OK;
+}
+
+int ml_comm_info(ml_ctx *ctx, int *n_ranks, int *rank, int *backend) {
+    ML_REQUIRE(ctx && n_ranks && rank && backend, "NULL argument");
+    *n_ranks = ctx->n_ranks;
+    *rank = ctx->rank;
+    *backend = ctx->comm_file ? 2 : ctx->comm ? 1 : 0;
+    if (ctx->comm) ML_NCCL(g_rccl.CommCount((ncclComm_t)ctx->comm, n_ranks));   // what RCCL itself says
     return ML_OK;
 }
 

@@ -221,6 +221,11 @@ struct FarfieldPlan {
     int il_pad1 = 0, il_pad2 = 0;
     long serial = 0;   // incremented by every ml_farfield_plan call
     bool amplitudes_reduced = false;   // ml_farfield_project_reduce ran on the current vectors
+    // ... and left the amplitudes RANK-BLOCKED when amp_rows > 0: blocks of amp_rows direction rows, both
+    // planes of a block contiguous (what a reduce-scatter deals to the ranks; farfield.hip ProjArgs);
+    // amp_gathered: every rank holds every block's sum (and the whole power map), not only its own
+    int amp_rows = 0;
+    bool amp_gathered = true;
     int nx_total = 0, ny = 0, mx = 0, my = 0, pair_list = 0;
     double dxp = 0, dyp = 0, wavelength = 0, n_glass = 0;
     DevBuf ux, uy;       // direction cosines
@@ -330,7 +335,7 @@ struct ml_ctx {
     // (grid_serial, layout_serial, ovr_serial, samples)
     ml::DevBuf geo_ix, active_list, active_count, active_flag;
     long geo_key[4] = {-1, -1, -1, -1};
-    int n_active = -1;   // patches with lens samples; -1: not read back yet
+    int n_active[3] = {-1, 0, 0};   // entries of the three patch lists (NfArgs::active_list); [0] = -1: not read back yet
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores
@@ -366,6 +371,7 @@ struct ml_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t amp_ready[2] = {nullptr, nullptr}, reduce_done[2] = {nullptr, nullptr};
     bool reduce_in_flight = false;
+    bool reduce_by_allreduce = false;   // ml_comm_set_reduce: all-reduce instead of reduce-scatter (comparison runs)
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
     // ML_COMM_BACKEND=file: TEST backend, all-reduce through files in /tmp (several ranks may
@@ -379,16 +385,19 @@ struct ml_ctx {
 namespace ml {
 
 // profile helpers (ctx.hip)
-void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b);
-void prof_end(ml_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b);
+void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b, hipStream_t stream = nullptr);
+void prof_end(ml_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b, hipStream_t stream = nullptr);
 int prof_harvest(ml_ctx *ctx);
 
 struct ProfScope {
     ml_ctx *ctx;
     int kernel;
+    hipStream_t stream;   // the stream the timed work is queued on (default: the context's)
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(ml_ctx *c, int k) : ctx(c), kernel(k) { prof_begin(ctx, kernel, &a, &b); }
-    ~ProfScope() { prof_end(ctx, kernel, a, b); }
+    ProfScope(ml_ctx *c, int k, hipStream_t s = nullptr) : ctx(c), kernel(k), stream(s) {
+        prof_begin(ctx, kernel, &a, &b, stream);
+    }
+    ~ProfScope() { prof_end(ctx, kernel, a, b, stream); }
 };
 
 // zgemm.hip: C[M][N] (+)= alpha * A[M][K] * B[K][N], complex128 interleaved, row-major.
@@ -454,6 +463,10 @@ int fields_unmodulate(ml_ctx *ctx);
 int flush_unfold(ml_ctx *ctx);
 // in-place sum of `count` doubles over the communicator, queued on `stream` (no-op without one)
 int comm_allreduce_sum(ml_ctx *ctx, double *buf, size_t count, hipStream_t stream);
+// buf = n_ranks chunks of `chunk` doubles: afterwards chunk `rank` holds the sum over the ranks of
+// their chunk `rank` (the other chunks are scratch) / every chunk r holds rank r's chunk r
+int comm_reduce_scatter_sum(ml_ctx *ctx, double *buf, size_t chunk, hipStream_t stream);
+int comm_allgather(ml_ctx *ctx, double *buf, size_t chunk, hipStream_t stream);
 // the main stream (and the host, if `host`) waits for a reduction still running on comm_stream
 int comm_join(ml_ctx *ctx, bool host);
 

@@ -36,18 +36,18 @@ static hipEvent_t take_event(ml_ctx *ctx) {
     return e;
 }
 
-void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b) {
-    if (kernel < 0 || kernel >= ML_K_COUNT) return;   // launches that are not timed (other stream)
+void prof_begin(ml_ctx *ctx, int kernel, hipEvent_t *a, hipEvent_t *b, hipStream_t stream) {
+    if (kernel < 0 || kernel >= ML_K_COUNT) return;   // launches that are not timed
     if (!ctx->prof.on || !((ctx->prof.mask >> kernel) & 1u)) return;
     if (ctx->prof.seen[kernel]++ % ctx->prof.period != 0) return;
     *a = take_event(ctx);
     *b = take_event(ctx);
-    (void)hipEventRecord(*a, ctx->stream);
+    (void)hipEventRecord(*a, stream ? stream : ctx->stream);
 }
 
-void prof_end(ml_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b) {
+void prof_end(ml_ctx *ctx, int kernel, hipEvent_t a, hipEvent_t b, hipStream_t stream) {
     if (!ctx->prof.on || !a || !b) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, stream ? stream : ctx->stream);
     ctx->prof.pending.push_back({kernel, a, b});
 }
 
@@ -905,8 +905,8 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
         ++ctx->ovr_serial;
     }
     ML_TRY(ctx->geo_ix.reserve((size_t)blocks * 64 * 2 * sizeof(int)));   // patch-major, 64 per patch
-    ML_TRY(ctx->active_list.reserve((size_t)blocks * 2 * sizeof(int)));
-    ML_TRY(ctx->active_count.reserve(((size_t)blocks / 1024 + 4) * sizeof(int)));   // total + one per chunk of 1024 patches
+    ML_TRY(ctx->active_list.reserve((size_t)3 * blocks * 2 * sizeof(int)));           // three lists (NfArgs::active_list)
+    ML_TRY(ctx->active_count.reserve((size_t)3 * (blocks / 1024 + 4) * sizeof(int)));   // each: total + one per chunk of 1024 patches
     ML_TRY(ctx->active_flag.reserve((size_t)blocks * sizeof(int)));
     return nearfield_launch(ctx, p, n, nx, ny);
 }

@@ -227,8 +227,14 @@ struct ProjArgs {
     double *P;
     double2 *a_theta, *a_phi;            // may be null (stage 0)
     // 0: vectors -> amplitudes -> power in one go; 1: vectors -> amplitudes only (the linear
-    // part: a rank's partial sums, to be all-reduced); 2: amplitudes -> power
+    // part: a rank's partial sums, to be reduced over the ranks); 2: amplitudes -> power
     int stage;
+    // blk_rows > 0: the amplitudes in RANK-BLOCKED order (common.h FarfieldPlan::amp_rows) - element
+    // (plane p, direction row i, column j) at ((i / R) 2 R + p R + i mod R) my + j with R = blk_rows,
+    // so that block b = rows [b R, (b + 1) R) of BOTH planes is one contiguous chunk: what a
+    // reduce-scatter hands rank b.  a_theta = a_phi = the slot's base then.
+    int blk_rows;
+    int row_lo, row_hi;                  // stage 2: only the direction rows [row_lo, row_hi)
 };
 
 __device__ __forceinline__ double2 cscale(double2 a, double s) {
@@ -248,8 +254,14 @@ __device__ __forceinline__ void project_point(const ProjArgs &a, size_t at, int 
     const double uy = a.pair_list ? a.uy[i] : a.uy[j];
     double uz = 1 - ux * ux - uy * uy;
     uz = (uz < 0) ? NAN : sqrt(uz);
+    size_t ta = at, pa = at;   // where this direction's two amplitudes live
+    if (a.blk_rows) {
+        ta = ((size_t)(i / a.blk_rows) * a.blk_rows + i) * a.my + j;
+        pa = ta + (size_t)a.blk_rows * a.my;
+    }
     if (a.stage == 2) {
-        const double2 at_ = a.a_theta[at], ap_ = a.a_phi[at];
+        if (i < a.row_lo || i >= a.row_hi) return;
+        const double2 at_ = a.a_theta[ta], ap_ = a.a_phi[pa];
         const double m1 = hypot(at_.x, at_.y), m2 = hypot(ap_.x, ap_.y);
         double P = (a.coef * (m1 * m1 + m2 * m2)) / (uz + 1e-5);
         P *= 2;
@@ -280,16 +292,16 @@ __device__ __forceinline__ void project_point(const ProjArgs &a, size_t at, int 
     const double2 at_ = cadd(Lph, cscale(Nth, a.Z));            // Lphi + Z*Ntheta
     const double2 ap_ = cadd(Lth, cneg(cscale(Nph, a.Z)));      // Ltheta - Z*Nphi
     if (a.stage == 1) {
-        a.a_theta[at] = at_;
-        a.a_phi[at] = ap_;
+        a.a_theta[ta] = at_;
+        a.a_phi[pa] = ap_;
         return;
     }
     const double m1 = hypot(at_.x, at_.y), m2 = hypot(ap_.x, ap_.y);
     double P = (a.coef * (m1 * m1 + m2 * m2)) / (uz + 1e-5);
     P *= 2;
     a.P[at] = P;
-    if (a.a_theta) a.a_theta[at] = at_;
-    if (a.a_phi) a.a_phi[at] = ap_;
+    if (a.a_theta) a.a_theta[ta] = at_;
+    if (a.a_phi) a.a_phi[pa] = ap_;
 }
 
 __global__ __launch_bounds__(256) void project_kernel(const ProjArgs a) {
@@ -667,7 +679,7 @@ static int need_tw_x(ml_ctx *ctx) {
 }
 
 static int project_launch(ml_ctx *ctx, const ProjArgs &a, int kernel_id, hipStream_t stream = nullptr) {
-    // (HIP-event timing belongs to the context's own stream)
+    // (the power kernel behind a reduction on the second stream is not timed as a projection)
     ProfScope scope(ctx, stream ? ML_K_COUNT : kernel_id);
     hipLaunchKernelGGL(project_kernel, dim3((a.my + 255) / 256, a.mx), dim3(256), 0,
                        stream ? stream : ctx->stream, a);
@@ -1188,6 +1200,16 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream =
     a.a_theta = reinterpret_cast<double2 *>(pl.amp_ptr());
     a.a_phi = a.a_theta + n;
     a.stage = stage;
+    a.blk_rows = stage == 0 ? 0 : pl.amp_rows;
+    a.row_lo = 0;
+    a.row_hi = mx;
+    if (a.blk_rows) {
+        a.a_phi = a.a_theta;
+        if (stage == 2 && !pl.amp_gathered) {   // this rank holds the sum of its own block only
+            a.row_lo = ctx->rank * pl.amp_rows;
+            a.row_hi = a.row_lo + pl.amp_rows;
+        }
+    }
     if (pl.unfold_pending && stage != 2) {
         // vectors still in split-K slabs: unfold and project in one kernel, and let a spare
         // block sum the synthesis kernel's power partials if they are waiting too
@@ -1215,6 +1237,10 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream =
 
 int ml_farfield_project_async(ml_ctx *ctx, double Z0) {
     if (ctx && ctx->plan.amplitudes_reduced) return ML_OK;   // ml_farfield_project_reduce did it
+    if (ctx) {
+        ctx->plan.amp_rows = 0;
+        ctx->plan.amp_gathered = true;
+    }
     return project_stage(ctx, Z0, 0);
 }
 
@@ -1230,6 +1256,8 @@ int ml_farfield_project_reduce(ml_ctx *ctx, double Z0) {
     FarfieldPlan &pl = ctx->plan;
     const bool overlap = ctx->comm || ctx->comm_file;
     if (!overlap) {
+        pl.amp_rows = 0;
+        pl.amp_gathered = true;
         ML_TRY(project_stage(ctx, Z0, 1));
         ML_TRY(project_stage(ctx, Z0, 2));
         pl.amplitudes_reduced = true;
@@ -1245,13 +1273,32 @@ int ml_farfield_project_reduce(ml_ctx *ctx, double Z0) {
     }
     const int slot = pl.amp_slot ^ 1;
     // the reduction that last used this slot (two calls ago) has to be through with it
-    if (ctx->reduce_in_flight) ML_HIP(hipStreamWaitEvent(ctx->stream, ctx->reduce_done[slot], 0));
+    // (timed as ML_K_COMM_WAIT: what the main stream loses to a collective that has not caught up)
+    if (ctx->reduce_in_flight) {
+        ProfScope wait_scope(ctx, ML_K_COMM_WAIT);
+        ML_HIP(hipStreamWaitEvent(ctx->stream, ctx->reduce_done[slot], 0));
+    }
     pl.amp_slot = slot;
+    // REDUCE-SCATTER where the direction rows divide by the rank count: every rank ends up with the
+    // sum of ONE block of rows (both amplitudes) and takes the power of that block - (G - 1) / G of the
+    // payload per rank where the all-reduce moves 2 (G - 1) / G.  ml_farfield_gather completes the
+    // picture on every rank when somebody asks for it.
+    const int G = ctx->n_ranks;
+    const int mx = pl.mx, my = pl.pair_list ? 1 : pl.my;
+    const bool scatter = G > 1 && mx % G == 0 && !ctx->reduce_by_allreduce;
+    pl.amp_rows = scatter ? mx / G : 0;
+    pl.amp_gathered = !scatter;
     ML_TRY(project_stage(ctx, Z0, 1));
     ML_HIP(hipEventRecord(ctx->amp_ready[slot], ctx->stream));
     ML_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->amp_ready[slot], 0));
-    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
-    ML_TRY(comm_allreduce_sum(ctx, pl.amp_ptr(), 2 * n * 2, ctx->comm_stream));
+    const size_t n = (size_t)mx * my;
+    {
+        ProfScope coll_scope(ctx, ML_K_COLLECTIVE, ctx->comm_stream);
+        if (scatter)
+            ML_TRY(comm_reduce_scatter_sum(ctx, pl.amp_ptr(), 2 * n * 2 / G, ctx->comm_stream));
+        else
+            ML_TRY(comm_allreduce_sum(ctx, pl.amp_ptr(), 2 * n * 2, ctx->comm_stream));
+    }
     ML_TRY(project_stage(ctx, Z0, 2, ctx->comm_stream));
     ML_HIP(hipEventRecord(ctx->reduce_done[slot], ctx->comm_stream));
     ctx->reduce_in_flight = true;
@@ -1259,20 +1306,44 @@ int ml_farfield_project_reduce(ml_ctx *ctx, double Z0) {
     return ML_OK;
 }
 
+int ml_farfield_gather(ml_ctx *ctx) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    FarfieldPlan &pl = ctx->plan;
+    if (!pl.amp_rows || pl.amp_gathered) return ML_OK;
+    ML_HIP(hipSetDevice(ctx->device));
+    ML_TRY(comm_join(ctx, false));   // the reduce-scatter and the block's power are on the second stream
+    const int G = ctx->n_ranks, my = pl.pair_list ? 1 : pl.my;
+    const size_t n = (size_t)pl.mx * my;
+    ML_TRY(comm_allgather(ctx, pl.amp_ptr(), 2 * n * 2 / G, ctx->stream));
+    ML_TRY(comm_allgather(ctx, pl.power.as<double>(), n / G, ctx->stream));
+    pl.amp_gathered = true;
+    return ML_OK;
+}
+
 int ml_farfield_project(ml_ctx *ctx, double Z0, double *P, double *a_theta, double *a_phi) {
     ML_TRY(ml_farfield_project_async(ctx, Z0));
     ML_TRY(comm_join(ctx, false));   // a reduction on the second stream writes what is copied here
     FarfieldPlan &pl = ctx->plan;
-    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
+    if (pl.amp_rows && !pl.amp_gathered) {
+        set_error("the amplitudes are scattered over the ranks: every rank calls ml_farfield_gather first");
+        return ML_ESTATE;
+    }
+    const int my = pl.pair_list ? 1 : pl.my;
+    const size_t n = (size_t)pl.mx * my;
     if (P)
         ML_HIP(hipMemcpyAsync(P, pl.power.p, n * sizeof(double), hipMemcpyDeviceToHost,
                               ctx->stream));
-    if (a_theta)
-        ML_HIP(hipMemcpyAsync(a_theta, pl.amp_ptr(), n * 2 * sizeof(double),
-                              hipMemcpyDeviceToHost, ctx->stream));
-    if (a_phi)
-        ML_HIP(hipMemcpyAsync(a_phi, pl.amp_ptr() + 2 * n, n * 2 * sizeof(double),
-                              hipMemcpyDeviceToHost, ctx->stream));
+    // rank-blocked amplitudes (blocks of amp_rows direction rows, both planes per block) are put
+    // back in order by the copies
+    const size_t rows = pl.amp_rows ? pl.amp_rows : pl.mx, blocks = pl.mx / rows, chunk = rows * my * 2;
+    for (size_t b = 0; b < blocks; ++b) {
+        const double *src = pl.amp_ptr() + b * 2 * chunk;
+        if (a_theta)
+            ML_HIP(hipMemcpyAsync(a_theta + b * chunk, src, chunk * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (a_phi)
+            ML_HIP(hipMemcpyAsync(a_phi + b * chunk, src + (pl.amp_rows ? chunk : 2 * n), chunk * sizeof(double),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    }
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return prof_harvest(ctx);
 }
@@ -1507,6 +1578,9 @@ int ml_farfield_lattice_power(ml_ctx *ctx, int nx, int ny, const double *fftEx,
     a.P = d_P;
     a.a_theta = nullptr;
     a.a_phi = nullptr;
+    a.blk_rows = 0;
+    a.row_lo = 0;
+    a.row_hi = 0x7fffffff;
     ML_TRY(project_launch(ctx, a, ML_K_LATTICE_POWER));
     ML_HIP(hipMemcpyAsync(P, d_P, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));

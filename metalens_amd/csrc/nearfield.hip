@@ -161,8 +161,10 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.active_list = ctx->active_list.as<int2>();
     a.active_count = ctx->active_count.as<int>();
     a.active_flag = ctx->active_flag.as<int>();
+    a.list_stride = a.n_partials / 4;
+    a.count_stride = a.n_partials / 4 / 1024 + 4;
     a.use_active = 0;
-    a.n_active = 0;
+    for (int k = 0; k < 3; ++k) a.n_active[k] = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;
     a.center_present = ctx->center_present;
@@ -203,7 +205,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
         ML_TRY(nearfield_geometry_launch(ctx, a));
         memcpy(ctx->geo_key, geo_key, sizeof geo_key);
-        ctx->n_active = -1;
+        ctx->n_active[0] = -1;
         ctx->zero_key[1] = -1;   // every patch is visited (and its zeros stored) once more
     }
     // samples outside the lens are zero whatever the source: stored by the first synthesis into
@@ -214,17 +216,20 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     a.outside_is_zero = !plan_cache_disabled() && memcmp(zero_key, ctx->zero_key, sizeof zero_key) == 0;
     if (a.outside_is_zero) {
         // ... and then only the patches that hold lens samples are launched at all.  Their
-        // number comes back from the GPU once per geometry (a 4-byte copy, one synchronisation);
+        // numbers come back from the GPU once per geometry (three 4-byte copies, one synchronisation);
         // the power partials of the others stay at the zeros written here.
-        if (ctx->n_active < 0) {
-            ML_HIP(hipMemcpyAsync(&ctx->n_active, ctx->active_count.p, sizeof(int), hipMemcpyDeviceToHost,
-                                  ctx->stream));
+        if (ctx->n_active[0] < 0) {
+            const int lo = ctx->simple_orders ? 1 : 0, hi = ctx->simple_orders ? 2 : 0;
+            for (int k = 0; k < 3; ++k) ctx->n_active[k] = 0;
+            for (int k = lo; k <= hi; ++k)
+                ML_HIP(hipMemcpyAsync(&ctx->n_active[k], ctx->active_count.as<int>() + (size_t)k * a.count_stride,
+                                      sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             ML_HIP(hipMemsetAsync(ctx->partial_power.p, 0, ctx->partial_power.bytes, ctx->stream));
             ML_HIP(hipStreamSynchronize(ctx->stream));
         }
-        if (ctx->n_active > 0) {
+        if (ctx->n_active[0] + ctx->n_active[1] + ctx->n_active[2] > 0) {
             a.use_active = 1;
-            a.n_active = ctx->n_active;
+            for (int k = 0; k < 3; ++k) a.n_active[k] = ctx->n_active[k];
         }
     }
     {

@@ -85,11 +85,14 @@ struct NfArgs {
     const int *ring_ok_off;
     // per-sample geometry records (nearfield_fast.hip, kernel 1 writes, kernel 2 reads)
     int2 *geo_ix;      // [patch][64]: patch = by * patches_x + bx, 8 x 8 samples each
-    // 8 x 8 patches that hold at least one lens sample (written by kernel 1); use_active: the
-    // field kernel's grid is that list (n_active entries) instead of all patches
+    // lists of 8 x 8 patches (written behind kernel 1, nearfield_geometry_launch): list k at
+    // active_list + k list_stride with n_active[k] entries - 0: patches with a lens sample (general
+    // kernels), 1: with a ring sample, 2: with a centre sample (nearfield_simple.hip); use_active: the
+    // field kernels' grids are the lists instead of all patches
     int2 *active_list;
     int *active_count, *active_flag;
-    int use_active, n_active, patches_x;
+    int list_stride, count_stride;
+    int use_active, n_active[3], patches_x;
     // every table of the lens holds orders ox = -1, 0, 1 with oy = 0 only: the kernels that build
     // an order's phasor by one product run (nearfield_fast.hip order_phasor), else the general ones
     int simple_orders;
@@ -445,7 +448,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
 // writes the number of per-block power partials it produces to *n_partials
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
 // nearfield_simple.hip: the kernels of the round lens' order set (ox in {-1, 0, 1}, oy = 0)
-int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid);
+int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a);
 // the source-independent records of the current (grid, layout, tie answers)
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a);
 

@@ -223,22 +223,6 @@ __device__ __forceinline__ void order_apply(Acc &acc, const OrderCommon &oc, dou
     acc.Ey.i += fma(oc.cyy, vy_i, -oc.cxy * vx_i);
 }
 
-// Diagnostic build (-DML_PHASE_TIMERS, tools/nearfield_phase_timers.py): every wave of the field
-// kernel stamps s_memtime at fixed points; `dep` is a value that must have arrived by then.
-#ifdef ML_PHASE_TIMERS
-constexpr int PHASE_SLOTS = 10, PHASE_WAVES = 1 << 18;
-__device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
-#define ML_MARK(k, dep)                                   \
-    do {                                                  \
-        asm volatile("" ::"v"(dep));                      \
-        __builtin_amdgcn_sched_barrier(0);                \
-        stamp[k] = __builtin_amdgcn_s_memtime();          \
-        __builtin_amdgcn_sched_barrier(0);                \
-    } while (0)
-#else
-#define ML_MARK(k, dep)
-#endif
-
 // ---- kernel 1 of 2: the source-INDEPENDENT decisions of every sample ---------------------------
 // Ring (nearfield.py:125-128), sector and rotated local coordinates (:169,200-201), nearest
 // centre cell (:363-367) depend on the sample grid and the layout only.  They are evaluated once
@@ -303,16 +287,19 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
         const int type = (idx == 0 && aux >= 0) ? a.cwhich[aux] : (idx >= 1 && idx <= a.n_rings) ? a.ring_coll[idx - 1] : 0;
         a.geo_ix[rec] = make_int2(idx | (type << REC_TYPE_SHIFT), aux);
     }
-    // patches with at least one sample inside the lens: the field kernel visits only these once
-    // the zeros of the others are in place.  A flag per patch here, compacted into the list by
-    // active_compact_kernel (190 k waves adding to ONE counter took 2 ms)
-    const int any_lens = __any(idx <= a.n_rings);   // all lanes vote
-    if (lane == 0) a.active_flag[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = any_lens ? 1 : 0;
+    // patches with at least one sample inside the lens: the field kernels visit only these once
+    // the zeros of the others are in place.  Flags per patch here - bit 0 any lens sample, bit 1 any
+    // ring sample, bit 2 any centre sample - compacted into lists by active_compact_kernel (190 k
+    // waves adding to ONE counter took 2 ms)
+    const int any_ring = __any(idx >= 1 && idx <= a.n_rings), any_centre = __any(idx == 0);   // all lanes vote
+    if (lane == 0)
+        a.active_flag[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
+            ((any_ring | any_centre) ? 1 : 0) | (any_ring ? 2 : 0) | (any_centre ? 4 : 0);
 }
 
-// flags -> list of (bx, by), in patch order.  Two small kernels over chunks of 1024 patches:
-// lens patches per chunk, then (per chunk) the sum of the chunks before it + a scan of its own
-// flags + the writes.  count[0] = total, count[1 + c] = chunk c.
+// flags -> list of (bx, by) of the patches whose flags meet `mask`, in patch order.  Two small
+// kernels over chunks of 1024 patches: listed patches per chunk, then (per chunk) the sum of the
+// chunks before it + a scan of its own flags + the writes.  count[0] = total, count[1 + c] = chunk c.
 constexpr int COMPACT_CHUNK = 1024;
 
 __device__ __forceinline__ int chunk_scan(int mine, int *s_wave, int &total) {
@@ -333,16 +320,16 @@ __device__ __forceinline__ int chunk_scan(int mine, int *s_wave, int &total) {
     return base + before;
 }
 
-__global__ __launch_bounds__(COMPACT_CHUNK) void active_count_kernel(const int *flag, int n_patches, int *count) {
+__global__ __launch_bounds__(COMPACT_CHUNK) void active_count_kernel(const int *flag, int mask, int n_patches, int *count) {
     __shared__ int s_wave[COMPACT_CHUNK / 64];
     const int k = blockIdx.x * COMPACT_CHUNK + threadIdx.x;
     int total;
-    chunk_scan(k < n_patches ? flag[k] : 0, s_wave, total);
+    chunk_scan(k < n_patches ? (flag[k] & mask) != 0 : 0, s_wave, total);
     if (threadIdx.x == 0) count[1 + blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int *flag, int n_patches, int patches_x,
-                                                                       int2 *list, int *count) {
+__global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int *flag, int mask, int n_patches,
+                                                                       int patches_x, int2 *list, int *count) {
     __shared__ int s_wave[COMPACT_CHUNK / 64];
     __shared__ int s_before[COMPACT_CHUNK / 64];
     // lens patches in the chunks before this one (a few hundred chunks at most)
@@ -351,7 +338,7 @@ __global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int
     for (int off = 32; off; off >>= 1) part += __shfl_down(part, off);
     if ((threadIdx.x & 63) == 0) s_before[threadIdx.x >> 6] = part;
     const int k = blockIdx.x * COMPACT_CHUNK + threadIdx.x;
-    const int mine = k < n_patches ? flag[k] : 0;
+    const int mine = k < n_patches ? (flag[k] & mask) != 0 : 0;
     int total;
     const int at = chunk_scan(mine, s_wave, total);   // (its barrier also covers s_before)
     int before = 0;
@@ -399,10 +386,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
     const int j = bx * 8 + (lane & 7);                        // y index (fastest in memory)
     const bool inb = j < a.ny && i < a.nx;
     int idx = a.n_rings + 1, aux = -1;
-#ifdef ML_PHASE_TIMERS
-    unsigned long long stamp[PHASE_SLOTS] = {0};
-    stamp[0] = __builtin_amdgcn_s_memtime();
-#endif
     // the sample's coordinates do not wait for its record
     const double x_ld = a.x_pts[min(i, a.nx - 1)], y_ld = a.y_pts[min(j, a.ny - 1)];
     if (inb) {
@@ -446,7 +429,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
             power_in[m] = Ex_i * Hy_i[m] - Ey_i * Hx_i[m];
         }
     }
-    ML_MARK(1, idx + aux);
     const int cell_type = idx >> REC_TYPE_SHIFT;   // (ring samples: the collection)
     idx &= (1 << REC_TYPE_SHIFT) - 1;
     const bool lens = idx <= a.n_rings;
@@ -468,7 +450,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
         const double x = x_ld, y = y_ld;
 #pragma unroll
         for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
-        ML_MARK(2, Hx_i[0]);
 
         if (__ballot(lens && !peri)) {   // wave-uniform: some lane is a centre sample
             // ================= centre: the record holds the nearest hexagonal cell =================
@@ -503,7 +484,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
                 // phase-critical: offset from the cell centre (nearfield.py:408-409)
                 ox_ = x - ccx;
                 oy_ = y - ccy;
-                ML_MARK(3, ox_ + oy_);   // (centre waves: the cell centre has arrived)
             }
             // lane (row, column group) of the staged block [node c][amplitude q][CENTER_TYPES]:
             // row c * 4 + q = lane / 4, columns lane % 4 + 4 m - a quad of lanes reads 64 contiguous
@@ -596,7 +576,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
         int i0, i1, n0, n1, flags;
         if (peri) {
             const double cosr = cs.x, sinr = cs.y;
-            ML_MARK(3, cosr + r0.x + r1.x);   // (ring waves: the ring's record and rotation have arrived)
             // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
             xp = x * cosr + y * sinr - r0.x;
             yp = -x * sinr + y * cosr;
@@ -674,7 +653,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
     Acc pr[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
-    ML_MARK(9, E0.r + t0);   // (ring waves: set-up arithmetic done, block matching and staging next)
     unsigned long long todo = __ballot(key >= 0);
     while (todo) {   // rounds of NF_SLOTS distinct blocks; one round unless a wave spans many rings
         int myslot = -1, lead[NF_SLOTS];
@@ -731,7 +709,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
                     if (have[s]) s_tab[s * NF_PITCH + lane] = val[s];
             }
             __syncthreads();
-            ML_MARK(4, s_tab[lane].x);
             if (myslot >= 0) {
                 const int o1 = min(o0 + NF_CHUNK, n_orders);
                 // the order's grating vector one iteration ahead: its load (an L1 hit) is in
@@ -761,7 +738,6 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
             __syncthreads();   // the next pass overwrites the blocks
         }
     }
-    ML_MARK(5, pr[0].Ex.r + pr[0].Hy.i);
     if (peri) {
         // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
         const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
@@ -788,42 +764,27 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
             const c2 Ey = {fma(q.Ex.r, sinr, q.Ey.r * cosr), fma(q.Ex.i, sinr, q.Ey.i * cosr)};
             const c2 Hx = {fma(q.Hx.r, cosr, -q.Hy.r * sinr), fma(q.Hx.i, cosr, -q.Hy.i * sinr)};
             const c2 Hy = {fma(q.Hx.r, sinr, q.Hy.r * cosr), fma(q.Hx.i, sinr, q.Hy.i * cosr)};
-#ifdef ML_PHASE_TIMERS
-            if (m == 0) ML_MARK(6, Ex.r + Hy.i);
-#endif
             store_fields(a, m, i, j, Ex, Ey, Hx, Hy);
         }
     }
-#ifdef ML_PHASE_TIMERS
-    stamp[7] = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_waitcnt(0);   // the stores have left the wave
-    stamp[8] = __builtin_amdgcn_s_memtime();
-    const size_t wid = (size_t)by * a.patches_x + bx;   // patch id, whichever launch form
-    if (lane == 0 && wid < PHASE_WAVES) {
-        for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = stamp[k];
-    }
-#endif
 }
-
-#ifdef ML_PHASE_TIMERS
-extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase),
-                                    n_waves * PHASE_SLOTS * sizeof(unsigned long long), 0,
-                                    hipMemcpyDeviceToHost);
-}
-#endif
 
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     const dim3 grid((a.ny + 7) / 8, (a.nx + 7) / 8);
     hipLaunchKernelGGL(nearfield_geometry_kernel, grid, dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
+    // the lists the field kernels of this lens launch from (NfArgs::active_list): every lens patch
+    // for the general kernels; ring patches and centre patches for the two kernels of nearfield_simple.hip
     const int n_patches = (int)(grid.x * grid.y), chunks = (n_patches + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
-    hipLaunchKernelGGL(active_count_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
-                       n_patches, a.active_count);
-    ML_HIP(hipGetLastError());
-    hipLaunchKernelGGL(active_compact_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
-                       n_patches, (int)grid.x, a.active_list, a.active_count);
-    ML_HIP(hipGetLastError());
+    for (int k = a.simple_orders ? 1 : 0; k <= (a.simple_orders ? 2 : 0); ++k) {
+        int *count = a.active_count + (size_t)k * a.count_stride;
+        hipLaunchKernelGGL(active_count_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
+                           1 << k, n_patches, count);
+        ML_HIP(hipGetLastError());
+        hipLaunchKernelGGL(active_compact_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
+                           1 << k, n_patches, (int)grid.x, a.active_list + (size_t)k * a.list_stride, count);
+        ML_HIP(hipGetLastError());
+    }
     return ML_OK;
 }
 
@@ -833,8 +794,8 @@ int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials) {
     // kernel does not have (spills) and ran 25-40 % slower.
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
     *n_partials = (int)(full.x * full.y) * 4;   // four power partials per patch (wave_power)
-    const dim3 grid = a.use_active ? dim3(a.n_active) : full;
-    if (a.simple_orders) return nearfield_simple_launch(ctx, a, grid);
+    if (a.simple_orders) return nearfield_simple_launch(ctx, a);
+    const dim3 grid = a.use_active ? dim3(a.n_active[0]) : full;
     if (a.n_pol == 1)
         hipLaunchKernelGGL((nearfield_field_kernel<1>), grid, dim3(64), 0, ctx->stream, a);
     else if (a.n_pol == 2)

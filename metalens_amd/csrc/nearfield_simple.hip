@@ -27,6 +27,8 @@
 // polarisation algebra, small-argument sin / cos) is accurate to a few ulp; what feeds LARGE phases
 // - x', y', the propagation distance and k * distance - follows the reference operation by
 // operation (this file is compiled with -ffp-contract=off; every fma() here is deliberate).
+#include <algorithm>
+
 #include "nearfield_math.h"
 
 namespace ml {
@@ -36,14 +38,85 @@ constexpr int SK_PITCH = CELL_BLOCK + 1;        // +1: blocks start in different
 constexpr int SK_TYPES = 20;                    // centre: cell types per staged block (the reference's default K, lens_center.py:28)
 static_assert(SK_TYPES == CENTER_GROUP, "the centre table's cell blocks hold groups of SK_TYPES types");
 
+// The launch's scalars and table pointers a patch needs again and again.  Read from the kernel
+// arguments ONCE, at the start of the wave, and pinned in scalar registers (the empty asm statement
+// makes the values opaque, so the loads cannot sink back to their uses): left to itself the
+// compiler fetches each of them where it is used - some twenty-five scalar loads along a ring
+// wave's path, each followed by its own wait for the scalar cache.
+#define ML_GLOBAL __attribute__((address_space(1)))   // (a pointer that went through the asm statement is
+                                                       // "generic" to the compiler, and its loads flat_loads, unless told)
+struct Consts {
+    double kvac, kvac2, kg2, efh, sx, sy, dz, dz2, z2;
+    double b0, b1, b2, b3;   // the (ux', uy') range every ring table covers (NfArgs::ring_bounds_all)
+    const ML_GLOBAL double2 *ring_rec, *rot_table, *ring_tab, *premod;
+    const ML_GLOBAL int2 *geo_ix;
+    ML_GLOBAL double *fields, *partial_power;
+    int plane_wave, patches_x, n_rings, outside_is_zero, nx, ny, n_partials;
+    double hcoef, pcoef, pol[3];   // member 0 of the batch (what a single source reads)
+};
+__device__ __forceinline__ void load_consts(const NfArgs &a, Consts &K) {
+    K.kvac = a.p.kvac;
+    K.kvac2 = a.p.kvac2;
+    K.kg2 = a.p.k_glass2;
+    K.efh = a.e_from_h;
+    K.sx = a.p.source_x;
+    K.sy = a.p.source_y;
+    K.dz = a.p.dz;
+    K.dz2 = a.p.dz2;
+    K.z2 = a.p.source_z2;
+    K.ring_rec = (const ML_GLOBAL double2 *)a.ring_rec;
+    K.rot_table = (const ML_GLOBAL double2 *)a.rot_table;
+    K.ring_tab = (const ML_GLOBAL double2 *)a.ring_tab;
+    K.plane_wave = a.p.plane_wave;
+    K.b0 = a.ring_bounds_all[0];
+    K.b1 = a.ring_bounds_all[1];
+    K.b2 = a.ring_bounds_all[2];
+    K.b3 = a.ring_bounds_all[3];
+    K.premod = (const ML_GLOBAL double2 *)a.premod;
+    K.geo_ix = (const ML_GLOBAL int2 *)a.geo_ix;
+    K.fields = (ML_GLOBAL double *)a.fields;
+    K.patches_x = a.patches_x;
+    K.n_rings = a.n_rings;
+    K.outside_is_zero = a.outside_is_zero;
+    K.nx = a.nx;
+    K.ny = a.ny;
+    asm volatile("" : "+s"(K.kvac), "+s"(K.kvac2), "+s"(K.kg2), "+s"(K.efh), "+s"(K.sx), "+s"(K.sy), "+s"(K.dz), "+s"(K.dz2),
+                 "+s"(K.z2), "+s"(K.ring_rec), "+s"(K.rot_table), "+s"(K.ring_tab), "+s"(K.plane_wave));
+    K.partial_power = (ML_GLOBAL double *)a.partial_power;
+    K.n_partials = a.n_partials;
+    K.hcoef = a.hcoef[0];
+    K.pcoef = a.pcoef[0];
+    K.pol[0] = a.pol[0][0];
+    K.pol[1] = a.pol[0][1];
+    K.pol[2] = a.pol[0][2];
+    asm volatile("" : "+s"(K.b0), "+s"(K.b1), "+s"(K.b2), "+s"(K.b3), "+s"(K.premod), "+s"(K.geo_ix), "+s"(K.fields),
+                 "+s"(K.patches_x), "+s"(K.n_rings), "+s"(K.outside_is_zero), "+s"(K.nx), "+s"(K.ny));
+    asm volatile("" : "+s"(K.partial_power), "+s"(K.n_partials), "+s"(K.hcoef), "+s"(K.pcoef), "+s"(K.pol[0]), "+s"(K.pol[1]),
+                 "+s"(K.pol[2]));
+}
+
+// wave_power (nearfield_dev.h) from the pinned arguments
+__device__ __forceinline__ void wave_power_k(const NfArgs &a, const Consts &K, double power_here, int bx, int by, int member) {
+    power_here = dpp_add<0x111, 0xf>(power_here);
+    power_here = dpp_add<0x112, 0xf>(power_here);
+    power_here = dpp_add<0x114, 0xf>(power_here);
+    power_here = dpp_add<0x118, 0xf>(power_here);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 15)
+        K.partial_power[(size_t)member * K.n_partials + ((size_t)by * K.patches_x + bx) * 4 + (lane >> 4)] = power_here;
+    // (workgroup 0 exists in the full and in the listed grid alike; wave 0 of it clears the keys the NEXT launch reports into)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && member == 0)
+        for (int k = threadIdx.x; k < a.n_viol_keys; k += 64) a.viol_next[k] = 0ull;
+}
+
 struct AccS {
     double Exr, Exi, Eyr, Eyi, Hxr, Hxi, Hyr, Hyi;
 };
 
-// what the three orders of a sample share: k u_x', 2 pi / period, k u_y', (k u_y')^2, (k u_y')^2 - k_glass^2,
-// the order-(0,0) phasor (x the propagation phasor) and exp(i G x')
+// what the three orders of a sample share: k u_x', 2 pi / period, k u_y', (k u_y')^2, the order-(0,0)
+// phasor (x the propagation phasor) and exp(i G x')
 struct OrderShared {
-    double kx0, G, ky, ky2, cY;
+    double kx0, G, ky, ky2;
     c2 E0, X;
 };
 
@@ -56,20 +129,19 @@ struct OrderFactors {
 };
 
 template <int OX>
-__device__ __forceinline__ bool order_setup(const OrderShared &S, const ml_nearfield_params &p, double e_from_h,
-                                            double &kx, double &kt2) {
+__device__ __forceinline__ bool order_setup(const OrderShared &S, const Consts &K, double &kx, double &kt2) {
     kx = OX == 0 ? S.kx0 : OX > 0 ? S.kx0 + S.G : S.kx0 - S.G;
     kt2 = kx * kx + S.ky2;
-    return kt2 <= p.kvac2;   // propagating in air (nearfield.py:279-280, 398)
+    return kt2 <= K.kvac2;   // propagating in air (nearfield.py:279-280, 398)
 }
 
 template <int OX>
-__device__ __forceinline__ void order_factors_s(OrderFactors &f, const OrderShared &S, const ml_nearfield_params &p,
-                                                double e_from_h, double kx, double kt2) {
-    const double g = e_from_h * rsqrt_fast(p.k_glass2 - kt2);   // Z0 / (n k_glass kz)
+__device__ __forceinline__ void order_factors_s(OrderFactors &f, const OrderShared &S, const Consts &K, double kx,
+                                                double kt2) {
+    const double g = K.efh * rsqrt_fast(K.kg2 - kt2);   // Z0 / (n k_glass kz)
     f.cxy = (kx * S.ky) * g;
-    f.cxx = (p.k_glass2 - kx * kx) * g;
-    f.cyy = S.cY * g;
+    f.cxx = (K.kg2 - kx * kx) * g;
+    f.cyy = (S.ky2 - K.kg2) * g;
     f.ph = OX == 0 ? S.E0 : OX > 0 ? cmulf(S.E0, S.X) : cmulf_conj(S.E0, S.X);
 }
 
@@ -98,11 +170,11 @@ __device__ __forceinline__ void order_accumulate(AccS &acc, const OrderFactors &
 template <int OX, int NP, int STRIDE>
 __device__ __forceinline__ void order_simple(AccS *acc, const double2 *blk, const double *wa, const double *wb,
                                              const double *Hwx, const double *Hwy, const OrderShared &S,
-                                             const ml_nearfield_params &p, double e_from_h) {
+                                             const Consts &K) {
     double kx, kt2;
-    if (!order_setup<OX>(S, p, e_from_h, kx, kt2)) return;
+    if (!order_setup<OX>(S, K, kx, kt2)) return;
     OrderFactors f;
-    order_factors_s<OX>(f, S, p, e_from_h, kx, kt2);
+    order_factors_s<OX>(f, S, K, kx, kt2);
     if (NP == 1) {
         double ufy_r, ufy_i, ufx_r, ufx_i;
 #pragma unroll
@@ -171,27 +243,38 @@ __device__ __forceinline__ void locate_axis(const double *axis, int n, double x,
 // the bound reports of a sample outside its table, per order in the reference's check order
 // (nearfield.py:294-305, 412-419): rare path, entered by the whole wave only if some lane needs it
 template <bool RING>
-__device__ __forceinline__ void report_orders(const NfArgs &a, double kx0, double G, double ky, int present,
+__device__ __forceinline__ void report_orders(const NfArgs &a, double kvac2, double kx0, double G, double ky, int present,
                                               int order_of, int slot, double u, double v, double period) {
-    const ml_nearfield_params &p = a.p;
     const TableDesc &T = RING ? a.tables[slot] : a.center_desc;
     const double ky2 = ky * ky;
 #pragma unroll
     for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
         const double kx = oc == 0 ? kx0 : oc == 2 ? kx0 + G : kx0 - G;
-        if (((present >> oc) & 1) && kx * kx + ky2 <= p.kvac2)
+        if (((present >> oc) & 1) && kx * kx + ky2 <= kvac2)
             check_bounds(a, T, slot, (order_of >> (4 * oc)) & 15, u, v, period, RING);
     }
 }
 
+// store_fields (nearfield_dev.h) from the pinned arguments
+__device__ __forceinline__ void store_fields_k(const Consts &K, int member, int i, int j, c2 Ex, c2 Ey, c2 Hx, c2 Hy) {
+    const size_t plane = (size_t)K.nx * K.ny;
+    const size_t at = (size_t)i * K.ny + j;
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    double2v *F = reinterpret_cast<double2v *>(K.fields) + (size_t)member * 4 * plane;
+    __builtin_nontemporal_store((double2v){Ex.r, Ex.i}, F + at);
+    __builtin_nontemporal_store((double2v){Ey.r, Ey.i}, F + plane + at);
+    __builtin_nontemporal_store((double2v){Hx.r, Hx.i}, F + 2 * plane + at);
+    __builtin_nontemporal_store((double2v){Hy.r, Hy.i}, F + 3 * plane + at);
+}
+
 // incidence direction at a sample (nearfield.py:172-184): unit vector from the source, 1 / distance
-__device__ __forceinline__ void incidence(const ml_nearfield_params &p, double x, double y, double &ux, double &uy,
-                                          double &uz, double &inv) {
-    const double dx = x - p.source_x, dy = y - p.source_y;
-    inv = rsqrt_fast(fma(dx, dx, fma(dy, dy, p.dz2)));
+__device__ __forceinline__ void incidence(const Consts &K, double x, double y, double &ux, double &uy, double &uz,
+                                          double &inv) {
+    const double dx = x - K.sx, dy = y - K.sy;
+    inv = rsqrt_fast(fma(dx, dx, fma(dy, dy, K.dz2)));
     ux = dx * inv;
     uy = dy * inv;
-    uz = p.dz * inv;
+    uz = K.dz * inv;
 }
 
 // direction cosines in the grating's frame (rotation cs = (cos, sin), nearfield.py:195-196)
@@ -210,6 +293,8 @@ __device__ __forceinline__ void rotate_dir(double ux, double uy, double2 cs, dou
 __device__ __forceinline__ unsigned lds_address(const double2 *p) {
     return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char *)(const char *)p;
 }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (M0 is a reserved register: the clobber is a statement of fact)
 template <int N16>
 __device__ __forceinline__ void stage_block(const double2 *src, const double2 *lds, unsigned lane_off) {
     const char *base = reinterpret_cast<const char *>(src);   // wave-uniform
@@ -221,6 +306,7 @@ __device__ __forceinline__ void stage_block(const double2 *src, const double2 *l
                      : "v"(lane_off), "s"(base + m * 1024), "s"(dst + m * 1024)
                      : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 // the wave's global -> LDS loads have landed except the newest LEFT of them (a workgroup is one
 // wave: nobody else to wait for); the compiler may not move LDS reads in front of this
@@ -230,36 +316,65 @@ __device__ __forceinline__ void staged_wait() {
 }
 
 constexpr int CB = CENTER_BLOCK;   // complex per staged centre block
+constexpr int RING_LDS = SK_SLOTS * SK_PITCH;   // complex: the ring blocks of a round
 
-template <int NP>
-__global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a) {
-    // two buffers: the centre stages order o + 1 while order o is evaluated; ring blocks use the first
-    __shared__ double2 s_tab[CB], s_tab1[CB];
-    static_assert(SK_SLOTS * SK_PITCH <= CB, "the ring blocks of a round fit one buffer");
+typedef int int2v __attribute__((ext_vector_type(2)));
+
+// Diagnostic build (-DML_PHASE_TIMERS, tools/nearfield_phase_timers.py): every wave stamps s_memtime
+// at fixed points; `dep` is a value that must have arrived by then.
+#ifdef ML_PHASE_TIMERS
+constexpr int PHASE_SLOTS = 10, PHASE_WAVES = 1 << 18;
+__device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
+#define ML_MARK(k, dep)                                   \
+    do {                                                  \
+        asm volatile("" ::"v"(dep));                      \
+        __builtin_amdgcn_sched_barrier(0);                \
+        stamp[k] = __builtin_amdgcn_s_memtime();          \
+        __builtin_amdgcn_sched_barrier(0);                \
+    } while (0)
+#else
+#define ML_MARK(k, dep)
+#endif
+
+// Two kernels share the samples of a lens: nearfield_ring_kernel takes the RING samples of the
+// patches that hold any (96 registers and 4.7 KB of LDS: five waves per SIMD), nearfield_centre_kernel
+// the CENTRE samples of the patches that hold any (two 5 KB block buffers, 112 registers: four).  A
+// patch that straddles the switch radius is visited by both, each storing its own samples.  The
+// incident power of a patch and - on the first synthesis into a buffer - the zeros outside the lens
+// are the ring kernel's where the patch has ring samples (and on its full-grid launch), the centre
+// kernel's otherwise.
+enum { PART_RING = 1, PART_CENTRE = 2 };
+
+template <int NP, int PART>
+__device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab, double2 *s_tab1, int bx, int by) {
     const int lane = threadIdx.x;
     const unsigned lane_off = (unsigned)lane * 16u;
     const ml_nearfield_params &p = a.p;
-    // patch of this wave: the whole grid, or (once the zeros outside the lens are in place) the
-    // list of patches that hold lens samples
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (a.use_active) {
-        const int2 pb = a.active_list[blockIdx.x];
-        bx = pb.x;
-        by = pb.y;
-    }
+    Consts K;
+    load_consts(a, K);
     const int i = by * 8 + (lane >> 3);   // x index
     const int j = bx * 8 + (lane & 7);    // y index (fastest in memory)
-    const bool inb = j < a.ny && i < a.nx;
+    const bool inb = j < K.ny && i < K.nx;
     // the sample's coordinates do not wait for its record
-    const double x = a.x_pts[min(i, a.nx - 1)], y = a.y_pts[min(j, a.ny - 1)];
-    typedef int int2v __attribute__((ext_vector_type(2)));
-    const int2v *recs = reinterpret_cast<const int2v *>(a.geo_ix + ((size_t)by * a.patches_x + bx) * 64);   // patch-major
-    int idx = a.n_rings + 1, aux = -1;
-    if (inb) {
-        const int2v ix = recs[lane];
-        idx = ix.x;   // cell type / collection above bit 20, split off below
-        aux = ix.y;
-    }
+    const double x = a.x_pts[min(i, K.nx - 1)], y = a.y_pts[min(j, K.ny - 1)];
+    // (every patch has 64 records, whether or not all its samples exist: the load needs no branch - a
+    // branch would make the wave wait for the record right here, in front of the arithmetic below)
+    const int2v ix = reinterpret_cast<const int2v *>(K.geo_ix + ((size_t)by * K.patches_x + bx) * 64)[lane];   // patch-major
+#ifdef ML_PHASE_TIMERS
+    unsigned long long stamp[PHASE_SLOTS] = {0};
+    stamp[0] = __builtin_amdgcn_s_memtime();
+    struct StampOut {   // written on every way out of the patch
+        unsigned long long *st;
+        size_t wid;
+        __device__ ~StampOut() {
+            st[7] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0);   // the stores have left the wave
+            st[8] = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0 && wid < PHASE_WAVES && PART == PART_RING)
+                for (int k = 0; k < PHASE_SLOTS; ++k) g_phase[wid * PHASE_SLOTS + k] = st[k];
+        }
+    } stamp_out{stamp, (size_t)by * K.patches_x + bx};
+#endif
     // ---- incidence direction (shared) and incident field per polarisation (nearfield.py:172-228;
     // amplitude-type arithmetic).  They need the sample's coordinates and the source only, so they
     // are worked out for every lane while the record is on its way and masked by it afterwards.
@@ -267,7 +382,7 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
     // Z0 u_z |H|^2 = (Z0 H_coef^2) (u_z / d)^2 |u x p|^2  (amp = H_coef sqrt(u_z) / d, the Lambert factor).
     double ux = 0.0, uy = 0.0, uz = 1.0;
     double Hx_i[NP], Hy_i[NP], power_in[NP];
-    if (p.plane_wave) {
+    if (K.plane_wave) {
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             Hx_i[m] = a.pw_Hx[m];
@@ -276,167 +391,177 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
         }
     } else {
         double inv;
-        incidence(p, x, y, ux, uy, uz, inv);
+        incidence(K, x, y, ux, uy, uz, inv);
         const double t = uz * inv, rs = rsqrt_fast(uz);   // uz > 0
         const double t2 = t * t;
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
-            const double *pol = a.pol[m];
-            const double amp = (a.hcoef[m] * rs) * t;   // H_coef sqrt(uz) / d
+            const double *pol = NP == 1 ? K.pol : a.pol[m];
+            const double amp = ((NP == 1 ? K.hcoef : a.hcoef[m]) * rs) * t;   // H_coef sqrt(uz) / d
             const double hx = fma(uy, pol[2], -(uz * pol[1]));
             const double hy = fma(uz, pol[0], -(ux * pol[2]));
             const double hz = fma(ux, pol[1], -(uy * pol[0]));
             Hx_i[m] = hx * amp;
             Hy_i[m] = hy * amp;
-            power_in[m] = (a.pcoef[m] * t2) * fma(hx, hx, fma(hy, hy, hz * hz));
+            power_in[m] = ((NP == 1 ? K.pcoef : a.pcoef[m]) * t2) * fma(hx, hx, fma(hy, hy, hz * hz));
         }
     }
+    int idx = inb ? ix.x : K.n_rings + 1;   // cell type / collection above bit 20, split off below
+    const int aux = inb ? ix.y : -1;
+    ML_MARK(1, idx + aux);   // the record has arrived
     const int cell_type = idx >> REC_TYPE_SHIFT;   // (ring samples: the collection)
     idx &= (1 << REC_TYPE_SHIFT) - 1;
-    const bool lens = idx <= a.n_rings;
+    const bool lens = idx <= K.n_rings;
     const bool peri = lens && idx >= 1;
+    // who sums the patch's incident power and stores its zeros: see above
+    const bool mine_too = PART == PART_RING || !__ballot(peri);   // wave-uniform
+    if (mine_too) {
 #pragma unroll
-    for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
+        for (int m = 0; m < NP; ++m) wave_power_k(a, K, lens ? power_in[m] : 0.0, bx, by, m);
+        if (inb && !lens && !K.outside_is_zero) {
+            const c2 zero = {0.0, 0.0};
+#pragma unroll
+            for (int m = 0; m < NP; ++m) store_fields_k(K, m, i, j, zero, zero, zero, zero);
+        }
+    }
+    ML_MARK(2, Hx_i[0]);   // incident field and power done
 
-    if (__ballot(lens && !peri)) {   // wave-uniform: some lane is a centre sample
-        // ================= centre: the record holds the nearest hexagonal cell =================
-        // The lanes of a patch sit in ~50 cells of up to K types, and (the direction of incidence
-        // hardly changes over 2 um) almost always in ONE (ux, uy) cell of the centre table.  Per
-        // order the wave stages that cell's block - four nodes x four amplitudes x a group of
-        // SK_TYPES types, contiguous in the centre table's cell-block form (common.h) - through LDS
-        // and every lane picks its type's sixteen values from there; order o + 1's block is on its
-        // way into the other buffer while order o is evaluated.  A round serves the lanes of one
-        // (table cell, group of types); a wave that straddles a table cell, or a table of more
-        // types, takes more rounds.
-        const bool cen = lens && !peri && aux >= 0;
-        AccS acc[NP];
+    if (PART == PART_CENTRE) {
+        if (!__ballot(lens && !peri)) return;   // (wave-uniform; only on the full-grid launch)
+    // ================= centre: the record holds the nearest hexagonal cell =================
+    // The lanes of a patch sit in ~50 cells of up to K types, and (the direction of incidence
+    // hardly changes over 2 um) almost always in ONE (ux, uy) cell of the centre table.  Per
+    // order the wave stages that cell's block - four nodes x four amplitudes x a group of
+    // SK_TYPES types, contiguous in the centre table's cell-block form (common.h) - through LDS
+    // and every lane picks its type's sixteen values from there; order o + 1's block is on its
+    // way into the other buffer while order o is evaluated.  A round serves the lanes of one
+    // (table cell, group of types); a wave that straddles a table cell, or a table of more
+    // types, takes more rounds.
+    const bool cen = lens && !peri && aux >= 0;
+    AccS acc[NP];
 #pragma unroll
-        for (int m = 0; m < NP; ++m) acc[m] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const TableDesc &T = a.center_desc;
-        int i0, i1;
-        double t0, t1;
-        if (T.uniform) {   // (every lane: ux, uy are defined for all of them)
-            locate_uniform(T.uni_ax, (double)(T.n0 - 2), (double)(T.n1 - 2), ux, uy, i0, t0, i1, t1);
-        } else {
-            locate_axis(T.axis0, T.n0, ux, i0, t0);
-            locate_axis(T.axis1, T.n1, uy, i1, t1);
+    for (int m = 0; m < NP; ++m) acc[m] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const TableDesc &T = a.center_desc;
+    int i0, i1;
+    double t0, t1;
+    if (T.uniform) {   // (every lane: ux, uy are defined for all of them)
+        locate_uniform(T.uni_ax, (double)(T.n0 - 2), (double)(T.n1 - 2), ux, uy, i0, t0, i1, t1);
+    } else {
+        locate_axis(T.axis0, T.n0, ux, i0, t0);
+        locate_axis(T.axis1, T.n1, uy, i1, t1);
+    }
+    const bool out_c = (int)(ux < T.bounds[0]) | (int)(ux > T.bounds[1]) | (int)(uy < T.bounds[2]) |
+                       (int)(uy > T.bounds[3]);
+    const int n2 = T.n2, groups = (n2 + SK_TYPES - 1) / SK_TYPES;
+    const int which = min(cell_type, n2 - 1);
+    const int grp = which / SK_TYPES;
+    const int cblk = (i0 * (T.n1 - 1) + i1) * groups + grp;   // the sample's block of order 0
+    const size_t order_blocks = (size_t)(T.n0 - 1) * (T.n1 - 1) * groups;
+    OrderShared S;   // (centre samples only; no defaults: each costs a move and a select)
+    double wa[4], wb[4];
+    if (cen) {
+        // the record holds the cell's slot in the bin-sorted arrays
+        const double2 cc = a.cxy[aux];
+        // phase-critical: offset from the cell centre (nearfield.py:408-409)
+        const double ox_ = x - cc.x, oy_ = y - cc.y;
+        // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
+        // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
+        // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
+        // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
+        S.kx0 = K.kvac * ux;
+        S.ky = K.kvac * uy;
+        double a0 = S.kx0 * ox_ + S.ky * oy_;
+        int kq = 0;
+        if (!K.plane_wave) {
+            const double gx = cc.x - K.sx, gy = cc.y - K.sy;
+            const double air = sqrt_exact(gx * gx + gy * gy + K.z2);
+            double r;
+            reduce_pio2(K.kvac * air, r, kq);
+            a0 = r + a0;
         }
-        const bool out_c = (int)(ux < T.bounds[0]) | (int)(ux > T.bounds[1]) | (int)(uy < T.bounds[2]) |
-                           (int)(uy > T.bounds[3]);
-        const int n2 = T.n2, groups = (n2 + SK_TYPES - 1) / SK_TYPES;
-        const int which = min(cell_type, n2 - 1);
-        const int grp = which / SK_TYPES;
-        const int cblk = (i0 * (T.n1 - 1) + i1) * groups + grp;   // the sample's block of order 0
-        const size_t order_blocks = (size_t)(T.n0 - 1) * (T.n1 - 1) * groups;
-        OrderShared S;   // (centre samples only; no defaults: each costs a move and a select)
-        double wa[4], wb[4];
-        if (cen) {
-            // the record holds the cell's slot in the bin-sorted arrays
-            const double2 cc = a.cxy[aux];
-            // phase-critical: offset from the cell centre (nearfield.py:408-409)
-            const double ox_ = x - cc.x, oy_ = y - cc.y;
-            // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
-            // :391-409 with ox = oy = 0) times the propagation phasor from the cell centre
-            // (:453-461, exact argument), through ONE sincos: the large angle k |r| is reduced
-            // to [-pi/4, pi/4] + quadrants first, the small one added to the remainder
-            S.kx0 = p.kvac * ux;
-            S.ky = p.kvac * uy;
-            double a0 = S.kx0 * ox_ + S.ky * oy_;
-            int kq = 0;
-            if (!p.plane_wave) {
-                const double gx = cc.x - p.source_x, gy = cc.y - p.source_y;
-                const double air = sqrt_exact(gx * gx + gy * gy + p.source_z2);
-                double r;
-                reduce_pio2(p.kvac * air, r, kq);
-                a0 = r + a0;
-            }
-            sincos_cw_q(a0, kq, S.E0.i, S.E0.r);
-            S.G = T.center_g[0];
-            sincos_cw(S.G * ox_, S.X.i, S.X.r);
-            S.ky2 = S.ky * S.ky;
-            S.cY = S.ky2 - p.k_glass2;
-            const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
+        sincos_cw_q(a0, kq, S.E0.i, S.E0.r);
+        S.G = T.center_g[0];
+        sincos_cw(S.G * ox_, S.X.i, S.X.r);
+        S.ky2 = S.ky * S.ky;
+        const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
-                wa[c] = NP == 1 ? w[c] * Hy_i[0] : w[c];
-                wb[c] = NP == 1 ? w[c] * Hx_i[0] : 0.0;
-            }
+        for (int c = 0; c < 4; ++c) {
+            // un-rotated weights: x table <-> H along y (nearfield.py:375-376)
+            wa[c] = NP == 1 ? w[c] * Hy_i[0] : w[c];
+            wb[c] = NP == 1 ? w[c] * Hx_i[0] : 0.0;
         }
-        const int mine_off = which - grp * SK_TYPES;
-        unsigned long long todo = __ballot(cen);
-        while (todo) {
-            const int kl = __builtin_amdgcn_readlane(cblk, __ffsll((long long)todo) - 1);
-            const bool mine = cen && cblk == kl;
-            todo &= ~__ballot(mine);
-            const double2 *src = a.center_tab + (size_t)(unsigned)kl * CB;
-            stage_block<CB / 64>(src, s_tab, lane_off);
+    }
+    const int mine_off = which - grp * SK_TYPES;
+    unsigned long long todo = __ballot(cen);
+    while (todo) {
+        const int kl = __builtin_amdgcn_readlane(cblk, __ffsll((long long)todo) - 1);
+        const bool mine = cen && cblk == kl;
+        todo &= ~__ballot(mine);
+        const double2 *src = a.center_tab + (size_t)(unsigned)kl * CB;
+        stage_block<CB / 64>(src, s_tab, lane_off);
 #pragma unroll
-            for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
-                if (oc + 1 < SIMPLE_ORDERS) {
-                    stage_block<CB / 64>(src + (oc + 1) * order_blocks * CB, ((oc + 1) & 1) ? s_tab1 : s_tab, lane_off);
-                    staged_wait<CB / 64>();
-                } else {
-                    staged_wait<0>();
-                }
-                if (mine) {
-                    OrderShared R = S;
-                    asm volatile("" : "+v"(R.kx0));   // (see the ring samples' order loop)
-                    const double2 *blk = ((oc & 1) ? s_tab1 : s_tab) + mine_off;
-                    if (oc == 0) order_simple<0, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, p, a.e_from_h);
-                    if (oc == 1) order_simple<-1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, p, a.e_from_h);
-                    if (oc == 2) order_simple<1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, p, a.e_from_h);
-                }
-                // (every LDS read of this order has come back - its values were used - before the
-                // load that overwrites its buffer is issued, one iteration on)
-                __builtin_amdgcn_sched_barrier(0);
+        for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
+            if (oc + 1 < SIMPLE_ORDERS) {
+                stage_block<CB / 64>(src + (oc + 1) * order_blocks * CB, ((oc + 1) & 1) ? s_tab1 : s_tab, lane_off);
+                staged_wait<CB / 64>();
+            } else {
+                staged_wait<0>();
             }
+            if (mine) {
+                OrderShared R = S;
+                asm volatile("" : "+v"(R.kx0));   // (see the ring samples' order loop)
+                const double2 *blk = ((oc & 1) ? s_tab1 : s_tab) + mine_off;
+                if (oc == 0) order_simple<0, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, K);
+                if (oc == 1) order_simple<-1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, K);
+                if (oc == 2) order_simple<1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, K);
+            }
+            // (every LDS read of this order has come back - its values were used - before the
+            // load that overwrites its buffer is issued, one iteration on)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (__ballot(cen && out_c)) {
-            if (cen && out_c)
-                report_orders<false>(a, p.kvac * ux, T.center_g[0], p.kvac * uy, a.center_present, a.center_order_of,
-                                     MAX_SLOTS, ux, uy, 0.0);
-        }
-        if (cen && a.premod) {
-            // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
-            const double2 t2 = a.premod[j];
-            const c2 e = {t2.x, t2.y};
+    }
+    if (__ballot(cen && out_c)) {
+        if (cen && out_c)
+            report_orders<false>(a, K.kvac2, K.kvac * ux, T.center_g[0], K.kvac * uy, a.center_present, a.center_order_of,
+                                 MAX_SLOTS, ux, uy, 0.0);
+    }
+    if (cen && K.premod) {
+        // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
+        const double2 t2 = K.premod[j];
+        const c2 e = {t2.x, t2.y};
 #pragma unroll
-            for (int m = 0; m < NP; ++m) {
-                AccS &q = acc[m];
-                const c2 Ex = cmulf({q.Exr, q.Exi}, e), Ey = cmulf({q.Eyr, q.Eyi}, e);
-                const c2 Hx = cmulf({q.Hxr, q.Hxi}, e), Hy = cmulf({q.Hyr, q.Hyi}, e);
-                q = {Ex.r, Ex.i, Ey.r, Ey.i, Hx.r, Hx.i, Hy.r, Hy.i};
-            }
+        for (int m = 0; m < NP; ++m) {
+            AccS &q = acc[m];
+            const c2 Ex = cmulf({q.Exr, q.Exi}, e), Ey = cmulf({q.Eyr, q.Eyi}, e);
+            const c2 Hx = cmulf({q.Hxr, q.Hxi}, e), Hy = cmulf({q.Hyr, q.Hyi}, e);
+            q = {Ex.r, Ex.i, Ey.r, Ey.i, Hx.r, Hx.i, Hy.r, Hy.i};
         }
+    }
+
         if (lens && !peri) {
 #pragma unroll
             for (int m = 0; m < NP; ++m)
-                store_fields(a, m, i, j, {acc[m].Exr, acc[m].Exi}, {acc[m].Eyr, acc[m].Eyi},
+                store_fields_k(K, m, i, j, {acc[m].Exr, acc[m].Exi}, {acc[m].Eyr, acc[m].Eyi},
                              {acc[m].Hxr, acc[m].Hxi}, {acc[m].Hyr, acc[m].Hyi});
         }
+        return;
     }
-    if (inb && !lens && !a.outside_is_zero) {
-        const c2 zero = {0.0, 0.0};
-#pragma unroll
-        for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
-    }
-    if (!__ballot(peri)) return;
+    if (!__ballot(peri)) return;   // (wave-uniform; only on the full-grid launch)
 
     // ================= periphery =================
     // the ring's record (common.h ring_rec) and rotation, requested as soon as the geometry record is
-    // there (behind the centre section, which a wave without centre samples skips: while it runs
-    // the registers are the centre's).  State of ring samples only, deliberately without defaults.
+    // there.  State of ring samples only, deliberately without defaults.
     double2 r0, r1, cs;
     if (peri) {
-        const double2 *rr = a.ring_rec + (size_t)(idx - 1) * 2;
+        const double2 *rr = K.ring_rec + (size_t)(idx - 1) * 2;
         r0 = rr[0];
         r1 = rr[1];
-        cs = a.rot_table[aux];
+        cs = K.rot_table[aux];
     }
     double uxp, uyp, t0, t1, xp, yp;
     int cell = 0;
     if (peri) {
+        ML_MARK(3, cs.x + r0.x + r1.x);   // (ring waves: the ring's record and rotation have arrived)
         // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
         xp = x * cs.x + y * cs.y - r0.x;
         yp = -x * cs.y + y * cs.x;
@@ -494,10 +619,12 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
 #pragma unroll
             for (int s = 0; s < SK_SLOTS; ++s)
                 if (lead[s] >= 0)
-                    stage_block<1>(a.ring_tab + (size_t)(unsigned)lead[s] * CELL_BLOCK, s_tab + s * SK_PITCH, lane_off);
+                    stage_block<1>(K.ring_tab + (size_t)(unsigned)lead[s] * CELL_BLOCK, s_tab + s * SK_PITCH, lane_off);
         }
     };
+    ML_MARK(9, blk);     // (ring waves: table cell located, block matching next)
     match_and_stage();   // the first round's blocks are on their way during the arithmetic below
+    ML_MARK(6, myslot);  // (ring waves: blocks matched, loads issued)
     bool outside = false;
     OrderShared S;
     double wa[4], wb[4], Hw_x[NP], Hw_y[NP];
@@ -507,8 +634,8 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
         // reporting path (per order, in the reference's check order).  A sample inside the range
         // EVERY ring table covers, on a ring whose period its table covers (bit 32 of the ring record),
         // cannot fail; only the others read their table's bounds.
-        outside = (int)(uxp < a.ring_bounds_all[0]) | (int)(uxp > a.ring_bounds_all[1]) |
-                  (int)(uyp < a.ring_bounds_all[2]) | (int)(uyp > a.ring_bounds_all[3]) | (int)((bits >> 32) & 1);
+        outside = (int)(uxp < K.b0) | (int)(uxp > K.b1) |
+                  (int)(uyp < K.b2) | (int)(uyp > K.b3) | (int)((bits >> 32) & 1);
         if (outside) {
             const double *b = a.tables[a.gc[idx - 1]].bounds;
             const double period = r0.y;
@@ -520,23 +647,22 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
         // from the grating centre (:337-341, exact argument), through ONE sincos: the large angle
         // k |r| is reduced to [-pi/4, pi/4] + quadrants first and the small one added to the
         // remainder.  X = exp(i G x').
-        S.kx0 = p.kvac * uxp;
-        S.ky = p.kvac * uyp;
+        S.kx0 = K.kvac * uxp;
+        S.ky = K.kvac * uyp;
         double a0 = S.kx0 * xp + S.ky * yp;
         int kq = 0;
-        if (!p.plane_wave) {
+        if (!K.plane_wave) {
             const double rcen = r0.x;
-            const double gx = rcen * cs.x - p.source_x, gy = rcen * cs.y - p.source_y;
-            const double air = sqrt_exact(gx * gx + gy * gy + p.source_z2);
+            const double gx = rcen * cs.x - K.sx, gy = rcen * cs.y - K.sy;
+            const double air = sqrt_exact(gx * gx + gy * gy + K.z2);
             double r;
-            reduce_pio2(p.kvac * air, r, kq);
+            reduce_pio2(K.kvac * air, r, kq);
             a0 = r + a0;
         }
         sincos_cw_q(a0, kq, S.E0.i, S.E0.r);
         S.G = r1.x;   // 2 pi / period
         sincos_cw(S.G * xp, S.X.i, S.X.r);
         S.ky2 = S.ky * S.ky;
-        S.cY = S.ky2 - p.k_glass2;
         // interpolation weights; one source: times the two polarisation weights
         const double w[4] = {(1 - t0) * (1 - t1), (1 - t0) * t1, t0 * (1 - t1), t0 * t1};
 #pragma unroll
@@ -553,6 +679,7 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
     AccS pr[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ML_MARK(4, wa[0] + pr[0].Exr);   // (ring waves: phasors and weights done)
     while (true) {
         staged_wait<0>();
         if (myslot >= 0) {
@@ -563,45 +690,46 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
             asm volatile("" : "+v"(R.kx0));
             // (the three orders one after the other: scheduled together, all 48 LDS reads are put in
             // flight at once and what they displace is spilled)
-            order_simple<0, NP, 1>(pr, b, wa, wb, Hw_x, Hw_y, R, p, a.e_from_h);
+            order_simple<0, NP, 1>(pr, b, wa, wb, Hw_x, Hw_y, R, K);
             __builtin_amdgcn_sched_barrier(0);
-            order_simple<-1, NP, 1>(pr, b + 16, wa, wb, Hw_x, Hw_y, R, p, a.e_from_h);
+            order_simple<-1, NP, 1>(pr, b + 16, wa, wb, Hw_x, Hw_y, R, K);
             __builtin_amdgcn_sched_barrier(0);
-            order_simple<1, NP, 1>(pr, b + 32, wa, wb, Hw_x, Hw_y, R, p, a.e_from_h);
+            order_simple<1, NP, 1>(pr, b + 32, wa, wb, Hw_x, Hw_y, R, K);
         }
         if (!todo) break;   // wave-uniform
         __builtin_amdgcn_sched_barrier(0);   // (this round's LDS reads are done before the next round's loads go out)
         match_and_stage();
     }
+    ML_MARK(5, pr[0].Exr + pr[0].Hyi);   // orders done
     if (__ballot(outside)) {
         if (outside) {
             // rare path: everything it reports is worked out again (nothing kept live for it)
-            const int2v ix = recs[lane];
+            const int2v ix = reinterpret_cast<const int2v *>(K.geo_ix + ((size_t)by * K.patches_x + bx) * 64)[lane];
             const int ring = (ix.x & ((1 << REC_TYPE_SHIFT) - 1)) - 1;
             const CollDesc *C = a.coll + (ix.x >> REC_TYPE_SHIFT);   // (per-lane index: ordinary loads from the kernel arguments)
             double vx = 0.0, vy = 0.0, vz, vinv, vxp, vyp;
-            if (!p.plane_wave) incidence(p, x, y, vx, vy, vz, vinv);
-            rotate_dir(vx, vy, a.rot_table[ix.y], vxp, vyp);
-            const double2 *rr = a.ring_rec + (size_t)ring * 2;
-            report_orders<true>(a, p.kvac * vxp, rr[1].x, p.kvac * vyp, C->present, C->order_of, a.gc[ring], vxp, vyp,
+            if (!K.plane_wave) incidence(K, a.x_pts[i], a.y_pts[j], vx, vy, vz, vinv);
+            rotate_dir(vx, vy, K.rot_table[ix.y], vxp, vyp);
+            const double2 *rr = K.ring_rec + (size_t)ring * 2;
+            report_orders<true>(a, K.kvac2, K.kvac * vxp, rr[1].x, K.kvac * vyp, C->present, C->order_of, a.gc[ring], vxp, vyp,
                                 rr[0].y);
         }
     }
     if (peri) {
-        // one source: the rotation stays in registers; batches have none to spare and re-read it (an L1 hit)
-        const double2 cs2 = NP == 1 ? cs : a.rot_table[aux];
+        // (the rotation is re-read, an L1 hit: four registers that are not live across the order loop)
+        const double2 cs2 = K.rot_table[aux];
         const double cosr = cs2.x, sinr = cs2.y;
         // (the propagation phasor already rides in every order's phasor; what is left is the
         // far-field plan's input modulation, if the plan has one: re-read here, an L2 hit)
         c2 e = {1.0, 0.0};
-        if (a.premod) {
-            const double2 t2 = a.premod[j];
+        if (K.premod) {
+            const double2 t2 = K.premod[j];
             e = {t2.x, t2.y};
         }
 #pragma unroll
         for (int m = 0; m < NP; ++m) {
             AccS q = pr[m];
-            if (a.premod) {
+            if (K.premod) {
                 const c2 Ex = cmulf({q.Exr, q.Exi}, e), Ey = cmulf({q.Eyr, q.Eyi}, e);
                 const c2 Hx = cmulf({q.Hxr, q.Hxi}, e), Hy = cmulf({q.Hyr, q.Hyi}, e);
                 q = {Ex.r, Ex.i, Ey.r, Ey.i, Hx.r, Hx.i, Hy.r, Hy.i};
@@ -611,20 +739,73 @@ __global__ __launch_bounds__(64, 3) void nearfield_simple_kernel(const NfArgs a)
             const c2 Ey = {fma(q.Exr, sinr, q.Eyr * cosr), fma(q.Exi, sinr, q.Eyi * cosr)};
             const c2 Hx = {fma(q.Hxr, cosr, -(q.Hyr * sinr)), fma(q.Hxi, cosr, -(q.Hyi * sinr))};
             const c2 Hy = {fma(q.Hxr, sinr, q.Hyr * cosr), fma(q.Hxi, sinr, q.Hyi * cosr)};
-            store_fields(a, m, i, j, Ex, Ey, Hx, Hy);
+            store_fields_k(K, m, i, j, Ex, Ey, Hx, Hy);
         }
     }
 }
 
-int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a, dim3 grid) {
-    if (a.n_pol == 1)
-        hipLaunchKernelGGL((nearfield_simple_kernel<1>), grid, dim3(64), 0, ctx->stream, a);
-    else if (a.n_pol == 2)
-        hipLaunchKernelGGL((nearfield_simple_kernel<2>), grid, dim3(64), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((nearfield_simple_kernel<3>), grid, dim3(64), 0, ctx->stream, a);
+#ifndef ML_NF_RING_MINW
+#define ML_NF_RING_MINW 5   // single-source ring kernel: 96 registers, five waves per SIMD
+#endif
+
+// LISTED: the launch is a list of patches (`list`, a leading kernel argument of its own so that the
+// pointer can arrive in scalar registers with the wave - kernarg preload, see the Makefile - and the
+// list entry is the FIRST load of the wave, not the third of a dependent chain); else the whole grid
+template <int NP, bool LISTED>
+__global__ __launch_bounds__(64, NP == 1 ? ML_NF_RING_MINW : 3) void nearfield_ring_kernel(const int2 *list, const NfArgs a) {
+    __shared__ double2 s_tab[RING_LDS];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (LISTED) {
+        const int2 pb = list[blockIdx.x];
+        bx = pb.x;
+        by = pb.y;
+    }
+    synthesize_patch<NP, PART_RING>(a, s_tab, s_tab, bx, by);
+}
+
+template <int NP, bool LISTED>
+__global__ __launch_bounds__(64, 3) void nearfield_centre_kernel(const int2 *list, const NfArgs a) {
+    // two buffers: order o + 1's block is on its way while order o is evaluated
+    __shared__ double2 s_tab[CB], s_tab1[CB];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (LISTED) {
+        const int2 pb = list[blockIdx.x];
+        bx = pb.x;
+        by = pb.y;
+    }
+    synthesize_patch<NP, PART_CENTRE>(a, s_tab, s_tab1, bx, by);
+}
+
+#ifdef ML_PHASE_TIMERS
+extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_phase), n_waves * PHASE_SLOTS * sizeof(unsigned long long), 0,
+                                    hipMemcpyDeviceToHost);
+}
+#endif
+
+template <int NP>
+static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
+    const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
+    // (the centre kernel first: it is the smaller one, and the ring kernel's tail is the one the row
+    // transform behind it has to wait for either way)
+    if (!a.use_active) {
+        if (a.n_cells > 0 || true)
+            hipLaunchKernelGGL((nearfield_centre_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
+        hipLaunchKernelGGL((nearfield_ring_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
+    } else {
+        if (a.n_active[2] > 0)
+            hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, ctx->stream,
+                               a.active_list + (size_t)2 * a.list_stride, a);
+        if (a.n_active[1] > 0)
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
+                               a.active_list + (size_t)1 * a.list_stride, a);
+    }
     ML_HIP(hipGetLastError());
     return ML_OK;
+}
+
+int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a) {
+    return a.n_pol == 1 ? launch_parts<1>(ctx, a) : a.n_pol == 2 ? launch_parts<2>(ctx, a) : launch_parts<3>(ctx, a);
 }
 
 }  // namespace ml

@@ -87,6 +87,27 @@ def interleaved_rows(n_rows, world, rank, block):
     return (block * (world * m[:, None] + rank) + np.arange(block)[None, :]).ravel()
 
 
+def block_amplitudes(a_theta, a_phi, world):
+    """the two projected amplitudes [mx][my] in the RANK-BLOCKED order the GPU path reduces them in
+    (csrc/farfield.hip ProjArgs::blk_rows): block b = direction rows [b R, (b + 1) R), R = mx / world,
+    of BOTH planes, contiguous - what a reduce-scatter hands rank b.  Returns a float64 vector (RCCL has
+    no complex type) of world equal chunks."""
+    a_theta, a_phi = np.asarray(a_theta, dtype=np.complex128), np.asarray(a_phi, dtype=np.complex128)
+    mx = a_theta.shape[0]
+    assert a_theta.shape == a_phi.shape and mx % world == 0
+    rows = mx // world
+    blocks = np.stack([a_theta.reshape(world, rows, -1), a_phi.reshape(world, rows, -1)], axis=1)   # [b][plane][R][my]
+    return np.ascontiguousarray(blocks).view(np.float64).ravel()
+
+
+def unblock_amplitudes(buf, world, shape):
+    """inverse of block_amplitudes: (a_theta, a_phi) of ``shape`` from the rank-blocked vector"""
+    mx = shape[0]
+    rows = mx // world
+    blocks = np.asarray(buf, dtype=np.float64).view(np.complex128).reshape(world, 2, rows, -1)
+    return blocks[:, 0].reshape(shape), blocks[:, 1].reshape(shape)
+
+
 def _id_path():
     key = '%s_%s_%s' % (os.environ.get('MASTER_PORT', '0'),
                         os.environ.get('TORCHELASTIC_RUN_ID', 'none'), os.getppid())

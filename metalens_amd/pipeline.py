@@ -30,10 +30,14 @@ class HotPath:
                  hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
                  c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None,
                  reduce='amplitudes', fuse_modulation=True, method=None, sharding='auto'):
-        """``reduce`` (multi-GPU only): 'amplitudes' all-reduces the two projected complex
-        amplitudes (half the payload; the radiation vectors in ``results()`` are then this
-        rank's partial sums), 'vectors' all-reduces Nx, Ny, Lx, Ly and projects afterwards."""
-        assert reduce in ('amplitudes', 'vectors')
+        """``reduce`` (multi-GPU only): 'amplitudes' sums the two projected complex amplitudes over
+        the ranks - by a reduce-scatter over blocks of direction rows, each rank taking the power of
+        its block (``results()`` gathers the whole map); the radiation vectors in ``results()`` are
+        then this rank's partial sums - 'amplitudes-allreduce' does the same by an all-reduce (twice
+        the bytes per rank), 'vectors' all-reduces Nx, Ny, Lx, Ly and projects afterwards."""
+        assert reduce in ('amplitudes', 'amplitudes-allreduce', 'vectors', 'none')
+        allreduce = reduce == 'amplitudes-allreduce'   # (comparison runs: the all-reduce instead of the reduce-scatter)
+        reduce = 'amplitudes' if allreduce else reduce
         assert sharding in ('auto', 'interleaved', 'mirrored', 'rows')
         self.reduce = reduce
         # the plan's stage-1 input modulation rides in the synthesis kernel (metalens_hip.h,
@@ -44,6 +48,8 @@ class HotPath:
         # construction so that an earlier HotPath(precision='f32') cannot leak into this one
         self.ctx.set_precision(precision or 'f64')   # 'f64' | 'f32': arithmetic of the GEMMs
         self.ctx.set_method(method or 'auto')        # 'auto' | 'gemm': _lib.Context.set_method
+        if hasattr(self.ctx.lib, 'ml_comm_set_reduce'):
+            _lib.check(self.ctx.lib.ml_comm_set_reduce(self.ctx.handle, int(allreduce)))
         self.rank, self.world = rank, world
         self.c0 = constants.c0 if c0 is None else c0
         self.Z0 = constants.Z0 if Z0 is None else Z0
@@ -181,9 +187,9 @@ class HotPath:
         if (self.world > 1 or dist.force_rccl()) and self.reduce == 'amplitudes':
             _lib.check(lib.ml_farfield_project_reduce(ctx.handle, self.Z0))
         else:
-            if self.world > 1 or dist.force_rccl():
+            if (self.world > 1 or dist.force_rccl()) and self.reduce == 'vectors':
                 _lib.check(lib.ml_farfield_allreduce(ctx.handle))
-            _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
+            _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))   # ('none': this rank's partial sums)
 
     def step(self):
         """queue one pass of the hot path on the context's stream (asynchronous)"""
@@ -241,6 +247,10 @@ class HotPath:
         if left:
             raise ValueError('a sample on another rank fell outside the characterisation tables '
                              '(that rank reports the value and the bound)')
+        # the step's reduce-scatter left every rank with the sum of ITS block of direction rows: the
+        # whole map on every rank is a collective of its own, paid here and not per step
+        if (self.world > 1 or dist.force_rccl()) and self.reduce == 'amplitudes':
+            _lib.check(lib.ml_farfield_gather(ctx.handle))
         P = np.empty(self.shape)
         a_theta = np.empty(self.shape, dtype=np.complex128)
         a_phi = np.empty(self.shape, dtype=np.complex128)

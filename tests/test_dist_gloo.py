@@ -157,3 +157,66 @@ def test_two_rank_sharded_sum_equals_whole(tmp_path, sharding):
     for got, want in zip(z['vectors'], whole):
         assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
     assert abs(z['power'][0] - case['power']) <= 1e-13 * abs(case['power'])
+
+
+def test_rank_blocked_amplitudes_round_trip():
+    rng = np.random.default_rng(5)
+    for world, mx, my in ((2, 8, 5), (4, 512, 512), (8, 64, 1)):
+        a = rng.standard_normal((mx, my)) + 1j * rng.standard_normal((mx, my))
+        b = rng.standard_normal((mx, my)) + 1j * rng.standard_normal((mx, my))
+        buf = dist.block_amplitudes(a, b, world)
+        assert buf.size == 2 * 2 * mx * my and buf.size % world == 0
+        # chunk r = rows [r R, (r + 1) R) of a_theta, then the same rows of a_phi
+        rows, chunk = mx // world, buf.size // world
+        for r in range(world):
+            c = buf[r * chunk:(r + 1) * chunk].view(np.complex128).reshape(2, rows, my)
+            assert np.array_equal(c[0], a[r * rows:(r + 1) * rows]) and np.array_equal(c[1], b[r * rows:(r + 1) * rows])
+        ga, gb = dist.unblock_amplitudes(buf, world, (mx, my))
+        assert np.array_equal(ga, a) and np.array_equal(gb, b)
+
+
+def _scatter_worker(rank, world, port, out_dir):
+    """the step's collective as the GPU path runs it (csrc/farfield.hip ml_farfield_project_reduce /
+    ml_farfield_gather), with gloo standing in for RCCL: every rank projects ITS partial amplitudes into
+    the rank-blocked buffer, a reduce-scatter leaves rank r with the sum of block r (gloo has no
+    reduce-scatter: one reduce per root), each rank takes the power of its block, an all-gather of
+    blocks and power rows completes every rank's picture"""
+    import torch
+    import torch.distributed as td
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    td.init_process_group('gloo', rank=rank, world_size=world)
+    mx, my = 16, 6
+    rng = np.random.default_rng(100 + rank)
+    a_theta = rng.standard_normal((mx, my)) + 1j * rng.standard_normal((mx, my))   # this rank's partial sums
+    a_phi = rng.standard_normal((mx, my)) + 1j * rng.standard_normal((mx, my))
+    buf = torch.from_numpy(dist.block_amplitudes(a_theta, a_phi, world))
+    chunk = buf.numel() // world
+    for root in range(world):     # reduce-scatter
+        part = buf[root * chunk:(root + 1) * chunk].clone()
+        td.reduce(part, dst=root, op=td.ReduceOp.SUM)
+        if root == rank:
+            mine = part
+    rows = mx // world
+    blk = mine.numpy().view(np.complex128).reshape(2, rows, my)
+    power = np.abs(blk[0]) ** 2 + np.abs(blk[1]) ** 2          # (stands for nearfield_farfield.py:184-189 on the block)
+    gathered = [torch.empty(chunk, dtype=torch.float64) for _ in range(world)]
+    td.all_gather(gathered, mine)
+    pw = [torch.empty(rows * my, dtype=torch.float64) for _ in range(world)]
+    td.all_gather(pw, torch.from_numpy(power.ravel().copy()))
+    ga, gb = dist.unblock_amplitudes(torch.cat(gathered).numpy(), world, (mx, my))
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), a_theta=a_theta, a_phi=a_phi, sum_theta=ga, sum_phi=gb,
+             power=torch.cat(pw).numpy().reshape(mx, my))
+    td.destroy_process_group()
+
+
+def test_two_rank_reduce_scatter_of_blocked_amplitudes(tmp_path):
+    pytest.importorskip('torch')
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_scatter_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z = [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(2)]
+    want_t, want_p = z[0]['a_theta'] + z[1]['a_theta'], z[0]['a_phi'] + z[1]['a_phi']
+    for r in range(2):
+        assert np.array_equal(z[r]['sum_theta'], want_t) and np.array_equal(z[r]['sum_phi'], want_p)
+        assert np.array_equal(z[r]['power'], np.abs(want_t) ** 2 + np.abs(want_p) ** 2)

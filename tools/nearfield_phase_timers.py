@@ -29,9 +29,13 @@ buf = np.zeros((n_waves, 10), dtype=np.uint64)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 assert lib.ml_debug_phase_dump(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_waves)) == 0
 t = buf[:, :10].astype(np.int64)
-names = ['records arrive', 'incident field + power', 'ring record + rotation arrive / centre: cell centre arrives',
-         'ring: set-up + staging (loads, LDS, barrier) / centre: phasors',
-         'orders', 'post (sincos, rotate)', 'stores issued', 'stores drained']
+# stamps: 0 start, 1 record, 2 incident + power, 3 ring record + rotation, 9 table cell located, 6 blocks matched
+# and loads issued, 4 phasors + weights done, 5 orders done (includes the wait for the staged blocks), 7 stores
+# issued (rotation back + address arithmetic), 8 stores drained
+order = [1, 2, 3, 9, 6, 4, 5, 7, 8]
+names = ['record arrives', 'incident field + power', 'ring record + rotation arrive', 'local frame + table cell',
+         'block matching + load issue', 'bounds, phasors (2 sincos), weights', 'wait for blocks + three orders',
+         'rotate back + store issue', 'stores drained']
 by = np.arange(n_waves) // nb
 bx = np.arange(n_waves) % nb
 r = np.hypot((bx + 0.5) * 8 - side / 2, (by + 0.5) * 8 - side / 2) * (580e-9 / 2.2)
@@ -46,11 +50,7 @@ for label, sel in (('periphery waves', (r > r_c * 1.1) & (r < R * 0.98)), ('cent
     life = (tt[:, 8] - tt[:, 0]).mean()
     print('%s (%d): lifetime %.0f cycles' % (label, len(tt), life))
     prev = tt[:, 0]
-    for k, nm in enumerate(names, start=1):
+    for k, nm in zip(order, names):
         cur = np.where(tt[:, k] > 0, tt[:, k], prev)
-        print('   %-32s %8.0f  (%4.1f %%)' % (nm, (cur - prev).mean(), 100 * (cur - prev).mean() / life))
+        print('   %-40s %8.0f  (%4.1f %%)' % (nm, (cur - prev).mean(), 100 * (cur - prev).mean() / life))
         prev = cur
-    su = tt[:, 9] - tt[:, 3]
-    ok = (tt[:, 9] > 0) & (tt[:, 3] > 0)
-    if ok.any():
-        print('   (of the set-up + staging: set-up arithmetic until the block matching starts %.0f cycles)' % su[ok].mean())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Digest the rocprofv3 counter passes of ONE bench.py configuration into an entry of
-profiles/pmc_table.json, which bench.py reads for `roofline.traffic`, `roofline.valu_insts` etc.
+profiles/pmc_table.json, which bench.py reads for `roofline.traffic`, `roofline.valu` etc.
 
     python tools/pmc_table.py KEY FETCH_DIR WRITE_DIR SQ_DIR [--table profiles/pmc_table.json]
 
@@ -12,7 +12,8 @@ KEY is bench.py's config key, e.g. "gpus=1,aperture=4096,farfield=512,precision=
     rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE ...
 
 Per kernel class (near field, stage 1, stage 2, projection) the STEADY-STATE launch shape is taken:
-the (kernel, grid) pair with the most dispatches.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch;
+the (kernel, grid) pair with the most dispatches - for the near field, whose step is TWO launches (ring
+and centre kernel), the steady-state shape of each kernel, summed.  FETCH_SIZE / WRITE_SIZE are KiB per dispatch;
 FETCH_SIZE is doubled (gfx950 counts a 128-byte request of a wide coalesced read as 64 bytes)."""
 import collections
 import csv
@@ -21,7 +22,7 @@ import json
 import os
 import sys
 
-CLASSES = (('nearfield', ('nearfield_field_kernel',)),
+CLASSES = (('nearfield', ('nearfield_ring_kernel', 'nearfield_centre_kernel', 'nearfield_field_kernel')),
            ('stage1', ('zfft_kernel<16, 256, 2, 1', 'zfft_kernel<8, 128, 2, 1', 'zfft_kernel<32, 512, 2, 1',
                        'zfft_kernel<4, 64, 2, 1', 'zfft_kernel<0, 512, 1, 1', 'zfft_multi_kernel<1>',
                        'zfft_pass_kernel<16, 2, 2, 2, 1>', 'zfft_pass_kernel<32, 2, 2, 2, 1>')),
@@ -47,13 +48,23 @@ def per_class(d):
                 acc[(cls, name.split('(')[0], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
     out = {}
     for cls, _ in CLASSES:
-        cands = [(max(len(v) for v in c.values()), k) for k, c in acc.items() if k[0] == cls]
-        if not cands:
+        # one steady-state shape per kernel (name before the template arguments) of the class, summed
+        by_kernel = collections.defaultdict(list)
+        for k, c in acc.items():
+            if k[0] == cls:
+                by_kernel[k[1].split('<')[0]].append((max(len(v) for v in c.values()), k))
+        if not by_kernel:
             continue
-        _, best = max(cands)
-        out[cls] = {n: sum(v) / len(v) for n, v in acc[best].items()}
-        out[cls]['_kernel'] = best[1]
-        out[cls]['_grid'] = int(best[2])
+        total, names, grid = collections.defaultdict(float), [], 0
+        for cands in by_kernel.values():
+            _, best = max(cands)
+            for n, v in acc[best].items():
+                total[n] += sum(v) / len(v)
+            names.append(best[1])
+            grid += int(best[2])
+        out[cls] = dict(total)
+        out[cls]['_kernel'] = ' + '.join(sorted(names))
+        out[cls]['_grid'] = grid
     return out
 
 
@@ -82,6 +93,9 @@ def main():
             entry[cls] = e
     if all('traffic_bytes' in entry.get(c, {}) for c in ('nearfield', 'stage1', 'stage2', 'project')):
         entry['step_traffic_bytes'] = sum(entry[c]['traffic_bytes'] for c in ('nearfield', 'stage1', 'stage2', 'project'))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    entry['source_id'] = bench.kernel_source_id()   # the kernels these counters belong to (bench.py flags a mismatch)
     entry['source'] = 'rocprofv3 --pmc passes digested by tools/pmc_table.py from %s, %s, %s' % (
         fetch_dir, write_dir, sq_dir)
     data = json.load(open(table)) if os.path.exists(table) else {}
