@@ -345,7 +345,7 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 // kernel's otherwise.
 enum { PART_RING = 1, PART_CENTRE = 2 };
 
-template <int NP, int PART>
+template <int NP, int PART, bool LISTED>
 __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab, double2 *s_tab1, int bx, int by) {
     const int lane = threadIdx.x;
     const unsigned lane_off = (unsigned)lane * 16u;
@@ -414,11 +414,12 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     const bool lens = idx <= K.n_rings;
     const bool peri = lens && idx >= 1;
     // who sums the patch's incident power and stores its zeros: see above
-    const bool mine_too = PART == PART_RING || !__ballot(peri);   // wave-uniform
+    // (the full-grid launch - the first synthesis into a buffer - visits every patch with the ring kernel)
+    const bool mine_too = PART == PART_RING || (LISTED && !__ballot(peri));   // wave-uniform
     if (mine_too) {
 #pragma unroll
         for (int m = 0; m < NP; ++m) wave_power_k(a, K, lens ? power_in[m] : 0.0, bx, by, m);
-        if (inb && !lens && !K.outside_is_zero) {
+        if (!LISTED && inb && !lens && !K.outside_is_zero) {   // (a listed launch follows one that stored them)
             const c2 zero = {0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NP; ++m) store_fields_k(K, m, i, j, zero, zero, zero, zero);
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_RING_MINW : 3) void nearfield_r
         bx = pb.x;
         by = pb.y;
     }
-    synthesize_patch<NP, PART_RING>(a, s_tab, s_tab, bx, by);
+    synthesize_patch<NP, PART_RING, LISTED>(a, s_tab, s_tab, bx, by);
 }
 
 template <int NP, bool LISTED>
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(64, 3) void nearfield_centre_kernel(const int2 *lis
         bx = pb.x;
         by = pb.y;
     }
-    synthesize_patch<NP, PART_CENTRE>(a, s_tab, s_tab1, bx, by);
+    synthesize_patch<NP, PART_CENTRE, LISTED>(a, s_tab, s_tab1, bx, by);
 }
 
 #ifdef ML_PHASE_TIMERS
@@ -783,24 +784,46 @@ extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
 }
 #endif
 
+#ifndef ML_NF_TWO_STREAMS
+#define ML_NF_TWO_STREAMS 1   // the centre kernel on a second stream, beside the ring kernel (A/B builds: 0)
+#endif
+
 template <int NP>
 static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
-    // (the centre kernel first: it is the smaller one, and the ring kernel's tail is the one the row
-    // transform behind it has to wait for either way)
+    // The two kernels write disjoint samples and are independent of each other: the centre kernel goes
+    // to a second stream, forked off and joined back by events, so that its waves fill the issue slots
+    // the ring kernel leaves (and its launch does not wait for the ring kernel's tail, nor the ring
+    // kernel's for its own).
+    hipStream_t cs = ctx->stream;
+    const bool centre_work = !a.use_active || a.n_active[2] > 0;
+    const bool fork = ML_NF_TWO_STREAMS && centre_work && (!a.use_active || a.n_active[1] > 0);
+    if (fork) {
+        if (!ctx->nf_stream) {
+            ML_HIP(hipStreamCreateWithFlags(&ctx->nf_stream, hipStreamNonBlocking));
+            ML_HIP(hipEventCreateWithFlags(&ctx->nf_fork, hipEventDisableTiming));
+            ML_HIP(hipEventCreateWithFlags(&ctx->nf_join, hipEventDisableTiming));
+        }
+        ML_HIP(hipEventRecord(ctx->nf_fork, ctx->stream));
+        ML_HIP(hipStreamWaitEvent(ctx->nf_stream, ctx->nf_fork, 0));
+        cs = ctx->nf_stream;
+    }
     if (!a.use_active) {
-        if (a.n_cells > 0 || true)
-            hipLaunchKernelGGL((nearfield_centre_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
         hipLaunchKernelGGL((nearfield_ring_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
+        hipLaunchKernelGGL((nearfield_centre_kernel<NP, false>), full, dim3(64), 0, cs, nullptr, a);
     } else {
-        if (a.n_active[2] > 0)
-            hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, ctx->stream,
-                               a.active_list + (size_t)2 * a.list_stride, a);
         if (a.n_active[1] > 0)
             hipLaunchKernelGGL((nearfield_ring_kernel<NP, true>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)1 * a.list_stride, a);
+        if (a.n_active[2] > 0)
+            hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, cs,
+                               a.active_list + (size_t)2 * a.list_stride, a);
     }
     ML_HIP(hipGetLastError());
+    if (fork) {
+        ML_HIP(hipEventRecord(ctx->nf_join, ctx->nf_stream));
+        ML_HIP(hipStreamWaitEvent(ctx->stream, ctx->nf_join, 0));
+    }
     return ML_OK;
 }
 
