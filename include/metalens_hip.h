@@ -335,6 +335,10 @@ int ml_nearfield_powers(ml_ctx *ctx, double *power, int n);
 int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double cone_ux0, double cone_uy0,
                            int slot, int reset);
 int ml_farfield_sums(ml_ctx *ctx, double *P_sum, double *total_P, double *cone_P, int n_slots);
+/* total_P of the CURRENT projection alone (nearfield_farfield.py:74), same fixed-order sum, without
+ * touching P_sum or any sweep slot: a one-off far field on a context that is also running a sweep
+ * leaves the sweep's sums as they were.  Synchronises.                                          */
+int ml_farfield_total_power(ml_ctx *ctx, double *total_P);
 
 /* Exact ties of the nearest-cell search.  A centre-region sample that is exactly equidistant
  * from two cells (it sits on a mirror line of the cell lattice: the x = 0 row of a symmetric

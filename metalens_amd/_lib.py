@@ -43,7 +43,7 @@ SYMBOLS = (
     'ml_farfield_plan_kernels', 'ml_farfield_set_method',
     'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
-    'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_host_alloc', 'ml_host_free',
+    'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_farfield_total_power', 'ml_host_alloc', 'ml_host_free',
     'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather',
 )
 
@@ -104,6 +104,7 @@ def load():
     lib.ml_nearfield_powers.argtypes = [c_void_p, _dp, c_int]
     lib.ml_farfield_accumulate.argtypes = [c_void_p, c_double, c_double, c_double, c_double, c_int, c_int]
     lib.ml_farfield_sums.argtypes = [c_void_p, _dp, _dp, _dp, c_int]
+    lib.ml_farfield_total_power.argtypes = [c_void_p, _dp]
     lib.ml_host_alloc.argtypes = [ctypes.c_uint64, POINTER(c_void_p)]
     lib.ml_host_free.argtypes = [c_void_p]
     lib.ml_nearfield_result.argtypes = [c_void_p, _dp, POINTER(BoundViolation), c_int,
@@ -291,6 +292,7 @@ class Context:
         """'f64' (default) or 'f32': arithmetic of the folded aperture -> direction GEMMs
         (include/metalens_hip.h, ml_farfield_set_precision); everything else stays fp64"""
         check(self.lib.ml_farfield_set_precision(self.handle, {'f64': 0, 'f32': 1}[precision]))
+        self.precision = precision
 
     def set_method(self, method):
         """'auto' (default): axes whose direction grid sits on the aperture's FFT lattice run as

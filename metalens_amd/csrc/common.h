@@ -368,9 +368,6 @@ struct ml_ctx {
 
     // RCCL.  comm_stream carries the all-reduce of the projected amplitudes and the power kernel
     // behind it; amp_ready[s] / reduce_done[s] order it against the main stream per amplitude slot
-    // second stream of the synthesis: the centre kernel runs beside the ring kernel (nearfield_simple.hip)
-    hipStream_t nf_stream = nullptr;
-    hipEvent_t nf_fork = nullptr, nf_join = nullptr;
     hipStream_t comm_stream = nullptr;
     hipEvent_t amp_ready[2] = {nullptr, nullptr}, reduce_done[2] = {nullptr, nullptr};
     bool reduce_in_flight = false;

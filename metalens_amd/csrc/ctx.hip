@@ -535,12 +535,6 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
-    if (ctx->nf_stream) {
-        (void)hipStreamSynchronize(ctx->nf_stream);
-        (void)hipEventDestroy(ctx->nf_fork);
-        (void)hipEventDestroy(ctx->nf_join);
-        (void)hipStreamDestroy(ctx->nf_stream);
-    }
     if (ctx->comm_stream) {
         for (int k = 0; k < 2; ++k) {
             (void)hipEventDestroy(ctx->amp_ready[k]);

@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(256) void accumulate_kernel(const AccArgs a) {
     double tot = 0.0, cone = 0.0;
     if (at < n) {
         const double P = a.P[at];
-        a.P_sum[at] = a.reset ? a.weight * P : a.P_sum[at] + a.weight * P;
+        if (a.P_sum) a.P_sum[at] = a.reset ? a.weight * P : a.P_sum[at] + a.weight * P;
         if (isfinite(P)) {
             const int i = a.pair_list ? (int)at : (int)(at / a.my), j = a.pair_list ? (int)at : (int)(at % a.my);
             const double ux = a.ux[i] - a.cone_ux0, uy = a.uy[j] - a.cone_uy0;
@@ -1408,31 +1408,31 @@ __global__ __launch_bounds__(256) void accumulate_finish_kernel(const double *pa
     }
 }
 
-int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double cone_ux0, double cone_uy0,
-                           int slot, int reset) {
-    ML_REQUIRE(ctx, "ctx is NULL");
+// slot ML_MAX_SWEEP_SLOTS is private to ml_farfield_total_power: a one-off total never lands in a
+// slot (or the P_sum) that a sweep on the same context is filling
+static int accumulate_impl(ml_ctx *ctx, double weight, double cone_u, double cone_ux0, double cone_uy0,
+                           int slot, int reset, bool into_sum) {
     FarfieldPlan &pl = ctx->plan;
     if (!pl.ready || !pl.have_vectors) {
         set_error("nothing projected: call ml_farfield_transform and ml_farfield_project first");
         return ML_ESTATE;
     }
-    ML_REQUIRE(slot >= 0 && slot < ML_MAX_SWEEP_SLOTS, "slot %d out of range [0, %d)", slot,
-               ML_MAX_SWEEP_SLOTS);
     ML_HIP(hipSetDevice(ctx->device));
     ML_TRY(comm_join(ctx, false));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
     const int blocks = (int)((n + 255) / 256);
-    ML_TRY(ctx->acc_P.reserve(n * sizeof(double)));
+    if (into_sum) ML_TRY(ctx->acc_P.reserve(n * sizeof(double)));
     ML_TRY(ctx->acc_partials.reserve((size_t)blocks * 2 * sizeof(double)));
     if (!ctx->acc_sums.p) {
-        ML_TRY(ctx->acc_sums.reserve((size_t)ML_MAX_SWEEP_SLOTS * 2 * sizeof(double)));
-        ML_HIP(hipMemsetAsync(ctx->acc_sums.p, 0, (size_t)ML_MAX_SWEEP_SLOTS * 2 * sizeof(double), ctx->stream));
+        const size_t bytes = (size_t)(ML_MAX_SWEEP_SLOTS + 1) * 2 * sizeof(double);
+        ML_TRY(ctx->acc_sums.reserve(bytes));
+        ML_HIP(hipMemsetAsync(ctx->acc_sums.p, 0, bytes, ctx->stream));
     }
     AccArgs a;
     a.P = pl.power.as<double>();
     a.ux = pl.ux.as<double>();
     a.uy = pl.uy.as<double>();
-    a.P_sum = ctx->acc_P.as<double>();
+    a.P_sum = into_sum ? ctx->acc_P.as<double>() : nullptr;
     a.partials = ctx->acc_partials.as<double>();
     a.mx = pl.mx;
     a.my = pl.my;
@@ -1455,6 +1455,23 @@ int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double con
                        ctx->acc_partials.as<double>(), blocks, ctx->acc_sums.as<double>() + 2 * slot);
     ML_HIP(hipGetLastError());
     ctx->acc_blocks = blocks;
+    return ML_OK;
+}
+
+int ml_farfield_accumulate(ml_ctx *ctx, double weight, double cone_u, double cone_ux0, double cone_uy0,
+                           int slot, int reset) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(slot >= 0 && slot < ML_MAX_SWEEP_SLOTS, "slot %d out of range [0, %d)", slot,
+               ML_MAX_SWEEP_SLOTS);
+    return accumulate_impl(ctx, weight, cone_u, cone_ux0, cone_uy0, slot, reset, true);
+}
+
+int ml_farfield_total_power(ml_ctx *ctx, double *total_P) {
+    ML_REQUIRE(ctx && total_P, "NULL argument");
+    ML_TRY(accumulate_impl(ctx, 1.0, 0.0, 0.0, 0.0, ML_MAX_SWEEP_SLOTS, 0, false));
+    ML_HIP(hipMemcpyAsync(total_P, ctx->acc_sums.as<double>() + 2 * ML_MAX_SWEEP_SLOTS, sizeof(double),
+                          hipMemcpyDeviceToHost, ctx->stream));
+    ML_HIP(hipStreamSynchronize(ctx->stream));
     return ML_OK;
 }
 

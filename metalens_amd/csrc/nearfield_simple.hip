@@ -43,8 +43,13 @@ static_assert(SK_TYPES == CENTER_GROUP, "the centre table's cell blocks hold gro
 // makes the values opaque, so the loads cannot sink back to their uses): left to itself the
 // compiler fetches each of them where it is used - some twenty-five scalar loads along a ring
 // wave's path, each followed by its own wait for the scalar cache.
-#define ML_GLOBAL __attribute__((address_space(1)))   // (a pointer that went through the asm statement is
-                                                       // "generic" to the compiler, and its loads flat_loads, unless told)
+// (a pointer that went through the asm statement is "generic" to the compiler, and its loads
+// flat_loads, unless told; the host pass of the compiler knows no address spaces)
+#ifdef __HIP_DEVICE_COMPILE__
+#define ML_GLOBAL __attribute__((address_space(1)))
+#else
+#define ML_GLOBAL
+#endif
 struct Consts {
     double kvac, kvac2, kg2, efh, sx, sy, dz, dz2, z2;
     double b0, b1, b2, b3;   // the (ux', uy') range every ring table covers (NfArgs::ring_bounds_all)
@@ -344,6 +349,9 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 // are the ring kernel's where the patch has ring samples (and on its full-grid launch), the centre
 // kernel's otherwise.
 enum { PART_RING = 1, PART_CENTRE = 2 };
+#ifndef ML_NF_KEEP_ROT
+#define ML_NF_KEEP_ROT 0
+#endif
 
 template <int NP, int PART, bool LISTED>
 __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab, double2 *s_tab1, int bx, int by) {
@@ -717,8 +725,10 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         }
     }
     if (peri) {
-        // (the rotation is re-read, an L1 hit: four registers that are not live across the order loop)
-        const double2 cs2 = K.rot_table[aux];
+        // (ML_NF_KEEP_ROT = 0: the rotation is re-read, an L1 hit - four registers that are not live across the
+        // order loop, which is what fits five waves per SIMD; 1: it stays in registers)
+        double2 cs2 = cs;
+        if (!(ML_NF_KEEP_ROT && NP == 1)) cs2 = K.rot_table[aux];
         const double cosr = cs2.x, sinr = cs2.y;
         // (the propagation phasor already rides in every order's phasor; what is left is the
         // far-field plan's input modulation, if the plan has one: re-read here, an L2 hit)
@@ -784,46 +794,24 @@ extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
 }
 #endif
 
-#ifndef ML_NF_TWO_STREAMS
-#define ML_NF_TWO_STREAMS 1   // the centre kernel on a second stream, beside the ring kernel (A/B builds: 0)
-#endif
-
 template <int NP>
 static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
-    // The two kernels write disjoint samples and are independent of each other: the centre kernel goes
-    // to a second stream, forked off and joined back by events, so that its waves fill the issue slots
-    // the ring kernel leaves (and its launch does not wait for the ring kernel's tail, nor the ring
-    // kernel's for its own).
-    hipStream_t cs = ctx->stream;
-    const bool centre_work = !a.use_active || a.n_active[2] > 0;
-    const bool fork = ML_NF_TWO_STREAMS && centre_work && (!a.use_active || a.n_active[1] > 0);
-    if (fork) {
-        if (!ctx->nf_stream) {
-            ML_HIP(hipStreamCreateWithFlags(&ctx->nf_stream, hipStreamNonBlocking));
-            ML_HIP(hipEventCreateWithFlags(&ctx->nf_fork, hipEventDisableTiming));
-            ML_HIP(hipEventCreateWithFlags(&ctx->nf_join, hipEventDisableTiming));
-        }
-        ML_HIP(hipEventRecord(ctx->nf_fork, ctx->stream));
-        ML_HIP(hipStreamWaitEvent(ctx->nf_stream, ctx->nf_fork, 0));
-        cs = ctx->nf_stream;
-    }
+    // (the two kernels write disjoint samples and could run side by side: with the centre kernel forked
+    // off to a second stream and joined back by events the step measured 1.5 % SLOWER at 4096^2 and 5 %
+    // at 2048^2 - the events cost more than the ring kernel's idle issue slots give)
     if (!a.use_active) {
         hipLaunchKernelGGL((nearfield_ring_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
-        hipLaunchKernelGGL((nearfield_centre_kernel<NP, false>), full, dim3(64), 0, cs, nullptr, a);
+        hipLaunchKernelGGL((nearfield_centre_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
     } else {
         if (a.n_active[1] > 0)
             hipLaunchKernelGGL((nearfield_ring_kernel<NP, true>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)1 * a.list_stride, a);
         if (a.n_active[2] > 0)
-            hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, cs,
+            hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)2 * a.list_stride, a);
     }
     ML_HIP(hipGetLastError());
-    if (fork) {
-        ML_HIP(hipEventRecord(ctx->nf_join, ctx->nf_stream));
-        ML_HIP(hipStreamWaitEvent(ctx->stream, ctx->nf_join, 0));
-    }
     return ML_OK;
 }
 

@@ -107,7 +107,8 @@ __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int
 // LDS ([k2][n1]: the lanes of a 16-lane group read neighbouring or equal slots) to pay for it.
 // PASS (1: rows of the aperture, 2: columns of stage 1's result) only names the instantiation, so
 // that a profile lists the two passes separately.
-template <int R3T, int NTMAX, int MINW, int PASS>
+// IP: exchange 2 in place (zfft_core.h Geo::ip): one barrier fewer per row.
+template <int R3T, int NTMAX, int MINW, int PASS, bool IP>
 __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
     cd *lds = reinterpret_cast<cd *>(zfft_lds_raw);
@@ -159,15 +160,22 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         }
         __syncthreads();
         zf::gather2(g, tid, v, lds);
-        __syncthreads();
-        zf::scatter2(g, tid, v, lds);
+        if (IP) {
+            zf::scatter2_ip(g, tid, v, lds);   // (a thread overwrites only the slots it has just read)
+        } else {
+            __syncthreads();
+            zf::scatter2(g, tid, v, lds);
+        }
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
         const double al = a.alpha[row / a.alpha_rb];
         if (few && pair) {
             // the two bins share their LDS operands
             cd xa, xb;
-            zf::stage3_pair(g, k0, w0, w1, lds, xa, xb);
+            if (IP)
+                zf::stage3_pair_ip(g, k0, w0, w1, lds, xa, xb);
+            else
+                zf::stage3_pair(g, k0, w0, w1, lds, xa, xb);
             xa = zf::cmul(xa, p0);
             xb = zf::cmul(xb, p1);
             xa.x *= al;
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
             *db = xb;
         } else if (few) {
             if (own0) {
-                cd x = zf::cmul(zf::stage3(g, k0, w0, lds), p0);
+                cd x = zf::cmul(IP ? zf::stage3_ip(g, k0, w0, lds) : zf::stage3(g, k0, w0, lds), p0);
                 x.x *= al;
                 x.y *= al;
                 cd *d = dst + bin0 * a.out_es;
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
                 *d = x;
             }
             if (own1) {
-                cd x = zf::cmul(zf::stage3(g, k1, w1, lds), p1);
+                cd x = zf::cmul(IP ? zf::stage3_ip(g, k1, w1, lds) : zf::stage3(g, k1, w1, lds), p1);
                 x.x *= al;
                 x.y *= al;
                 cd *d = dst + bin1 * a.out_es;
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         } else {
             for (int o = tid; o < g.M; o += NT) {
                 const cd w = a.wk[o], p = a.pj[o];
-                cd x = zf::cmul(zf::stage3(g, a.kbin[o], w, lds), p);
+                cd x = zf::cmul(IP ? zf::stage3_ip(g, a.kbin[o], w, lds) : zf::stage3(g, a.kbin[o], w, lds), p);
                 x.x *= al;
                 x.y *= al;
                 cd *d = dst + o * a.out_es;
@@ -465,6 +473,7 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
     a.g.j0 = c.j0;
     a.g.pad1 = c.pad1;
     a.g.pad2 = c.pad2;
+    a.g.ip = 0;
     a.in = reinterpret_cast<const cd *>(c.in);
     a.in_s1 = c.in_s1;
     a.in_s2 = c.in_s2;
@@ -623,9 +632,17 @@ int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, i
     return ML_OK;
 }
 
+#ifndef ML_ZFFT_IP
+// exchange 2 of the one-level kernel in place for lattices up to this many residues (A/B builds: 0 =
+// never).  Measured on one box, stage 1: R3 = 16 (4096^2) 0.183 -> 0.179 ms, R3 = 8 (2048^2) 0.0585 ->
+// 0.0579, R3 = 32 (8192^2, NA 0.94, one workgroup per CU) 0.678 -> 0.713: the longer bank-conflict
+// tail of the in-place pattern costs more than the barrier where nothing else is resident to hide it
+#define ML_ZFFT_IP 16
+#endif
 template <int R3T, int NTMAX, int MINW, int PASS>
 static int launch_one(hipStream_t stream, const FftArgs &a, int grid, size_t lds_bytes) {
-    auto kern = zfft_kernel<R3T, NTMAX, MINW, PASS>;
+    constexpr bool IP = R3T != 0 && R3T <= ML_ZFFT_IP;
+    auto kern = zfft_kernel<R3T, NTMAX, MINW, PASS, IP>;
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
         ML_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -645,6 +662,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     a.g.j0 = c.j0;
     a.g.pad1 = c.pad1;
     a.g.pad2 = c.pad2;
+    a.g.ip = 0;
     a.in = reinterpret_cast<const cd *>(c.in);
     a.in_s1 = c.in_s1;
     a.in_s2 = c.in_s2;
@@ -686,7 +704,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
         ML_HIP(hipGetLastError());
         return ML_OK;
     }
-    const size_t lds_bytes = ((size_t)zf::lds_elems(a.g) + 256) * sizeof(cd);   // exchange buffer + twiddles
+    size_t lds_bytes = ((size_t)zf::lds_elems(a.g) + 256) * sizeof(cd);   // exchange buffer + twiddles
     // workgroups resident per CU (LDS-limited), 256 CUs; a multiple of 8 so that a workgroup
     // stays on the rows of one XCD
     const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds_bytes));
@@ -725,6 +743,12 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
         }
     }
     ML_REQUIRE(a.g.R3 <= 32, "a lattice of %d samples does not fit one workgroup (%d wanted bins)", c.N_eff, c.M);
+    if (a.g.R3 <= ML_ZFFT_IP && (a.g.R3 == 4 || a.g.R3 == 8 || a.g.R3 == 16 || a.g.R3 == 32)) {
+        // the in-place layout answers to one padding, chosen for its four access patterns
+        a.g.ip = 1;
+        zfft_choose_pads(-c.N_eff, c.M, c.j0, &a.g.pad1, &a.g.pad2);
+        lds_bytes = ((size_t)zf::lds_elems(a.g) + 256) * sizeof(cd);
+    }
     if (c.in_es == 1) switch (a.g.R3) {   // pass 1: contiguous rows
             case 4: return launch_one<4, 64, 2, 1>(stream, a, grid, lds_bytes);
             case 8: return launch_one<8, 128, 2, 1>(stream, a, grid, lds_bytes);
@@ -747,7 +771,7 @@ void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2) {
     const auto key = std::make_tuple(N_eff, M, j0);
     auto hit = memo.find(key);
     if (hit == memo.end()) {
-        zf::Geo g{N_eff / 256, N_eff, M, j0, 0, 0};
+        zf::Geo g{std::abs(N_eff) / 256, std::abs(N_eff), M, j0, 0, 0, N_eff < 0 ? 1 : 0};   // (N_eff < 0: in place)
         zf::choose_pads(g);
         if (memo.size() > 4096) memo.clear();
         hit = memo.emplace(key, std::make_pair(g.pad1, g.pad2)).first;

@@ -103,13 +103,20 @@ struct Geo {
     int j0;        // bin of output 0 (may be negative)
     int pad1;      // LDS: exchange 1 element (t, k2) lives at t + (NT + pad1) k2
     int pad2;      //      exchange 2 element (n0, k1, k2) at k2 + 16 k1 + (256 + pad2) n0
+    // ip != 0: exchange 2 IN PLACE - thread u = n0 + R3 k2 of stage 2 writes its sixteen results
+    // (k1 = 0..15) back to the sixteen slots it read (n1 = 0..15): element (n0, k1, k2) lives at
+    // exchange 1's address of (t = n0 + R3 k1, k2).  Nobody else touches those slots between the
+    // read and the write, so the barrier between them goes, and the last stage finds the R3 residues
+    // of a bin in R3 CONSECUTIVE elements.
+    int ip;
 };
 ZF_HD int lds_elems(const Geo &g) {
     const int e1 = (16 * g.R3 + g.pad1) * 16, e2 = (256 + g.pad2) * g.R3;
-    return e1 > e2 ? e1 : e2;
+    return (g.ip || e1 > e2) ? e1 : e2;
 }
 ZF_HD int ex1_addr(const Geo &g, int t, int k2) { return t + (16 * g.R3 + g.pad1) * k2; }
 ZF_HD int ex2_addr(const Geo &g, int n0, int k1, int k2) { return k2 + 16 * k1 + (256 + g.pad2) * n0; }
+ZF_HD int ex2ip_addr(const Geo &g, int n0, int k1, int k2) { return ex1_addr(g, n0 + g.R3 * k1, k2); }
 // wanted bin of output j, reduced to [0, N_eff)
 ZF_HD int bin_of(const Geo &g, int j) {
     const int N = 256 * g.R3;
@@ -171,6 +178,27 @@ ZF_HD void scatter2(const Geo &g, int u, const cd *v, cd *lds) {
     const int n0 = u % g.R3, k2 = u / g.R3;
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) lds[ex2_addr(g, n0, k1, k2)] = v[bin16(k1)];
+}
+// exchange 2 in place (Geo::ip): no barrier between gather2() and this
+ZF_HD void scatter2_ip(const Geo &g, int u, const cd *v, cd *lds) {
+    const int n0 = u % g.R3, k2 = u / g.R3;
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) lds[ex2ip_addr(g, n0, k1, k2)] = v[bin16(k1)];
+}
+ZF_HD cd stage3_ip(const Geo &g, int k, cd w, const cd *lds) {
+    const cd *b = lds + ex2ip_addr(g, 0, (k >> 4) & 15, k & 15);   // the bin's residues: b[0 .. R3)
+    cd x = b[g.R3 - 1];
+    for (int n0 = g.R3 - 2; n0 >= 0; --n0) x = cmac(x, w, b[n0]);
+    return x;
+}
+ZF_HD void stage3_pair_ip(const Geo &g, int k, cd wa, cd wb, const cd *lds, cd &xa, cd &xb) {
+    const cd *b = lds + ex2ip_addr(g, 0, (k >> 4) & 15, k & 15);
+    xa = xb = b[g.R3 - 1];
+    for (int n0 = g.R3 - 2; n0 >= 0; --n0) {
+        const cd t = b[n0];
+        xa = cmac(xa, wa, t);
+        xb = cmac(xb, wb, t);
+    }
 }
 // stage 3 for ONE wanted bin k: Horner over the residues with ratio w = W_N^k
 ZF_HD cd stage3(const Geo &g, int k, cd w, const cd *lds) {
@@ -249,7 +277,7 @@ inline LdsCost lds_cost(const Geo &g) {
             c.ex1_read += lds_cycles(addr, true);
             for (int l = 0; l < 64; ++l) {
                 const int u = w0 + l;
-                addr[l] = u < NT ? ex2_addr(g, u % g.R3, s, u / g.R3) : -1;
+                addr[l] = u >= NT ? -1 : g.ip ? ex2ip_addr(g, u % g.R3, s, u / g.R3) : ex2_addr(g, u % g.R3, s, u / g.R3);
             }
             c.ex2_write += lds_cycles(addr, false);
             c.ideal_rw += 4 + 8;
@@ -263,7 +291,7 @@ inline LdsCost lds_cost(const Geo &g) {
                     continue;
                 }
                 const int k = bin_of(g, o0 + l);
-                addr[l] = ex2_addr(g, n0, (k >> 4) & 15, k & 15);
+                addr[l] = g.ip ? ex2ip_addr(g, n0, (k >> 4) & 15, k & 15) : ex2_addr(g, n0, (k >> 4) & 15, k & 15);
             }
             c.ex2_read += lds_cycles(addr, true);
         }
@@ -280,7 +308,8 @@ inline void choose_pads(Geo &g) {
         t.pad1 = p1;
         t.pad2 = 0;
         const LdsCost c = lds_cost(t);
-        const long cost = (c.ex1_write + c.ex1_read) * 64 + p1;
+        // (in place, all four patterns live in exchange 1's layout and answer to pad1)
+        const long cost = (c.ex1_write + c.ex1_read + (g.ip ? c.ex2_write + c.ex2_read : 0)) * 64 + p1;
         if (best < 0 || cost < best) {
             best = cost;
             b1 = p1;

@@ -135,6 +135,9 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
     ctx = ctx or _lib.default_context()
     packing.upload_tables(ctx, gc_list, hexgridset, wavelength_in_nm)
     packing.upload_layout(ctx, S, lens_center_summary)
+    # the drop-in hands back (or leaves resident) the PLAIN fields: a HotPath that shared this
+    # context may have left the synthesis writing exp(-i pi (i+j)) modulated ones
+    _lib.check(ctx.lib.ml_nearfield_premodulate(ctx.handle, 0))
     p = nearfield_params(source_x, source_y, source_z, source_pol, wavelength, n_glass,
                          dipole_moment, c0, Z0)
     power = _lib.c_double(0)

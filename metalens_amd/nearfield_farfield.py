@@ -109,20 +109,25 @@ def farfield_from_resident_nearfield(xp_list, yp_list, wavelength, n_glass, *, Z
     # the reference's lattice, in the reference's own expressions, shifted as it returns it
     ux_list = np.fft.fftshift(fft_direction_cosines(num_x, dxp, wavelength, n_glass))
     uy_list = np.fft.fftshift(fft_direction_cosines(num_y, dyp, wavelength, n_glass))
-    t = FarfieldTransform(num_x, num_y, dxp, dyp, wavelength, n_glass, ux_list, uy_list, ctx=ctx)
+    # this flow documents fp64; whatever arithmetic the context's other users had chosen is put
+    # back afterwards (the plan itself is per call: the next user plans again anyway)
+    before = getattr(ctx, 'precision', 'f64')
+    t = FarfieldTransform(num_x, num_y, dxp, dyp, wavelength, n_glass, ux_list, uy_list, ctx=ctx,
+                          precision='f64')
     lib = ctx.lib
     _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
     _lib.check(lib.ml_farfield_project_async(ctx.handle, Z0))
-    # total_P = sum of the finite P * dux * duy (slot 0 of the sweep sums, reset)
-    _lib.check(lib.ml_farfield_accumulate(ctx.handle, 1.0, 0.0, 0.0, 0.0, 0, 1))
     P = _lib.pinned.empty((num_x, num_y), np.float64)
     _lib.check(lib.ml_farfield_project(ctx.handle, Z0, _lib.dptr(P), None, None))
+    # total_P = sum of the finite P * dux * duy, in a slot of its own: a sweep running on the same
+    # context keeps its P_sum and its per-source sums
     total = np.zeros(1)
-    _lib.check(lib.ml_farfield_sums(ctx.handle, None, _lib.dptr(total), None, 1))
+    _lib.check(lib.ml_farfield_total_power(ctx.handle, _lib.dptr(total)))
     dux = ux_list[1] - ux_list[0]
     duy = uy_list[1] - uy_list[0]
     ux, uy = np.meshgrid(ux_list, uy_list, indexing='ij', sparse=True)
     del t
+    ctx.set_precision(before)
     return P, float(total[0]), ux, uy, dux, duy
 
 

@@ -85,22 +85,39 @@ def _chunk_digest(view):
     return h.digest()
 
 
+def _drop_pool():
+    """a forked child inherits _POOL without its worker threads: start over there"""
+    global _POOL
+    _POOL = None
+
+
+if hasattr(os, 'register_at_fork'):
+    os.register_at_fork(after_in_child=_drop_pool)
+
+
 def _feed(h, a):
     """hash an array's dtype, shape and bytes (no copy for contiguous arrays).  Large arrays (the
     cell list of a millimetre lens is 30 MB, hashed on EVERY drop-in call) are hashed as eight
-    chunks on a thread pool - xxhash releases the GIL - and the chunk digests fed in order"""
+    chunk digests fed in order.  The chunk layout depends on the byte count ALONE, so the token of
+    a given content is the same on every host and under every CPU affinity; only WHERE the chunks
+    are hashed differs (a thread pool when there are cores for it - xxhash releases the GIL)"""
     global _POOL
     a = np.ascontiguousarray(a)
     h.update(('%s%s' % (a.dtype.str, a.shape)).encode())
     view = memoryview(a).cast('B')
-    if view.nbytes < _BIG or _cores() < 2 * _CHUNKS:
+    if view.nbytes < _BIG:
         h.update(view)
         return
-    if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=_CHUNKS)
     step = -(-view.nbytes // _CHUNKS)
-    for d in _POOL.map(_chunk_digest, [view[k:k + step] for k in range(0, view.nbytes, step)]):
+    chunks = [view[k:k + step] for k in range(0, view.nbytes, step)]
+    if _cores() < 2 * _CHUNKS:
+        digests = map(_chunk_digest, chunks)
+    else:
+        if _POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _POOL = ThreadPoolExecutor(max_workers=_CHUNKS)
+        digests = _POOL.map(_chunk_digest, chunks)
+    for d in digests:
         h.update(d)
 
 

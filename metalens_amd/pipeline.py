@@ -226,8 +226,15 @@ class HotPath:
             self.step()
             self.sync()
         else:
-            if self.x_local.size and ties.pending(self.ctx).size:
-                raise RuntimeError('nearest-cell ties still open after three rounds')
+            # 'still open' is decided by ALL ranks together, as 'redo' was: a rank that raised alone
+            # would leave the others waiting in _fetch's collective
+            still = 1.0 if self.x_local.size and ties.pending(self.ctx).size else 0.0
+            if self.world > 1 or dist.force_rccl():
+                still = float(dist.allreduce_host(self.ctx, [still], 'max')[0])
+            if still:
+                raise RuntimeError('nearest-cell ties still open after three rounds'
+                                   + ('' if self.x_local.size and ties.pending(self.ctx).size
+                                      else ' (on another rank)'))
         return self._fetch()
 
     def _fetch(self):

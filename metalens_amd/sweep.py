@@ -72,7 +72,13 @@ class SourceSweep:
 
     def queue(self, sources):
         """queue the whole sweep on the GPU and return without synchronising (benchmarks);
-        tie settlement and the downloads are ``run``'s business"""
+        tie settlement and the downloads are ``run``'s business.
+
+        NOT content-checked: ``queue`` trusts the hashes taken by the last ``prepare()`` / ``run()``
+        of this object.  An IN-PLACE edit of a table or of ``lens_center_summary`` made since then is
+        not noticed and the pass runs on the resident (older) content - call ``prepare()`` (or
+        ``run``) after editing.  Another object replacing the context's tables or layout IS
+        noticed (the context's tokens change) and triggers a full re-check."""
         self.prepare(check_content=False)
         weights = np.ones(len(sources))
         for g in self._group(sources):

@@ -108,7 +108,7 @@ def test_large_arrays_are_hashed_in_parallel_chunks(monkeypatch):
         assert digest(b) != d
     small = rng.standard_normal(16)
     monkeypatch.setattr(packing, '_cores', lambda: 1)
-    assert digest(small) == digest(small.copy()) and digest(a) != d   # serial form: another digest, same content rule
+    assert digest(small) == digest(small.copy()) and digest(a) == d   # few cores: same chunks hashed in line, same digest
 
 
 def test_failed_table_upload_leaves_nothing_marked_resident():
@@ -146,3 +146,28 @@ def test_failed_table_upload_leaves_nothing_marked_resident():
     n = ctx.lib.calls
     packing.upload_tables(ctx, gcs, lens['hexgridset'], 580)      # resident: no further upload
     assert ctx.lib.calls == n
+
+
+def test_large_array_digest_does_not_depend_on_the_core_count(monkeypatch):
+    """the chunk layout of a big array follows its byte count alone, so the token of a
+    given content is the same whether the chunks are hashed on a pool or in line"""
+    a = np.random.default_rng(3).standard_normal((packing._BIG // 8) + 1001)
+
+    def digest():
+        h = packing._hasher()
+        packing._feed(h, a)
+        return h.digest()
+
+    monkeypatch.setattr(packing, '_cores', lambda: 1)
+    serial = digest()
+    monkeypatch.setattr(packing, '_cores', lambda: 64)
+    pooled = digest()
+    assert serial == pooled
+    assert packing._POOL is not None
+    packing._drop_pool()                      # what a forked child does
+    assert packing._POOL is None and digest() == serial
+    b = a.copy()
+    b[-1] += 1.0
+    h = packing._hasher()
+    packing._feed(h, b)
+    assert h.digest() != serial

@@ -10,8 +10,8 @@
 
 using zf::cd;
 
-static double run(int R3, int n_valid, int M, int j0, bool verbose) {
-    zf::Geo g{R3, n_valid, M, j0, 0, 0};
+static double run(int R3, int n_valid, int M, int j0, bool verbose, int ip = 0) {
+    zf::Geo g{R3, n_valid, M, j0, 0, 0, ip};
     zf::choose_pads(g);
     const int NT = 16 * R3, N = 256 * R3;
     std::vector<cd> in(N), lds(zf::lds_elems(g));
@@ -33,22 +33,34 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose) {
         for (int n2 = 0; n2 < 16; ++n2) v[t][n2] = in[t + NT * n2];
         zf::stage1_regs(g, t, v[t].data(), ta, tb, lds.data());
     }
-    for (int u = 0; u < NT; ++u) zf::gather2(g, u, v[u].data(), lds.data());
-    for (int u = 0; u < NT; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
+    if (ip) {   // thread by thread, no barrier in between: a thread overwrites only what it has read itself
+        for (int u = 0; u < NT; ++u) {
+            zf::gather2(g, u, v[u].data(), lds.data());
+            zf::scatter2_ip(g, u, v[u].data(), lds.data());
+        }
+    } else {
+        for (int u = 0; u < NT; ++u) zf::gather2(g, u, v[u].data(), lds.data());
+        for (int u = 0; u < NT; ++u) zf::scatter2(g, u, v[u].data(), lds.data());
+    }
     double worst = 0, scale = 0;
     std::vector<cd> out(M);
     auto ratio = [&](int k) {
         const long double a = -2 * M_PIl * k / N;
         return zf::mk((double)cosl(a), (double)sinl(a));
     };
-    for (int j = 0; j < M; ++j) out[j] = zf::stage3(g, zf::bin_of(g, j), ratio(zf::bin_of(g, j)), lds.data());
+    for (int j = 0; j < M; ++j)
+        out[j] = ip ? zf::stage3_ip(g, zf::bin_of(g, j), ratio(zf::bin_of(g, j)), lds.data())
+                    : zf::stage3(g, zf::bin_of(g, j), ratio(zf::bin_of(g, j)), lds.data());
     // bins 256 apart share their operands: the paired form (the kernel's path for 256-thread
     // workgroups) must give exactly the same values
     for (int j = 0; j + 256 < M; ++j) {
         const int ka = zf::bin_of(g, j), kb = zf::bin_of(g, j + 256);
         if (((kb - ka) & 255) != 0) continue;
         cd xa, xb;
-        zf::stage3_pair(g, ka, ratio(ka), ratio(kb), lds.data(), xa, xb);
+        if (ip)
+            zf::stage3_pair_ip(g, ka, ratio(ka), ratio(kb), lds.data(), xa, xb);
+        else
+            zf::stage3_pair(g, ka, ratio(ka), ratio(kb), lds.data(), xa, xb);
         if (xa.x != out[j].x || xa.y != out[j].y || xb.x != out[j + 256].x || xb.y != out[j + 256].y) {
             printf("stage3_pair differs from stage3 at bin %d\n", j);
             return 1.0;
@@ -67,9 +79,9 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose) {
     }
     const zf::LdsCost c = zf::lds_cost(g);
     if (verbose)
-        printf("R3=%2d N=%5d valid=%5d M=%4d j0=%5d pads=(%d,%d) lds=%6d B  err=%.2e  cycles ex1 w/r %ld/%ld "
+        printf("%sR3=%2d N=%5d valid=%5d M=%4d j0=%5d pads=(%d,%d) lds=%6d B  err=%.2e  cycles ex1 w/r %ld/%ld "
                "ex2 w/r %ld/%ld (ideal w %ld r %ld)\n",
-               R3, N, n_valid, M, j0, g.pad1, g.pad2, zf::lds_elems(g) * 16, worst / scale, c.ex1_write,
+               ip ? "in place: " : "", R3, N, n_valid, M, j0, g.pad1, g.pad2, zf::lds_elems(g) * 16, worst / scale, c.ex1_write,
                c.ex1_read, c.ex2_write, c.ex2_read, c.ideal_rw * 8 / 12, c.ideal_rw * 4 / 12);
     return worst / scale;
 }
@@ -141,6 +153,7 @@ int main() {
                             {16, 4096, 300, 1000}, {1, 256, 64, -32},    {2, 512, 512, -256},
                             {16, 4096, 4096, -2048}, {5, 1280, 77, -3}, {12, 3072, 512, -256}};
     for (auto &c : cases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true));
+    for (auto &c : cases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true, 1));   // exchange 2 in place
     const int pcases[][5] = {{16, 2, 4096, 512, -256}, {32, 2, 8192, 512, -256}, {8, 2, 2048, 256, -128},
                              {16, 4, 4000, 512, -256}, {32, 4, 8192, 300, 4000}, {12, 2, 3072, 100, -50}};
     for (auto &c : pcases) worst = fmax(worst, run_passes(c[0], c[1], c[2], c[3], c[4]));
