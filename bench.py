@@ -254,6 +254,8 @@ def main():
     ap.add_argument('--pair-list', type=int, default=0,
                     help='> 0: that many arbitrary directions (ux[d], uy[d]) inside the NA cone '
                          'instead of the M x M tensor grid')
+    ap.add_argument('--stack', type=int, default=1,
+                    help='--pols batches: the 4 S field planes through one stage-1 / stage-2 launch (0: S pairs of launches)')
     ap.add_argument('--pols', default='x',
                     help="polarisations of the dipole; more than one letter (e.g. xyz, the incoherent "
                          "emitter of nearfield.py:69-73) makes a step ONE batched synthesis pass + a "
@@ -348,7 +350,7 @@ def main():
         from metalens_amd.sweep import SourceSweep
         sw = SourceSweep(wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
                          lens['hexgridset'], x, x, ux, uy, ctx=ctx, precision=args.precision,
-                         method=args.method)
+                         method=args.method, stack_transforms=bool(args.stack))
         batch = [(0.0, 0.0, -lens['source_distance'], pol) for pol in args.pols]
         sw.run(batch)                 # priming pass; settles ties, checks the table bounds
         one_step = hp.step
@@ -520,7 +522,8 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': scaling,
         'vs_baseline': None,
-        'dtype': 'f64' if args.precision == 'f64' else 'f32 GEMMs (f64 near field and storage)',
+        'dtype': 'f64' if args.precision == 'f64' else
+        'f32 GEMMs (f64 near field and storage); tolerance 1e-4 of max|E| over the direction grid, NOT pointwise',
         'data': 'synthetic',
         'config': {'workload': what, 'aperture': side, 'farfield': u.size,
                    'rings': int(len(lens['lens_periphery_summary']['r_center_list'])),

@@ -221,7 +221,11 @@ int ml_farfield_set_method(ml_ctx *ctx, int method);
  * accumulate in fp32 on v_mfma_f32_16x16x4_f32 (twice the matrix rate); near-field synthesis,
  * phase reduction of the twiddle seeds, storage and the projection stay fp64.  Direction grids
  * that are not centre-symmetric (generic complex GEMM) are always computed in fp64.  The
- * setting belongs to the context and persists across ml_farfield_plan calls.               */
+ * setting belongs to the context and persists across ml_farfield_plan calls.
+ * NORMALISATION of the 1e-4: max |dE| <= 1e-4 max |E| over the direction grid (rounding of an
+ * N-term fp32 sum is absolute).  It is NOT a pointwise bound: a direction 1000 x dimmer than the peak
+ * carries up to ~1e-3 relative at 16384^2 (tests/test_gpu_parity.py POINTWISE_F32 holds the
+ * measured figure); dim side lobes that matter belong to ML_PRECISION_F64 (pointwise 2e-12).   */
 #define ML_PRECISION_F64 0
 #define ML_PRECISION_F32_GEMM 1
 int ml_farfield_set_precision(ml_ctx *ctx, int precision);
@@ -324,6 +328,12 @@ int ml_farfield_project_async(ml_ctx *ctx, double Z0);
 int ml_nearfield_batch_async(ml_ctx *ctx, const ml_nearfield_params *p, int n, const double *x_pts,
                              int nx, const double *y_pts, int ny);
 int ml_fields_select(ml_ctx *ctx, int set);
+/* The first n_sets resident field sets through ONE stage-1 launch (4 * n_sets planes stacked; the row
+ * transforms do not care whose rows they are) and one stage-2 launch each.  Afterwards ml_fields_select(m) also
+ * picks the radiation vectors that ml_farfield_project*, ml_farfield_download work on.  *done = 1 if
+ * the stacked launches ran; 0 (and nothing launched) when the plan is not a whole-aperture one-level
+ * FFT on both axes - the caller then transforms set by set with ml_farfield_transform_async.      */
+int ml_farfield_transform_batch_async(ml_ctx *ctx, int n_sets, int *done);
 int ml_nearfield_powers(ml_ctx *ctx, double *power, int n);
 /* Sums over the sources of a sweep, kept on the GPU: after ml_farfield_project[_async],
  *   P_sum (+)= weight * P                              (reset != 0 starts a new sum)

@@ -63,7 +63,7 @@ struct FftArgs {
     const cd *wk;      // [M]       W_N^(k_j): the Horner ratio of bin j
     const cd *pj;      // [M]       exp(+2 pi i c k_j / N): moves the origin to sample c
     const int *kbin;   // [M]       k_j reduced to [0, N)
-    double alpha[4];   // row r is scaled by alpha[r / alpha_rb]
+    double alpha[4];   // row r is scaled by alpha[(r / alpha_rb) % 4]  (a batch stacks several sets of 4 planes)
     int alpha_rb;
     int rows, chunk, accumulate;
 };
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         }
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-        const double al = a.alpha[row / a.alpha_rb];
+        const double al = a.alpha[(row / a.alpha_rb) & 3];
         if (few && pair) {
             // the two bins share their LDS operands
             cd xa, xb;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs
             __syncthreads();   // the next pass' stage 1 overwrites the buffer
         }
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-        const double al = a.alpha[row / a.alpha_rb];
+        const double al = a.alpha[(row / a.alpha_rb) & 3];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             // (with PAIR, acc[q + NB / 2] belongs to bin tid + NT q + 256 = tid + NT (q + NB / 2))
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void zfft_multi_kernel(const FftArgs a, int cp
         __syncthreads();
         if (live) {
             cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-            const double al = a.alpha[row / a.alpha_rb];
+            const double al = a.alpha[(row / a.alpha_rb) & 3];
             for (int o = tid; o < g.M; o += NT) {
                 cd x = zf::cmul(zf::stage3(g, a.kbin[o], a.wk[o], lds), a.pj[o]);
                 x.x *= al;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
         zf::scatter2(g, tid, v, lds);
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-        const double al = a.alpha[row / a.alpha_rb];
+        const double al = a.alpha[(row / a.alpha_rb) & 3];
         for (int o = threadIdx.x; o < g.M; o += T) {
             const int k = a.kbin[o];
             const cd w = a.wk[o];

@@ -24,6 +24,7 @@ import numpy as np
 from . import _lib, constants, packing, ties
 from .constants import nm
 from .grating import n_glass as tabulated_n_glass
+from .prepared import PreparedLens
 
 inf = float('inf')
 
@@ -106,6 +107,11 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
     c0 = constants.c0 if c0 is None else c0
     Z0 = constants.Z0 if Z0 is None else Z0
     wavelength_in_nm = int(round(wavelength / nm))
+    # a PreparedLens in place of the periphery summary (prepared.py): hashed and uploaded once
+    prepared = lens_periphery_summary if isinstance(lens_periphery_summary, PreparedLens) else None
+    if prepared is not None:
+        lens_periphery_summary = prepared.lens_periphery_summary
+        lens_center_summary, hexgridset = prepared.lens_center_summary, prepared.hexgridset
     S = lens_periphery_summary
     gc_list = S['gratingcollection_list']
     lens_max_r = S['r_max_list'][-1]
@@ -132,9 +138,13 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
         zero = np.zeros((xs.size, ys.size), dtype=complex)
         return zero, zero, zero, zero, x_pts, y_pts, 0, n_glass
 
-    ctx = ctx or _lib.default_context()
-    packing.upload_tables(ctx, gc_list, hexgridset, wavelength_in_nm)
-    packing.upload_layout(ctx, S, lens_center_summary)
+    if prepared is not None:
+        ctx = ctx or prepared.ctx
+        prepared.make_resident(ctx, wavelength_in_nm)
+    else:
+        ctx = ctx or _lib.default_context()
+        packing.upload_tables(ctx, gc_list, hexgridset, wavelength_in_nm)
+        packing.upload_layout(ctx, S, lens_center_summary)
     # the drop-in hands back (or leaves resident) the PLAIN fields: a HotPath that shared this
     # context may have left the synthesis writing exp(-i pi (i+j)) modulated ones
     _lib.check(ctx.lib.ml_nearfield_premodulate(ctx.handle, 0))

@@ -85,6 +85,30 @@ def test_big_equals_single(ma):
     assert abs(one[6] - big[6]) <= 1e-14 * abs(one[6])
 
 
+def test_prepared_lens_equals_plain_calls(ma):
+    """ma.PreparedLens in place of the periphery summary (hashed and uploaded once): bit-identical
+    results, for several sources, with another lens using the context in between, and through the
+    strip driver"""
+    a = np.load(golden_io.golden_path('nearfield_B_straddle_offaxis_y.npz'))
+    b = np.load(golden_io.golden_path('nearfield_A_default_grid.npz'))
+    args = case_args(a)
+    lens = ma.PreparedLens(args['lens_periphery_summary'], args['lens_center_summary'], args['hexgridset'],
+                           args['wavelength'])
+    pargs = dict(args, lens_periphery_summary=lens, lens_center_summary=None, hexgridset=None)
+    for pol, sx in (('x', 0.0), ('y', 3e-6), ('z', -2e-6)):
+        plain = ma.build_nearfield(**dict(args, source_pol=pol, source_x=sx))
+        other = ma.build_nearfield(**case_args(b))          # another lens takes the context
+        assert other[0].shape == (b['x_pts'].size, b['y_pts'].size)
+        got = ma.build_nearfield(**dict(pargs, source_pol=pol, source_x=sx))
+        for u, v in zip(plain[:4], got[:4]):
+            assert np.array_equal(u, v)
+        assert plain[6] == got[6] and plain[7] == got[7]
+    pargs.pop('dipole_moment')
+    big = ma.build_nearfield_big(pts_at_a_time=48 * 7, **dict(pargs, source_pol='z', source_x=-2e-6))
+    for u, v in zip(plain[:4], big[:4]):
+        assert np.array_equal(u, v)
+
+
 def test_empty_window_shortcut(ma):
     case = np.load(golden_io.golden_path('nearfield_B_edge_onaxis_x.npz'))
     far = case['x_pts'] + 400e-6
@@ -449,6 +473,41 @@ def test_source_sweep_incoherent_sum_vs_oracle(ma):
     assert 0 < got['cone_efficiency'] < got['efficiency'] < 10
 
 
+@pytest.mark.parametrize('side,M,diameter', [(512, 64, 3e-4), (2048, 256, 1e-3)])
+def test_stacked_batch_transforms_equal_per_member_ones(ma, side, M, diameter):
+    """f4(a): the 4 S planes of a polarisation batch through ONE stage-1 and ONE stage-2 launch
+    (ml_farfield_transform_batch_async) against S separate transforms: the same kernels on the same
+    rows, so every map, total and sum is bit-identical; the 3-member, 1-member and 2-member groups
+    of one sweep, on the lattice grid of the bench workload (both axes pruned FFTs)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from metalens_amd import _lib
+    wl = 580e-9
+    lens, x, u = bench.build_workload(side, M, diameter, 0.5, wl, 1.0)
+    f = lens['source_distance']
+    sources = [(0.0, 0.0, -f, 'x'), (0.0, 0.0, -f, 'y'), (0.0, 0.0, -f, 'z'),
+               (1.0e-6, -0.5e-6, -1.02 * f, 'y'),
+               (-2.0e-6, 0.0, -f, 'z'), (-2.0e-6, 0.0, -f, 'x')]
+    weights = np.array([1.0, 0.5, 2.0, 1.0, 1.0, 3.0])
+    out = {}
+    for stack in (True, False):
+        sw = ma.SourceSweep(wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                            lens['hexgridset'], x, x, u, u, stack_transforms=stack)
+        out[stack] = sw.run(sources, weights=weights, cone=0.05, keep_each=True)
+        assert sw.ctx.plan_kernels() == ('fft', 'fft')
+    ctx = _lib.default_context()
+    done = _lib.c_int(0)
+    _lib.check(ctx.lib.ml_farfield_transform_batch_async(ctx.handle, 2, _lib.byref(done)))
+    assert done.value == 1                                 # this plan does take the stacked launches
+    a, b = out[True], out[False]
+    for key in ('P_each', 'P_sum', 'total_P', 'cone_P', 'power_in'):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), key
+    assert np.isfinite(a['total_P']).all() and (a['total_P'] > 0).all()
+
+
 def test_polarisation_batch_equals_single_sources(ma):
     """the batched synthesis (one pass, three resident field sets) against three single-source
     calls of the drop-in function, fields and incident power, dipoles and plane waves"""
@@ -636,13 +695,13 @@ def test_f32_gemm_hot_path_vs_f64(ma, f32_gemm):
         assert 1e-10 < err <= TOL_F32, (key, err)
 
 
-def _run_bench(extra, env, timeout=600, aperture=512):
+def _run_bench(extra, env, timeout=600, aperture=512, farfield=64, diameter='3e-4'):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', str(aperture),
-           '--farfield', '64',
-           '--diameter', '3e-4', '--na', '0.5', '--steps', '2', '--warmup', '1', '--blocks', '1',
+           '--farfield', str(farfield),
+           '--diameter', diameter, '--na', '0.5', '--steps', '2', '--warmup', '1', '--blocks', '1',
            '--cpu-rows', '0', '--cpu-fft-side', '0', '--scaling', 'strong'] + extra
     return subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE,
                             stderr=subprocess.PIPE, text=True)
@@ -750,6 +809,14 @@ def test_wavelength_replicas(tmp_path):
         assert round(rep['wavelength_nm']) == nm_ and rep['n_glass'] == ng
         assert 0 <= d['rel_err']['nearfield_vs_oracle'] < 1e-12 and 0 <= d['rel_err']['farfield_E_vs_oracle'] < 1e-12
         assert d['config']['parallelism'].startswith('replicas only')
+    # one wavelength at the north-star aperture (4096^2 -> 512^2 on the 1 mm lens)
+    p = _run_bench(extra + ['--replica-index', '1'], {}, aperture=4096, farfield=512, diameter='1e-3')
+    out, err = p.communicate(timeout=900)
+    assert p.returncode == 0, err[-2000:]
+    d = json.loads([l for l in out.splitlines() if l.strip()][-1])
+    (rep,) = d['config']['replicas']
+    assert round(rep['wavelength_nm']) == 532 and rep['n_glass'] == 1.4607 and d['config']['aperture'] == 4096
+    assert 0 <= d['rel_err']['nearfield_vs_oracle'] < 1e-12 and 0 <= d['rel_err']['farfield_E_vs_oracle'] < 1e-12
     env = dict(ML_COMM_BACKEND='file', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611')
     procs = [_run_bench(['--gpus', '2'] + extra, dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=512)
              for r in range(2)]
@@ -1329,6 +1396,27 @@ def test_random_windows_sweep(ma, seed):
     assert worst < TOL
 
 
+def _record(name, **values):
+    """measured parity figures of a GPU run, one JSON line each, for profiles/ (ML_RECORD_PARITY=file)"""
+    path = os.environ.get('ML_RECORD_PARITY')
+    if path:
+        import json
+        with open(path, 'a') as f:
+            f.write(json.dumps(dict(name=name, **values)) + '\n')
+
+
+# |dE| / |E| over the sampled directions above 1e-3 of the peak, GPU against the fp64 oracle:
+#   fp64 paths: 2e-12.  The oracle's OWN distance from a long-double evaluation of the same sums, by
+#     the same measure at 4096^2, is 6.0e-13 for a_phi and 2.6e-14 for a_theta
+#     (tools/oracle_longdouble.py, profiles/r04_oracle_longdouble.json): rounding of an N^2-term fp64
+#     sum is ~1e-15 of max|E| whoever takes it, seen up to 1000 x magnified in the dimmest of these
+#     directions - the GPU measures 7.1e-13 against the oracle at 4096^2 and 1.6e-12 at 2048^2
+#   fp32 GEMM mode: twice the value measured at 16384^2 (profiles/r04_parity_measured.jsonl); the
+#     1e-4 of BASELINE.json is met relative to max|E| - the normalisation the bench line names
+POINTWISE_F64 = 2e-12
+POINTWISE_F32 = 1.5e-3   # measured 7.4e-4 (a_phi, 16384^2)
+
+
 def pointwise_rel_err(got, ref, floor=1e-3):
     """max |d| / |ref| over the points where |ref| > floor * max|ref| (the far-field tolerance of
     this suite is otherwise normalised by max|E|, which says little about the dim directions)"""
@@ -1337,6 +1425,7 @@ def pointwise_rel_err(got, ref, floor=1e-3):
 
 
 @pytest.mark.parametrize('side,M,diameter,na,precision,method', [
+    (2048, 256, 1e-3, 0.5, 'f64', 'auto'),        # BASELINE configs[0]: the reference's own CPU-runnable case
     (4096, 512, 1e-3, 0.5, 'f64', 'auto'),        # north-star size; both axes run as pruned FFTs
     (4096, 512, 1e-3, 0.5, 'f64', 'gemm'),        # the same through the folded fp64 GEMMs
     (8192, 512, 2e-3, 0.94, 'f64', 'auto'),       # BASELINE configs[2]'s problem on one GPU
@@ -1393,7 +1482,10 @@ def test_north_star_size_properties(ma, side, M, diameter, na, precision, method
             assert np.abs(got - ref[key]).max() <= tol * np.abs(ref[key]).max()
             # pointwise |dE| / |E| where |E| > 1e-3 max|E|: rounding of an N^2-term sum is absolute
             # (~1e-15 max|E|), so the dimmest of these directions carries ~1e-12 relative
-            assert pointwise_rel_err(got, ref[key]) <= 10 * tol
+            pw = pointwise_rel_err(got, ref[key])
+            _record('north_star_pointwise', side=side, precision=precision, method=method, key=key,
+                    pointwise=float(pw), rel_to_max=float(np.abs(got - ref[key]).max() / np.abs(ref[key]).max()))
+            assert pw <= (POINTWISE_F64 if precision == 'f64' else POINTWISE_F32)
         if precision == 'f32':   # really the fp32 arithmetic: above fp64 round-off
             assert np.abs(r1['a_theta'][np.ix_(sel, sel)] - ref['a_theta']).max() > 1e-10 * np.abs(ref['a_theta']).max()
         del F, ref, want

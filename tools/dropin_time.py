@@ -30,3 +30,17 @@ for k in range(3):
 ok = ~np.isnan(P[0])
 print('resident vs host-FFT drop-in: max |dP| / max P = %.2e, total_P rel diff %.2e'
       % (np.abs(P2[0][ok] - P[0][ok]).max() / np.nanmax(P[0]), abs(P2[1] - P[1]) / abs(P[1])))
+# the same with the lens prepared once (ma.PreparedLens): no content hash per call
+t = time.perf_counter()
+prepared = ma.PreparedLens(lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'], 580e-9)
+print('PreparedLens(...) (hash + upload when new): %.2f ms' % ((time.perf_counter() - t) * 1e3))
+pargs = (src[0], src[1], src[2], src[3], 580e-9, prepared, None, None)
+for name, a in (('plain objects ', args), ('PreparedLens  ', pargs)):
+    best = []
+    for k in range(20):
+        t = time.perf_counter()
+        o = ma.build_nearfield(*a, x_pts=x, y_pts=x, download=False)
+        best.append((time.perf_counter() - t) * 1e3)
+    print('build_nearfield(download=False) 2048^2, %s: median %.2f ms, min %.2f ms (20 calls)'
+          % (name, float(np.median(best)), min(best)))
+assert o[6] == out2[6]
