@@ -254,8 +254,6 @@ def main():
     ap.add_argument('--pair-list', type=int, default=0,
                     help='> 0: that many arbitrary directions (ux[d], uy[d]) inside the NA cone '
                          'instead of the M x M tensor grid')
-    ap.add_argument('--stack', type=int, default=1,
-                    help='--pols batches: the 4 S field planes through one stage-1 / stage-2 launch (0: S pairs of launches)')
     ap.add_argument('--pols', default='x',
                     help="polarisations of the dipole; more than one letter (e.g. xyz, the incoherent "
                          "emitter of nearfield.py:69-73) makes a step ONE batched synthesis pass + a "
@@ -350,7 +348,7 @@ def main():
         from metalens_amd.sweep import SourceSweep
         sw = SourceSweep(wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
                          lens['hexgridset'], x, x, ux, uy, ctx=ctx, precision=args.precision,
-                         method=args.method, stack_transforms=bool(args.stack))
+                         method=args.method)
         batch = [(0.0, 0.0, -lens['source_distance'], pol) for pol in args.pols]
         sw.run(batch)                 # priming pass; settles ties, checks the table bounds
         one_step = hp.step

@@ -328,12 +328,6 @@ int ml_farfield_project_async(ml_ctx *ctx, double Z0);
 int ml_nearfield_batch_async(ml_ctx *ctx, const ml_nearfield_params *p, int n, const double *x_pts,
                              int nx, const double *y_pts, int ny);
 int ml_fields_select(ml_ctx *ctx, int set);
-/* The first n_sets resident field sets through ONE stage-1 launch (4 * n_sets planes stacked; the row
- * transforms do not care whose rows they are) and one stage-2 launch each.  Afterwards ml_fields_select(m) also
- * picks the radiation vectors that ml_farfield_project*, ml_farfield_download work on.  *done = 1 if
- * the stacked launches ran; 0 (and nothing launched) when the plan is not a whole-aperture one-level
- * FFT on both axes - the caller then transforms set by set with ml_farfield_transform_async.      */
-int ml_farfield_transform_batch_async(ml_ctx *ctx, int n_sets, int *done);
 int ml_nearfield_powers(ml_ctx *ctx, double *power, int n);
 /* Sums over the sources of a sweep, kept on the GPU: after ml_farfield_project[_async],
  *   P_sum (+)= weight * P                              (reset != 0 starts a new sum)

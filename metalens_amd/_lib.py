@@ -44,7 +44,7 @@ SYMBOLS = (
     'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_farfield_total_power', 'ml_host_alloc', 'ml_host_free',
-    'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather', 'ml_farfield_transform_batch_async',
+    'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather',
 )
 
 
@@ -105,7 +105,6 @@ def load():
     lib.ml_farfield_accumulate.argtypes = [c_void_p, c_double, c_double, c_double, c_double, c_int, c_int]
     lib.ml_farfield_sums.argtypes = [c_void_p, _dp, _dp, _dp, c_int]
     lib.ml_farfield_total_power.argtypes = [c_void_p, _dp]
-    lib.ml_farfield_transform_batch_async.argtypes = [c_void_p, c_int, POINTER(c_int)]
     lib.ml_host_alloc.argtypes = [ctypes.c_uint64, POINTER(c_void_p)]
     lib.ml_host_free.argtypes = [c_void_p]
     lib.ml_nearfield_result.argtypes = [c_void_p, _dp, POINTER(BoundViolation), c_int,

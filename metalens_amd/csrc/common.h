@@ -241,10 +241,6 @@ struct FarfieldPlan {
     int amp_slot = 0;
     double *amp_ptr() const { return reinterpret_cast<double *>(amplitudes.p) + (size_t)amp_slot * 4 * mx * (pair_list ? 1 : my); }
     bool have_vectors = false;
-    // > 0: the last transform was ml_farfield_transform_batch_async over this many field sets; the
-    // vectors of set m sit in block (batch - 1 - m) of `vectors` (the stacked stage 2 writes plane p
-    // of the batch to slot 4 * batch - 1 - p, as one set's plane f goes to slot 3 - f)
-    int batch = 0;
     bool tw_x_ready = false;  // complex x twiddles built for the current plan
     int stage1_splits = 1;   // split-K slabs currently held in `stage1`
     // folded (even/odd) stage 1, see zfold.hip; used when uy is centre-symmetric

@@ -732,7 +732,6 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
         memcmp(pl.h_ux.data(), ux, mx * sizeof(double)) == 0 &&
         memcmp(pl.h_uy.data(), uy, my * sizeof(double)) == 0) {
         pl.have_vectors = false;
-        pl.batch = 0;
         pl.amplitudes_reduced = false;
         return ML_OK;
     }
@@ -740,7 +739,6 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     pl.ready = false;
     ++pl.serial;
     pl.have_vectors = false;
-    pl.batch = 0;
     pl.amplitudes_reduced = false;
     pl.nx_total = nx_total;
     pl.ny = ny;
@@ -879,7 +877,25 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         if (forced_split > 0) want_split1 = forced_split;
         pl.stage1_splits = zfold_splits(pl.fold_T, want_split1);
     }
-    ML_TRY(pl.stage1.reserve((size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
+#ifndef ML_STAGE1_TRANSPOSED
+#define ML_STAGE1_TRANSPOSED 1
+#endif
+    // Both axes one-level FFTs on a large aperture: stage 1 writes its result TRANSPOSED, G[f][b][n1]
+    // with rows of nxl + 8 (a 128-byte skew: consecutive bins of a row transform land in different
+    // L2 channels), and stage 2 streams contiguous rows with non-temporal loads like stage 1 does,
+    // instead of gathering 16-byte pieces 8 KB apart with loads that keep G in the caches.  What this
+    // buys is mostly NOT in the transform (4096^2 -> 512^2: stage 1 0.179 -> 0.207 ms for its 16-byte
+    // scattered stores - neighbouring rows meet in the XCD's L2 -, stage 2 0.057 -> 0.037) but in the
+    // NEXT synthesis, 0.265 -> 0.229 ms: a G that is read once and dropped no longer pushes the
+    // geometry records (134 MB at 4096^2, + 134 MB of G > the 256 MB memory-side cache) out between
+    // steps.  Small apertures, where everything fits anyway, keep the row-major G (2048^2 -> 256^2:
+    // 0.167 against 0.178 ms per step).
+    const bool g_transposed = ML_STAGE1_TRANSPOSED && pl.fft_y.ok && pl.fft_x.ok && !pl.pair_list &&
+                              pl.fft_y.split == 1 && pl.fft_x.split == 1 && sh.kind != 2 &&
+                              (size_t)nxl * ny * 8 + (size_t)4 * nxl * my * 16 > (size_t)200 << 20;
+    const int64_t g_ld = nxl + 8;
+    ML_TRY(pl.stage1.reserve(g_transposed ? (size_t)4 * my * g_ld * 2 * sizeof(double)
+                                          : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
     static const long fold2_min_tiles = diag_int("ML_FOLD2_MIN_TILES", 32);
@@ -939,6 +955,12 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.out_s1 = 0;
             c.out_s2 = my;
             c.out_es = 1;
+            if (g_transposed) {   // row (f, n1), bin b -> G[f][b][n1]
+                c.out_rb = nxl;
+                c.out_s1 = (int64_t)my * g_ld;
+                c.out_s2 = 1;
+                c.out_es = g_ld;
+            }
             c.tw1 = pl.fft_tw1.as<double>();
             c.wk = pl.fft_y.wk.as<double>();
             c.pj = pl.fft_y.pj.as<double>();
@@ -1057,6 +1079,11 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         c.in_s1 = (int64_t)nxl * my;
         c.in_s2 = 1;
         c.in_es = my;
+        if (g_transposed) {
+            c.in_s1 = (int64_t)my * g_ld;
+            c.in_s2 = g_ld;
+            c.in_es = 1;
+        }
         if (mirrored) {
             c.a0 = row0;
             c.h0 = nxl / 2;
@@ -1124,112 +1151,6 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     }
     pl.have_vectors = true;
     pl.amplitudes_reduced = false;
-    pl.batch = 0;
-    return ML_OK;
-}
-
-// The 4 * S field planes of a polarisation batch through ONE stage-1 launch (the FFT kernel takes
-// rows as they come: a batch is 4 * S * nx rows) and S stage-2 launches that leave every member's
-// radiation vectors resident: the tails of S - 1 stage-1 launches go.  Whole apertures whose two axes run as one-level
-// pruned FFTs; *done = 0 (nothing launched) for any other plan - the caller transforms set by set.
-int ml_farfield_transform_batch_async(ml_ctx *ctx, int n_sets, int *done) {
-    ML_REQUIRE(ctx && done, "NULL argument");
-    *done = 0;
-    FarfieldPlan &pl = ctx->plan;
-    if (!pl.ready) {
-        set_error("ml_farfield_plan has not been called");
-        return ML_ESTATE;
-    }
-    ML_REQUIRE(n_sets >= 1 && n_sets <= ctx->n_sets, "%d field sets asked for, %d resident", n_sets, ctx->n_sets);
-    if (!(pl.fft_y.ok && pl.fft_x.ok) || pl.pair_list || pl.fft_y.split > 1 || pl.fft_x.split > 1 ||
-        ctx->nx != pl.nx_total || ctx->ny != pl.ny || ctx->fields_premod_serial >= 0)
-        return ML_OK;
-    ML_HIP(hipSetDevice(ctx->device));
-    const int nxl = ctx->nx, ny = pl.ny, mx = pl.mx, my = pl.my, S = n_sets;
-    pl.unfold_pending = false;
-    pl.stage1_splits = 1;
-    ML_TRY(pl.stage1.reserve((size_t)S * 4 * nxl * my * 2 * sizeof(double)));
-    ML_TRY(pl.vectors.reserve((size_t)S * 4 * mx * my * 2 * sizeof(double)));
-    {
-        ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
-        ZfftCall c;
-        c.passes = pl.fft_y.passes;
-        c.N_eff = pl.fft_y.N_eff;
-        c.n_valid = ny;
-        c.M = my;
-        c.j0 = pl.fft_y.j0;
-        c.pad1 = pl.fft_y.pad1;
-        c.pad2 = pl.fft_y.pad2;
-        c.in = reinterpret_cast<double *>(ctx->fields.p);   // set 0; the sets follow one another
-        c.rows = 4 * S * nxl;
-        c.in_rb = c.rows;
-        c.in_s1 = 0;
-        c.in_s2 = ny;
-        c.in_es = 1;
-        c.a0 = 0;
-        c.h0 = ny;
-        c.a1 = c.h1 = 0;
-        c.row_first = ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr;
-        c.rf_mod = nxl;
-        c.out = pl.stage1.as<double>();
-        c.out_rb = c.rows;
-        c.out_s1 = 0;
-        c.out_s2 = my;
-        c.out_es = 1;
-        c.tw1 = pl.fft_tw1.as<double>();
-        c.wk = pl.fft_y.wk.as<double>();
-        c.pj = pl.fft_y.pj.as<double>();
-        c.kbin = pl.fft_y.kbin.as<int>();
-        for (int k = 0; k < 4; ++k) c.alpha[k] = 1.0;
-        c.alpha_rb = c.rows;
-        c.accumulate = 0;
-        ML_TRY(zfft_run(ctx->stream, c));
-    }
-    {
-        ProfScope scope(ctx, ML_K_ZGEMM_STAGE2);
-        const double dA = pl.dxp * pl.dyp;
-        const double alpha[4] = {-dA, dA, dA, -dA};   // Nx,Ny,Lx,Ly = -Hy, Hx, Ey, -Ex (x dA)
-        ZfftCall c;
-        c.passes = pl.fft_x.passes;
-        c.N_eff = pl.fft_x.N_eff;
-        c.n_valid = pl.nx_total;
-        c.M = mx;
-        c.j0 = pl.fft_x.j0;
-        c.pad1 = pl.fft_x.pad1;
-        c.pad2 = pl.fft_x.pad2;
-        c.rows = 4 * my;
-        c.in_rb = my;
-        c.in_s1 = (int64_t)nxl * my;
-        c.in_s2 = 1;
-        c.in_es = my;
-        c.a0 = 0;
-        c.h0 = nxl;
-        c.a1 = c.h1 = 0;
-        c.row_first = nullptr;
-        c.rf_mod = 1;
-        c.out_rb = my;
-        c.out_s1 = -(int64_t)mx * my;
-        c.out_s2 = 1;
-        c.out_es = my;
-        c.tw1 = pl.fft_tw1.as<double>();
-        c.wk = pl.fft_x.wk.as<double>();
-        c.pj = pl.fft_x.pj.as<double>();
-        c.kbin = pl.fft_x.kbin.as<int>();
-        for (int k = 0; k < 4; ++k) c.alpha[k] = alpha[k];
-        c.alpha_rb = my;
-        c.accumulate = 0;
-        // (stacking stage 2 as well - 4 S my columns in one launch - measured 45 % SLOWER than S
-        // launches at 4096^2 -> 512^2, S = 3: 0.253 against 0.174 ms; stage 1 gains 4 % stacked)
-        for (int m = 0; m < S; ++m) {
-            c.in = pl.stage1.as<double>() + (size_t)m * 4 * nxl * my * 2;
-            c.out = pl.vectors.as<double>() + (size_t)(4 * (S - 1 - m) + 3) * mx * my * 2;
-            ML_TRY(zfft_run(ctx->stream, c));
-        }
-    }
-    pl.have_vectors = true;
-    pl.amplitudes_reduced = false;
-    pl.batch = S;
-    *done = 1;
     return ML_OK;
 }
 
@@ -1279,15 +1200,6 @@ int ml_farfield_transform_interleaved_async(ml_ctx *ctx, int block, int n_ranks,
     return transform_impl(ctx, sh, accumulate);
 }
 
-// radiation vectors the projection / download work on: the only set, or (after a batch transform)
-// those of the selected field set
-static double2 *vec_ptr(ml_ctx *ctx) {
-    FarfieldPlan &pl = ctx->plan;
-    const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);
-    const int block = pl.batch > 0 ? pl.batch - 1 - std::min(ctx->field_set, pl.batch - 1) : 0;
-    return pl.vectors.as<double2>() + (size_t)block * 4 * n;
-}
-
 static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream = nullptr) {
     ML_REQUIRE(ctx, "ctx is NULL");
     FarfieldPlan &pl = ctx->plan;
@@ -1299,7 +1211,7 @@ static int project_stage(ml_ctx *ctx, double Z0, int stage, hipStream_t stream =
     const int mx = pl.mx, my = pl.pair_list ? 1 : pl.my;
     const size_t n = (size_t)mx * my;
     ProjArgs a;
-    const double2 *v = vec_ptr(ctx);
+    const double2 *v = pl.vectors.as<double2>();
     a.Nx = v;
     a.Ny = v + n;
     a.Lx = v + 2 * n;
@@ -1667,7 +1579,7 @@ int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double
     double *dst[4] = {Nx, Ny, Lx, Ly};
     for (int k = 0; k < 4; ++k)
         if (dst[k])
-            ML_HIP(hipMemcpyAsync(dst[k], reinterpret_cast<double *>(vec_ptr(ctx)) + k * n * 2,
+            ML_HIP(hipMemcpyAsync(dst[k], pl.vectors.as<double>() + k * n * 2,
                                   n * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ML_HIP(hipStreamSynchronize(ctx->stream));
     return ML_OK;

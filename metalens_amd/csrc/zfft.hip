@@ -63,7 +63,7 @@ struct FftArgs {
     const cd *wk;      // [M]       W_N^(k_j): the Horner ratio of bin j
     const cd *pj;      // [M]       exp(+2 pi i c k_j / N): moves the origin to sample c
     const int *kbin;   // [M]       k_j reduced to [0, N)
-    double alpha[4];   // row r is scaled by alpha[(r / alpha_rb) % 4]  (a batch stacks several sets of 4 planes)
+    double alpha[4];   // row r is scaled by alpha[r / alpha_rb]
     int alpha_rb;
     int rows, chunk, accumulate;
 };
@@ -79,6 +79,9 @@ __device__ __forceinline__ zf::Geo geo_of(const FftArgs &a) {
 // STREAM: the rows of the aperture are read once per transform (non-temporal: they must not push
 // the next synthesis' tables and records out of the caches); the column pass re-uses every line
 // it touches across neighbouring workgroups and reads normally
+#ifndef ML_NT_PASS2
+#define ML_NT_PASS2 0
+#endif
 template <int R3T, bool STREAM>
 __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int row, int tid, cd *v) {
     const int NT = 16 * g.R3;
@@ -108,6 +111,14 @@ __device__ __forceinline__ void load_row(const FftArgs &a, const zf::Geo &g, int
 // PASS (1: rows of the aperture, 2: columns of stage 1's result) only names the instantiation, so
 // that a profile lists the two passes separately.
 // IP: exchange 2 in place (zfft_core.h Geo::ip): one barrier fewer per row.
+// row of the idx-th turn of the workgroups on XCD `xcd` (-1: past the end).  (Visiting the four field
+// planes newest rows first - the tail of the synthesis might still be in the memory-side cache - measured
+// 3 % slower than this XCD-blocked ascending order: the field stores are non-temporal.)
+__device__ __forceinline__ int row_of_turn(const FftArgs &a, int xcd, int idx) {
+    const int row = xcd * a.chunk + idx;
+    return idx < a.chunk && row < a.rows ? row : -1;
+}
+
 template <int R3T, int NTMAX, int MINW, int PASS, bool IP>
 __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     extern __shared__ __align__(16) unsigned char zfft_lds_raw[];
@@ -144,13 +155,13 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
     __syncthreads();
     const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
     int idx = blockIdx.x >> 3;
-    int row = xcd * a.chunk + idx;   // block-uniform
+    int row = row_of_turn(a, xcd, idx);   // block-uniform
     cd v[16], nx[16];
-    if (idx < a.chunk && row < a.rows) load_row<R3T, PASS == 1>(a, g, row, tid, v);
-    while (idx < a.chunk && row < a.rows) {
-        const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
-        const bool more = idx_n < a.chunk && row_n < a.rows;
-        if (more) load_row<R3T, PASS == 1>(a, g, row_n, tid, nx);
+    if (row >= 0) load_row<R3T, PASS == 1 || ML_NT_PASS2>(a, g, row, tid, v);
+    while (row >= 0) {
+        const int idx_n = idx + step, row_n = row_of_turn(a, xcd, idx_n);
+        const bool more = row_n >= 0;
+        if (more) load_row<R3T, PASS == 1 || ML_NT_PASS2>(a, g, row_n, tid, nx);
         {
             cd ta[4];
             ta[0] = tb[0];
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(NTMAX, MINW) void zfft_kernel(const FftArgs a) {
         }
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-        const double al = a.alpha[(row / a.alpha_rb) & 3];
+        const double al = a.alpha[row / a.alpha_rb];
         if (few && pair) {
             // the two bins share their LDS operands
             cd xa, xb;
@@ -268,18 +279,18 @@ __global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs
     __syncthreads();
     const int xcd = blockIdx.x & 7, step = gridDim.x >> 3;
     int idx = blockIdx.x >> 3;
-    int row = xcd * a.chunk + idx;   // block-uniform
+    int row = row_of_turn(a, xcd, idx);   // block-uniform
     cd v[16];
     // samples of this thread in pass p: base(p) + 16 R3 n2
     auto base_of = [&](int p) { return p * R3P + n0 + (R3P * P) * n1; };
-    while (idx < a.chunk && row < a.rows) {
-        const int idx_n = idx + step, row_n = xcd * a.chunk + idx_n;
+    while (row >= 0) {
+        const int idx_n = idx + step, row_n = row_of_turn(a, xcd, idx_n);
         cd acc[NB];
 #pragma unroll   // (left rolled the two-pass form lost its gain: stage 1 0.80 against 0.71 ms at 8192^2)
         for (int p = P - 1; p >= 0; --p) {
             // (no register prefetch of the next pass: with four workgroups on a CU another
             // workgroup's arithmetic covers these loads, and 64 registers more would spill)
-            load_row<0, PASS == 1>(a, gf, row, base_of(p), v);
+            load_row<0, PASS == 1 || ML_NT_PASS2>(a, gf, row, base_of(p), v);
             {
                 cd ta[4];
                 ta[0] = tb[0];
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(16 * R3P, MINW) void zfft_pass_kernel(const FftArgs
             __syncthreads();   // the next pass' stage 1 overwrites the buffer
         }
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-        const double al = a.alpha[(row / a.alpha_rb) & 3];
+        const double al = a.alpha[row / a.alpha_rb];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             // (with PAIR, acc[q + NB / 2] belongs to bin tid + NT q + 256 = tid + NT (q + NB / 2))
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void zfft_multi_kernel(const FftArgs a, int cp
         const bool live = row < a.rows;
         cd v[16];
         if (live) {
-            load_row<0, PASS == 1>(a, g, row, tid, v);
+            load_row<0, PASS == 1 || ML_NT_PASS2>(a, g, row, tid, v);
         } else {
 #pragma unroll
             for (int n2 = 0; n2 < 16; ++n2) v[n2] = zf::mk(0.0, 0.0);
@@ -394,7 +405,7 @@ __global__ __launch_bounds__(256) void zfft_multi_kernel(const FftArgs a, int cp
         __syncthreads();
         if (live) {
             cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-            const double al = a.alpha[(row / a.alpha_rb) & 3];
+            const double al = a.alpha[row / a.alpha_rb];
             for (int o = tid; o < g.M; o += NT) {
                 cd x = zf::cmul(zf::stage3(g, a.kbin[o], a.wk[o], lds), a.pj[o]);
                 x.x *= al;
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
         zf::scatter2(g, tid, v, lds);
         __syncthreads();
         cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
-        const double al = a.alpha[(row / a.alpha_rb) & 3];
+        const double al = a.alpha[row / a.alpha_rb];
         for (int o = threadIdx.x; o < g.M; o += T) {
             const int k = a.kbin[o];
             const cd w = a.wk[o];

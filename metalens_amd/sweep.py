@@ -32,10 +32,8 @@ MAX_SLOTS = 4096       # ML_MAX_SWEEP_SLOTS
 class SourceSweep:
     def __init__(self, wavelength, lens_periphery_summary, lens_center_summary, hexgridset,
                  x_pts, y_pts, ux, uy, dipole_moment=1e-30, c0=None, Z0=None, ctx=None,
-                 precision=None, method=None, stack_transforms=True):
+                 precision=None, method=None):
         self.ctx = ctx or _lib.default_context()
-        # a polarisation batch's 4 S planes through one stage-1 / stage-2 launch (A/B: False)
-        self.stack_transforms = stack_transforms
         self.ctx.set_precision(precision or 'f64')
         self.ctx.set_method(method or 'auto')
         self.c0 = constants.c0 if c0 is None else c0
@@ -108,15 +106,14 @@ class SourceSweep:
                                          self.dipole_moment, self.c0, self.Z0)
         _lib.check(lib.ml_nearfield_batch_async(ctx.handle, params, n, _lib.dptr(self.x), self.x.size,
                                                 _lib.dptr(self.y), self.y.size))
-        # the whole batch through one stage-1 and one stage-2 launch where the plan allows it
-        stacked = _lib.c_int(0)
-        if n > 1 and self.stack_transforms:
-            _lib.check(lib.ml_farfield_transform_batch_async(ctx.handle, n, _lib.byref(stacked)))
-        self._stacked = bool(stacked.value)
+        # member by member, each transform's second stage reading what its first stage has just
+        # written (134 MB at 4096^2 -> 512^2: it is still in the 256 MB memory-side cache).  Stacking
+        # the members' 4 S planes through one stage-1 launch was measured and taken out again: stage 1
+        # 0.535 -> 0.512 ms for x+y+z, but stage 2 then reads a 402 MB intermediate from HBM,
+        # 0.171 -> 0.268 ms (experiment log of round 4)
         for m, (k, pol) in enumerate(group['members']):
             _lib.check(lib.ml_fields_select(ctx.handle, m))
-            if not stacked.value:
-                _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
+            _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
             _lib.check(lib.ml_farfield_project_async(ctx.handle, self.Z0))
             _lib.check(lib.ml_farfield_accumulate(ctx.handle, float(weights[k]), cone[0], cone[1],
                                                   cone[2], k, int(k == 0)))
@@ -179,8 +176,7 @@ class SourceSweep:
             if keep_each:   # the projections of this group's members, one at a time (tests)
                 for m, (k, pol) in enumerate(g['members']):
                     _lib.check(lib.ml_fields_select(ctx.handle, m))
-                    if not self._stacked:   # (a stacked batch left every member's vectors resident)
-                        _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
+                    _lib.check(lib.ml_farfield_transform_async(ctx.handle, 0, 0))
                     P = np.empty((self.ux.size, self.uy.size))
                     _lib.check(lib.ml_farfield_project(ctx.handle, self.Z0, _lib.dptr(P), None, None))
                     each[k] = P

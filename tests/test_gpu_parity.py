@@ -473,41 +473,6 @@ def test_source_sweep_incoherent_sum_vs_oracle(ma):
     assert 0 < got['cone_efficiency'] < got['efficiency'] < 10
 
 
-@pytest.mark.parametrize('side,M,diameter', [(512, 64, 3e-4), (2048, 256, 1e-3)])
-def test_stacked_batch_transforms_equal_per_member_ones(ma, side, M, diameter):
-    """f4(a): the 4 S planes of a polarisation batch through ONE stage-1 and ONE stage-2 launch
-    (ml_farfield_transform_batch_async) against S separate transforms: the same kernels on the same
-    rows, so every map, total and sum is bit-identical; the 3-member, 1-member and 2-member groups
-    of one sweep, on the lattice grid of the bench workload (both axes pruned FFTs)"""
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if root not in sys.path:
-        sys.path.insert(0, root)
-    import bench
-    from metalens_amd import _lib
-    wl = 580e-9
-    lens, x, u = bench.build_workload(side, M, diameter, 0.5, wl, 1.0)
-    f = lens['source_distance']
-    sources = [(0.0, 0.0, -f, 'x'), (0.0, 0.0, -f, 'y'), (0.0, 0.0, -f, 'z'),
-               (1.0e-6, -0.5e-6, -1.02 * f, 'y'),
-               (-2.0e-6, 0.0, -f, 'z'), (-2.0e-6, 0.0, -f, 'x')]
-    weights = np.array([1.0, 0.5, 2.0, 1.0, 1.0, 3.0])
-    out = {}
-    for stack in (True, False):
-        sw = ma.SourceSweep(wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
-                            lens['hexgridset'], x, x, u, u, stack_transforms=stack)
-        out[stack] = sw.run(sources, weights=weights, cone=0.05, keep_each=True)
-        assert sw.ctx.plan_kernels() == ('fft', 'fft')
-    ctx = _lib.default_context()
-    done = _lib.c_int(0)
-    _lib.check(ctx.lib.ml_farfield_transform_batch_async(ctx.handle, 2, _lib.byref(done)))
-    assert done.value == 1                                 # this plan does take the stacked launches
-    a, b = out[True], out[False]
-    for key in ('P_each', 'P_sum', 'total_P', 'cone_P', 'power_in'):
-        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key]), equal_nan=True), key
-    assert np.isfinite(a['total_P']).all() and (a['total_P'] > 0).all()
-
-
 def test_polarisation_batch_equals_single_sources(ma):
     """the batched synthesis (one pass, three resident field sets) against three single-source
     calls of the drop-in function, fields and incident power, dipoles and plane waves"""
