@@ -441,6 +441,7 @@ struct ZfftCall {
     double alpha[4];
     int alpha_rb, rows, accumulate;
     int passes = 0;                  // > 1: the pass-split kernel (0: the library's default)
+    int second = 0;                  // contiguous rows that are the SECOND stage (of a transposed stage-1 result)
 };
 int zfft_split(int N_eff);   // sub-sequences a lattice of N_eff samples is transformed in (0: none)
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,

@@ -1083,6 +1083,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.in_s1 = (int64_t)my * g_ld;
             c.in_s2 = g_ld;
             c.in_es = 1;
+            c.second = 1;
         }
         if (mirrored) {
             c.a0 = row0;

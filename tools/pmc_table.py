@@ -29,7 +29,10 @@ CLASSES = (('nearfield', ('nearfield_ring_kernel', 'nearfield_centre_kernel', 'n
            ('stage2', ('zfft_kernel<16, 256, 2, 2', 'zfft_kernel<8, 128, 2, 2', 'zfft_kernel<32, 512, 2, 2',
                        'zfft_kernel<4, 64, 2, 2', 'zfft_kernel<0, 512, 1, 2', 'zfft_multi_kernel<2>',
                        'zfft_interleaved_kernel', 'zfft_pass_kernel<16, 2, 2, 2, 2>',
-                       'zfft_pass_kernel<32, 2, 2, 2, 2>')),
+                       'zfft_pass_kernel<32, 2, 2, 2, 2>',
+                       # (a transposed stage-1 result: stage 2 reads contiguous rows, PASS = 3)
+                       'zfft_kernel<16, 256, 2, 3', 'zfft_kernel<8, 128, 2, 3', 'zfft_kernel<32, 512, 2, 3',
+                       'zfft_pass_kernel<16, 2, 2, 2, 3>', 'zfft_pass_kernel<32, 2, 2, 2, 3>')),
            ('project', ('project_kernel',)))
 
 

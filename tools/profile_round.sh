@@ -14,7 +14,7 @@ mkdir -p $O
 T="timeout -k 5 ${PMC_TIMEOUT:-240}"
 cd /tmp && export TMPDIR=/tmp
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --cpu-rows 0 --cpu-fft-side 0 > $O/stats.log 2>&1
-pmc() {   # pmc NAME <bench args>: the three counter passes of one configuration
+pmc() {   # pmc NAME <bench args>: the counter passes of one configuration
   name=$1; shift
   SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 $@"
   $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$name/fetch -- $SHORT > $O/$name.fetch.log 2>&1
@@ -24,7 +24,10 @@ pmc() {   # pmc NAME <bench args>: the three counter passes of one configuration
 pmc c4096
 pmc c2048 --aperture 2048 --farfield 256
 pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
-pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
+# the instruction mix of the synthesis kernels at the north-star size (per-wave figures of DESIGN 4.1)
+SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0"
+$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4096/insts -- $SHORT > $O/c4096.insts.log 2>&1
+$T rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/c4096/active -- $SHORT > $O/c4096.active.log 2>&1
 cd $R
 B="python bench.py --cpu-rows 0 --cpu-fft-side 0"
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench.json
@@ -36,9 +39,13 @@ timeout 300 $B --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --profil
 timeout 300 $B --pols xyz --profile all 2>/dev/null | tail -1 > $O/bench_pols_xyz.json
 timeout 300 $B --precision f32 --profile all 2>/dev/null | tail -1 > $O/bench_f32.json
 timeout 300 $B --zoom 0.5 --profile all 2>/dev/null | tail -1 > $O/bench_zoom05.json
-timeout 300 $B --zoom 0.7 --profile all 2>/dev/null | tail -1 > $O/bench_zoom07.json
 timeout 300 $B --pair-list 4096 --profile all 2>/dev/null | tail -1 > $O/bench_pairlist4096.json
-timeout 300 $B --overlap 8,4,1,2 --profile all 2>/dev/null | tail -1 > $O/bench_overlap8.json
-timeout 300 $B --pipeline 1,4,1,2 --profile all 2>/dev/null | tail -1 > $O/bench_pipeline.json
+# the multi-rank path on this one GPU: plain `bench.py --gpus N` starts its own ranks (file communicator)
+for n in 2 4 8; do
+  ML_COMM_BACKEND=file timeout 600 python bench.py --gpus $n --cpu-rows 0 --cpu-fft-side 0 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --scaling strong 2>$O/bench_gpus$n.err | tail -1 > $O/bench_gpus${n}_8192_file_comm.json
+done
 timeout 300 python tools/dropin_time.py > $O/dropin.log 2>&1
+# (diagnostic build with the phase stamps: make -C metalens_amd/csrc EXTRA=-DML_PHASE_TIMERS BUILD=build_pt TARGET=../../abl_tmp/lib_pt.so,
+# made in the build container - it travels with the snapshot)
+[ -f abl_tmp/lib_pt.so ] && METALENS_HIP_LIB=abl_tmp/lib_pt.so timeout 300 python tools/nearfield_phase_timers.py 4096 > $O/phase_timers_4096.txt 2>&1
 ls $O
