@@ -286,9 +286,10 @@ def main():
     ap.add_argument('--precision', choices=('f64', 'f32'), default='f64',
                     help="arithmetic of the far-field GEMMs: f64 (BASELINE metric, 1e-12) or f32 "
                          "(fp32 matrix cores, 1e-4; near field, storage and projection stay fp64)")
-    ap.add_argument('--method', choices=('auto', 'gemm'), default='auto',
+    ap.add_argument('--method', choices=('auto', 'gemm', 'fft-streamed'), default='auto',
                     help='auto: output-pruned FFT on axes whose direction grid sits on the FFT '
-                         'lattice (zoom 1), GEMMs elsewhere; gemm: the folded matrix-core GEMMs')
+                         'lattice (zoom 1), GEMMs elsewhere; gemm: the folded matrix-core GEMMs; fft-streamed: '
+                         'auto with the stage-1 result transposed at every size (auto: from 200 MB on)')
     ap.add_argument('--sharding', choices=('auto', 'interleaved', 'mirrored', 'rows'), default='auto',
                     help='N > 1: how the aperture rows are dealt to the ranks (auto: interleaved blocks '
                          'where the x direction grid sits on the FFT lattice, else mirrored pairs, else '
@@ -575,7 +576,9 @@ def main():
                         'row transforms written; samples outside the lens circle are known zeros '
                         'and are not read, so traffic is below bytes_per_launch and frac (algorithmic) '
                         'above traffic_frac (measured); what bounds the kernel is the LDS pipe and '
-                        'its barriers (DESIGN.md 4.2)'}
+                        'its barriers, and - where the result is written transposed for a streaming '
+                        'stage 2 (large apertures) - its 16-byte scattered stores, a price paid for '
+                        'the synthesis and stage 2 (DESIGN.md 4.2)'}
         else:
             flops = 8.0 * 4 * local_rows * side * u.size
             mfma_peak = FP64_MFMA_PEAK_TFLOPS if args.precision == 'f64' else FP32_MFMA_PEAK_TFLOPS

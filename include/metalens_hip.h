@@ -214,6 +214,10 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
  * next ml_farfield_plan.                                                                     */
 #define ML_METHOD_AUTO 0
 #define ML_METHOD_GEMM 1
+/* ML_METHOD_FFT_STREAMED: as AUTO, and where both axes run as one-level FFTs stage 1 writes its result
+ * transposed for a streaming stage 2 whatever the aperture's size (AUTO does so from 200 MB of
+ * geometry records + stage-1 result on: DESIGN.md 4.2)                                           */
+#define ML_METHOD_FFT_STREAMED 2
 int ml_farfield_set_method(ml_ctx *ctx, int method);
 /* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",
  * configs[4] "fp32 GEMM-cast MFMA path").  ML_PRECISION_F64 (default): fp64 matrix cores.

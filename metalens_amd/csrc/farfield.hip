@@ -759,7 +759,7 @@ int ml_farfield_plan(ml_ctx *ctx, int nx_total, int ny, double dxp, double dyp, 
     ML_TRY(pl.amplitudes.reserve(2 * 2 * out_elems * 2 * sizeof(double)));   // two slots
     // direction grids on the aperture's FFT lattice: that axis runs as an output-pruned FFT
     pl.fft_y.ok = pl.fft_x.ok = false;
-    if (method == ML_METHOD_AUTO && !pair_list) {
+    if (method != ML_METHOD_GEMM && !pair_list) {
         ML_TRY(plan_fft_axis(ctx, pl.fft_y, ny, dyp, uy, my));
         ML_TRY(plan_fft_axis(ctx, pl.fft_x, nx_total, dxp, ux, mx));
     }
@@ -892,7 +892,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // 0.167 against 0.178 ms per step).
     const bool g_transposed = ML_STAGE1_TRANSPOSED && pl.fft_y.ok && pl.fft_x.ok && !pl.pair_list &&
                               pl.fft_y.split == 1 && pl.fft_x.split == 1 && sh.kind != 2 &&
-                              (size_t)nxl * ny * 8 + (size_t)4 * nxl * my * 16 > (size_t)200 << 20;
+                              (pl.method == ML_METHOD_FFT_STREAMED ||
+                               (size_t)nxl * ny * 8 + (size_t)4 * nxl * my * 16 > (size_t)200 << 20);
     // (skew sweep at 4096^2 -> 512^2, stage 1: 0 elements 0.220 ms, 16 0.222, 1 0.204, 2 0.212, 24 0.208,
     // 72 0.206, 4 0.190, 8 0.194-0.196, 40 0.196, 136 0.192: anything but a multiple of 256 bytes)
     const int64_t g_ld = nxl + 8;
@@ -1549,7 +1550,8 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
 
 int ml_farfield_set_method(ml_ctx *ctx, int method) {
     ML_REQUIRE(ctx, "ctx is NULL");
-    ML_REQUIRE(method == ML_METHOD_AUTO || method == ML_METHOD_GEMM, "unknown method %d", method);
+    ML_REQUIRE(method == ML_METHOD_AUTO || method == ML_METHOD_GEMM || method == ML_METHOD_FFT_STREAMED,
+               "unknown method %d", method);
     ctx->ff_method = method;
     return ML_OK;
 }

@@ -47,7 +47,7 @@ class HotPath:
         # both are properties of the context that later plans inherit: set them on every
         # construction so that an earlier HotPath(precision='f32') cannot leak into this one
         self.ctx.set_precision(precision or 'f64')   # 'f64' | 'f32': arithmetic of the GEMMs
-        self.ctx.set_method(method or 'auto')        # 'auto' | 'gemm': _lib.Context.set_method
+        self.ctx.set_method(method or 'auto')        # 'auto' | 'gemm' | 'fft-streamed': _lib.Context.set_method
         if hasattr(self.ctx.lib, 'ml_comm_set_reduce'):
             _lib.check(self.ctx.lib.ml_comm_set_reduce(self.ctx.handle, int(allreduce)))
         self.rank, self.world = rank, world
