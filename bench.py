@@ -665,7 +665,8 @@ def main():
             'first_ms': 1e3 * (t1 - t0), 'second_ms': 1e3 * (t2 - t1), 'third_ms': 1e3 * (t3 - t2),
             'note': 'host-timed single steps (queue + sync) on a sample grid the context has not seen: '
                     'first = axes upload, plan tables, row extents, geometry kernel + scans, a synthesis '
-                    'over ALL patches that also stores the zeros outside the lens, transform, projection; '
+                    'whose ring kernel visits ALL patches and stores the zeros outside the lens (the centre '
+                    'kernel works from its list already), transform, projection; '
                     'second = reads the active-patch count back (one sync) and launches the listed '
                     'patches; third = a steady single step, launch latency included (the timed region '
                     'queues its steps back to back)'}

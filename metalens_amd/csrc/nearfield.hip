@@ -164,6 +164,8 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.list_stride = a.n_partials / 4;
     a.count_stride = a.n_partials / 4 / 1024 + 4;
     a.use_active = 0;
+    a.list_count = nullptr;
+    a.first_pass = 0;
     for (int k = 0; k < 3; ++k) a.n_active[k] = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;

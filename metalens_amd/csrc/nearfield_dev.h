@@ -93,6 +93,12 @@ struct NfArgs {
     int *active_count, *active_flag;
     int list_stride, count_stride;
     int use_active, n_active[3], patches_x;
+    // the first synthesis into a buffer runs the ring kernel over the WHOLE grid (it stores the zeros
+    // outside the lens and sums every patch's incident power) and the centre kernel from its list with
+    // the entry count read on the device (list_count; the host has not seen it yet): first_pass tells
+    // the listed centre kernel that the power is not its business this time
+    const int *list_count;
+    int first_pass;
     // every table of the lens holds orders ox = -1, 0, 1 with oy = 0 only: the kernels that build
     // an order's phasor by one product run (nearfield_fast.hip order_phasor), else the general ones
     int simple_orders;
