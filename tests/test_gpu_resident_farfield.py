@@ -113,3 +113,45 @@ def test_shape_mismatch_is_refused():
     x = np.arange(20) * 2e-7
     with pytest.raises(ValueError):
         ma.farfield_from_resident_nearfield(x, x, 580e-9, 1.459, ctx=ctx)
+
+
+def test_resident_flow_leaves_the_context_as_it_found_it():
+    """the resident flow on a context that a sweep and an fp32 HotPath also use - the
+    sweep's per-source sums stay what they were (total_P is taken in a slot of its own), the
+    context's precision is put back, and a synthesis that a HotPath left writing modulated fields is
+    switched back to plain ones by build_nearfield"""
+    import metalens_amd as ma
+    from metalens_amd import _lib
+    case = np.load(golden_io.golden_path('nearfield_B_straddle_offaxis_y.npz'))
+    lens = golden_io.load_lens(golden_io.golden_path(str(case['lens'])))
+    wl = float(case['wavelength'])
+    x, y = case['x_pts'], case['y_pts']
+    u = np.linspace(-0.2, 0.2, 24)
+    ctx = _lib.default_context()
+    f = abs(float(case['source_z']))
+    sources = [(0.0, 0.0, -f, 'x'), (0.0, 0.0, -f, 'y'),
+               (float(case['source_x']), float(case['source_y']), -f, 'x')]   # (the fixture's own off-axis source)
+    sw = ma.SourceSweep(wl, lens[0], lens[1], lens[2], x, y, u, u, ctx=ctx)
+    before = sw.run(sources, cone=0.05)
+    # an fp32 hot path with the fused input modulation uses the context next
+    hp = ma.HotPath(sources[0], wl, lens[0], lens[1], lens[2], x, y, u, u, ctx=ctx, precision='f32',
+                    fuse_modulation=True)
+    hp.step()
+    hp.sync()
+    assert ctx.precision == 'f32'
+    out = ma.build_nearfield(0.0, 0.0, -f, 'x', wl, lens[0], lens[1], lens[2], x_pts=x, y_pts=y,
+                             ctx=ctx, download=False)
+    P, total_P, *_ = ma.farfield_from_resident_nearfield(x, y, wl, out[7], ctx=ctx)
+    assert ctx.precision == 'f32'                         # put back
+    assert np.isfinite(total_P) and total_P > 0
+    # the same flow from a clean context state gives the same map: the fields were plain
+    ctx.set_precision('f64')
+    out2 = ma.build_nearfield(0.0, 0.0, -f, 'x', wl, lens[0], lens[1], lens[2], x_pts=x, y_pts=y,
+                              ctx=ctx, download=False)
+    P2, total_P2, *_ = ma.farfield_from_resident_nearfield(x, y, wl, out2[7], ctx=ctx)
+    assert np.array_equal(P, P2, equal_nan=True) and total_P == total_P2
+    # the sweep's per-source sums are untouched (its P_sum belongs to its own direction grid and plan)
+    total = np.zeros(len(sources))
+    cone = np.zeros(len(sources))
+    _lib.check(ctx.lib.ml_farfield_sums(ctx.handle, None, _lib.dptr(total), _lib.dptr(cone), len(sources)))
+    assert np.array_equal(total, before['total_P']) and np.array_equal(cone, before['cone_P'])

@@ -24,6 +24,7 @@ pmc() {   # pmc NAME <bench args>: the counter passes of one configuration
 pmc c4096
 pmc c2048 --aperture 2048 --farfield 256
 pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
+pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
 # the instruction mix of the synthesis kernels at the north-star size (per-wave figures of DESIGN 4.1)
 SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0"
 $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4096/insts -- $SHORT > $O/c4096.insts.log 2>&1
@@ -40,6 +41,7 @@ timeout 300 $B --pols xyz --profile all 2>/dev/null | tail -1 > $O/bench_pols_xy
 timeout 300 $B --precision f32 --profile all 2>/dev/null | tail -1 > $O/bench_f32.json
 timeout 300 $B --zoom 0.5 --profile all 2>/dev/null | tail -1 > $O/bench_zoom05.json
 timeout 300 $B --pair-list 4096 --profile all 2>/dev/null | tail -1 > $O/bench_pairlist4096.json
+timeout 600 $B --aperture 16384 --farfield 1024 --diameter 4e-3 --steps 5 --warmup 1 --blocks 2 --cold 0 --profile all 2>/dev/null | tail -1 > $O/bench_16384x1024_f64.json
 # the multi-rank path on this one GPU: plain `bench.py --gpus N` starts its own ranks (file communicator)
 for n in 2 4 8; do
   ML_COMM_BACKEND=file timeout 600 python bench.py --gpus $n --cpu-rows 0 --cpu-fft-side 0 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --scaling strong 2>$O/bench_gpus$n.err | tail -1 > $O/bench_gpus${n}_8192_file_comm.json
