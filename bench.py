@@ -289,7 +289,7 @@ def main():
     ap.add_argument('--method', choices=('auto', 'gemm', 'fft-streamed'), default='auto',
                     help='auto: output-pruned FFT on axes whose direction grid sits on the FFT '
                          'lattice (zoom 1), GEMMs elsewhere; gemm: the folded matrix-core GEMMs; fft-streamed: '
-                         'auto with the stage-1 result transposed at every size (auto: from 200 MB on)')
+                         'auto with the stage-1 result transposed at every size (auto: from 96 MiB of records + stage-1 result on)')
     ap.add_argument('--sharding', choices=('auto', 'interleaved', 'mirrored', 'rows'), default='auto',
                     help='N > 1: how the aperture rows are dealt to the ranks (auto: interleaved blocks '
                          'where the x direction grid sits on the FFT lattice, else mirrored pairs, else '

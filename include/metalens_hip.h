@@ -215,7 +215,7 @@ int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel
 #define ML_METHOD_AUTO 0
 #define ML_METHOD_GEMM 1
 /* ML_METHOD_FFT_STREAMED: as AUTO, and where both axes run as one-level FFTs stage 1 writes its result
- * transposed for a streaming stage 2 whatever the aperture's size (AUTO does so from 200 MB of
+ * transposed for a streaming stage 2 whatever the aperture's size (AUTO does so from 96 MiB of
  * geometry records + stage-1 result on: DESIGN.md 4.2)                                           */
 #define ML_METHOD_FFT_STREAMED 2
 int ml_farfield_set_method(ml_ctx *ctx, int method);

@@ -298,7 +298,7 @@ class Context:
         """'auto' (default): axes whose direction grid sits on the aperture's FFT lattice run as
         output-pruned FFTs, the others as GEMMs; 'gemm': GEMMs everywhere; 'fft-streamed': as
         'auto' with the stage-1 result transposed for a streaming stage 2 at every size (auto:
-        from 200 MB on).  Applies to the next plan."""
+        from 96 MiB of records + stage-1 result on).  Applies to the next plan."""
         check(self.lib.ml_farfield_set_method(self.handle, {'auto': 0, 'gemm': 1, 'fft-streamed': 2}[method]))
 
     def plan_kernels(self):

@@ -888,12 +888,13 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // scattered stores - neighbouring rows meet in the XCD's L2 -, stage 2 0.057 -> 0.037) but in the
     // NEXT synthesis, 0.265 -> 0.229 ms: a G that is read once and dropped no longer pushes the
     // geometry records (134 MB at 4096^2, + 134 MB of G > the 256 MB memory-side cache) out between
-    // steps.  Small apertures, where everything fits anyway, keep the row-major G (2048^2 -> 256^2:
-    // 0.167 against 0.178 ms per step).
+    // steps.  Small apertures, where everything fits anyway, keep the row-major G (2048^2 -> 256^2,
+    // 67 MB of records + G: 0.167 against 0.178 ms per step; from 2560^2 -> 320^2, 105 MB, on the
+    // transposed one is 1-1.5 % ahead: 0.282 against 0.287 ms, 3072^2 0.368 / 0.372, 3584^2 0.458 / 0.463).
     const bool g_transposed = ML_STAGE1_TRANSPOSED && pl.fft_y.ok && pl.fft_x.ok && !pl.pair_list &&
                               pl.fft_y.split == 1 && pl.fft_x.split == 1 && sh.kind != 2 &&
                               (pl.method == ML_METHOD_FFT_STREAMED ||
-                               (size_t)nxl * ny * 8 + (size_t)4 * nxl * my * 16 > (size_t)200 << 20);
+                               (size_t)nxl * ny * 8 + (size_t)4 * nxl * my * 16 > (size_t)96 << 20);
     // (skew sweep at 4096^2 -> 512^2, stage 1: 0 elements 0.220 ms, 16 0.222, 1 0.204, 2 0.212, 24 0.208,
     // 72 0.206, 4 0.190, 8 0.194-0.196, 40 0.196, 136 0.192: anything but a multiple of 256 bytes)
     const int64_t g_ld = nxl + 8;

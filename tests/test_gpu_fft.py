@@ -20,7 +20,7 @@ def ma():
 @pytest.fixture(params=['auto', 'fft-streamed'])
 def ctx(request):
     """both layouts of the stage-1 result: row-major (what 'auto' takes at these sizes) and transposed
-    for a streaming stage 2 ('fft-streamed': what 'auto' takes from 200 MB on) -
+    for a streaming stage 2 ('fft-streamed': what 'auto' takes from 96 MiB on) -
     whole apertures, contiguous and mirrored row shards, accumulation"""
     from metalens_amd import _lib
     c = _lib.default_context()
