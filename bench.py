@@ -258,6 +258,9 @@ def main():
                     help="polarisations of the dipole; more than one letter (e.g. xyz, the incoherent "
                          "emitter of nearfield.py:69-73) makes a step ONE batched synthesis pass + a "
                          "transform and projection per member, sums kept on the GPU (N = 1 only)")
+    ap.add_argument('--positions', type=int, default=1,
+                    help='> 1: that many source POSITIONS per step (1 um apart along x, polarisation --pols[0]): a '
+                         'position batch - synthesised back to back, then a transform and projection per member')
     ap.add_argument('--blocks', type=int, default=5,
                     help='K-step blocks run back to back; the FIRST is the timed region `value` '
                          'comes from, the median block is reported beside it')
@@ -343,14 +346,15 @@ def main():
                  precision=args.precision, reduce=args.reduce,
                  fuse_modulation=bool(args.fuse_modulation), method=args.method, sharding=args.sharding)
 
-    n_pols = len(args.pols)
+    n_pols = len(args.pols) if args.positions <= 1 else args.positions
     if n_pols > 1:
         assert world == 1 and not args.pair_list, '--pols batches are a single-GPU tensor-grid mode'
         from metalens_amd.sweep import SourceSweep
         sw = SourceSweep(wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
                          lens['hexgridset'], x, x, ux, uy, ctx=ctx, precision=args.precision,
                          method=args.method)
-        batch = [(0.0, 0.0, -lens['source_distance'], pol) for pol in args.pols]
+        batch = ([(0.0, 0.0, -lens['source_distance'], pol) for pol in args.pols] if args.positions <= 1 else
+                 [(1e-6 * k, 0.0, -lens['source_distance'], args.pols[0]) for k in range(args.positions)])
         sw.run(batch)                 # priming pass; settles ties, checks the table bounds
         one_step = hp.step
         hp.step = lambda: sw.queue(batch)

@@ -326,7 +326,10 @@ int ml_farfield_project_async(ml_ctx *ctx, double Z0);
  * polarisation / dipole moment share everything per aperture sample except the two weights the
  * incident H enters with, so ml_nearfield_batch_async synthesises up to three of them in ONE pass
  * over the cached per-sample geometry (p[0..n): same position, wavelength and constants); member m
- * becomes resident field set m.  ml_fields_select picks the set that ml_farfield_transform*,
+ * becomes resident field set m.  Members at DIFFERENT positions (a field-of-view sweep; same
+ * wavelength, substrate and source kind) are accepted as well: they are synthesised one after the
+ * other into their field sets, bit-identical to n single calls, with geometry, lists and tables set
+ * up once and the geometry records still cached from member to member.  ml_fields_select picks the set that ml_farfield_transform*,
  * ml_fields_download work on; ml_nearfield_powers returns the incident power of every member.
  * ml_nearfield_async / ml_nearfield are the n = 1 case.                                       */
 int ml_nearfield_batch_async(ml_ctx *ctx, const ml_nearfield_params *p, int n, const double *x_pts,

@@ -844,13 +844,12 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
                              int nx, const double *y_pts, int ny) {
     ML_REQUIRE(ctx && p && x_pts && y_pts, "NULL argument");
     ML_REQUIRE(nx >= 1 && ny >= 1, "empty grid (%d x %d)", nx, ny);
-    ML_REQUIRE(n >= 1 && n <= 3, "a polarisation batch has 1 to 3 members, got %d", n);
+    ML_REQUIRE(n >= 1 && n <= 3, "a batch has 1 to 3 members, got %d", n);
     for (int m = 1; m < n; ++m)
-        ML_REQUIRE(p[m].source_x == p[0].source_x && p[m].source_y == p[0].source_y &&
-                       p[m].source_z == p[0].source_z && p[m].kvac == p[0].kvac &&
-                       p[m].k_glass == p[0].k_glass && p[m].n_glass == p[0].n_glass &&
+        ML_REQUIRE(p[m].kvac == p[0].kvac && p[m].k_glass == p[0].k_glass && p[m].n_glass == p[0].n_glass &&
                        p[m].Z0 == p[0].Z0 && p[m].plane_wave == p[0].plane_wave,
-                   "members of a batch may differ in polarisation and dipole moment only (member %d)", m);
+                   "members of a batch share wavelength, substrate and source kind (member %d): they may differ "
+                   "in position, polarisation and dipole moment", m);
     if (!ctx->have_layout) {
         set_error("ml_upload_layout has not been called");
         return ML_ESTATE;

@@ -234,9 +234,32 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
             for (int k = 0; k < 3; ++k) a.n_active[k] = ctx->n_active[k];
         }
     }
+    // members at ONE source position share everything but two real weights per sample and go through
+    // the batch kernels (NP = n); members at DIFFERENT positions (a field-of-view sweep) are
+    // synthesised one after the other into their field sets - the same kernels and arguments as n
+    // single calls, so bit-identical to them - before any of them is transformed: geometry, lists and
+    // tables are set up once, and the geometry records are still cached when the next member reads
+    // them (no stage-1 result in between)
+    bool one_position = true;
+    for (int m = 1; m < n; ++m)
+        one_position = one_position && p[m].source_x == p[0].source_x && p[m].source_y == p[0].source_y &&
+                       p[m].source_z == p[0].source_z;
     {
         ProfScope scope(ctx, ML_K_NEARFIELD);
-        ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
+        if (one_position) {
+            ML_TRY(nearfield_fast_launch(ctx, a, &n_partials));
+        } else {
+            for (int m = 0; m < n; ++m) {
+                NfArgs am;
+                fill_nf_args(ctx, p + m, 1, nx, ny, am);
+                am.outside_is_zero = a.outside_is_zero;
+                am.use_active = a.use_active;
+                for (int k = 0; k < 3; ++k) am.n_active[k] = a.n_active[k];
+                am.fields += (size_t)m * 4 * nx * ny * 2;
+                am.partial_power += (size_t)m * a.n_partials;
+                ML_TRY(nearfield_fast_launch(ctx, am, &n_partials));
+            }
+        }
     }
     memcpy(ctx->zero_key, zero_key, sizeof zero_key);
     ML_HIP(hipGetLastError());

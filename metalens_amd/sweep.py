@@ -85,23 +85,41 @@ class SourceSweep:
             self._pass(g, None, (0.0, 0.0, 0.0), weights)
 
     def _group(self, sources):
-        """consecutive sources at one position -> batches of up to MAX_BATCH polarisations"""
+        """consecutive sources at one position -> batches of up to MAX_BATCH polarisations (one
+        synthesis pass with everything but two weights per sample shared); then runs of
+        single-source groups at DIFFERENT positions (a field-of-view sweep) -> position batches of up
+        to MAX_BATCH members (synthesised back to back before any of them is transformed).  Members
+        of a group carry their own position; plane waves and dipoles do not mix."""
         groups = []
         for k, src in enumerate(sources):
             sx, sy, sz, pol = _check_source(src)
             if groups and groups[-1]['pos'] == (sx, sy, sz) and len(groups[-1]['members']) < MAX_BATCH:
                 groups[-1]['members'].append((k, pol))
+                groups[-1]['positions'].append((sx, sy, sz))
             else:
-                groups.append({'pos': (sx, sy, sz), 'members': [(k, pol)]})
-        return groups
+                groups.append({'pos': (sx, sy, sz), 'members': [(k, pol)], 'positions': [(sx, sy, sz)]})
+        merged = []
+        for g in groups:
+            last = merged[-1] if merged else None
+            single = len(g['members']) == 1
+            if (single and last is not None and last.get('mixed', len(last['members']) == 1)
+                    and len(last['members']) < MAX_BATCH
+                    and (last['positions'][0][2] == -float('inf')) == (g['pos'][2] == -float('inf'))):
+                last['members'] += g['members']
+                last['positions'] += g['positions']
+                last['mixed'] = True
+                last['pos'] = None
+            else:
+                merged.append(g)
+        return merged
 
     def _pass(self, group, slots_done, cone, weights):
         """queue one group: batched synthesis, then per member transform -> projection -> sums"""
         ctx, lib = self.ctx, self.ctx.lib
-        sx, sy, sz = group['pos']
         n = len(group['members'])
         params = (_lib.NearfieldParams * n)()
         for m, (k, pol) in enumerate(group['members']):
+            sx, sy, sz = group['positions'][m]
             params[m] = nearfield_params(sx, sy, sz, pol, self.wavelength, self.n_glass,
                                          self.dipole_moment, self.c0, self.Z0)
         _lib.check(lib.ml_nearfield_batch_async(ctx.handle, params, n, _lib.dptr(self.x), self.x.size,

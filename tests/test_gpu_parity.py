@@ -432,7 +432,8 @@ def test_rgb_wavelengths_vs_oracle(ma, wl_nm, n_glass):
 def test_source_sweep_incoherent_sum_vs_oracle(ma):
     """x + y + z dipoles summed incoherently (the reference's isotropic-emitter recipe,
     nearfield.py:69-73).  Sources at one position are ONE synthesis pass (a polarisation batch
-    of 3, then a single, then a batch of 2); P_sum, every total_P and the encircled power are
+    of 3, then a single, then a batch of 2), two single sources at different positions travel as
+    one POSITION batch; P_sum, every total_P and the encircled power are
     accumulated on the GPU and must equal the oracle's maps reduced on the host
     (metalens_amd/postprocess.py, itself pinned on the reference's total_P)."""
     from metalens_amd import postprocess
@@ -446,12 +447,14 @@ def test_source_sweep_incoherent_sum_vs_oracle(ma):
     f = lens['source_distance']
     sources = [(0.2e-6, 0.1e-6, -f, 'x'), (0.2e-6, 0.1e-6, -f, 'y'), (0.2e-6, 0.1e-6, -f, 'z'),
                (-1.0e-6, 0.5e-6, -1.05 * f, 'x'),
-               (0.0, 0.0, -0.97 * f, 'y'), (0.0, 0.0, -0.97 * f, 'z')]
-    weights = np.array([1.0, 1.0, 1.0, 0.5, 2.0, 2.0])
+               (0.0, 0.0, -0.97 * f, 'y'), (0.0, 0.0, -0.97 * f, 'z'),
+               (0.5e-6, 0.0, -f, 'x'), (-0.5e-6, 0.3e-6, -1.02 * f, 'y')]   # two positions: one POSITION batch
+    weights = np.array([1.0, 1.0, 1.0, 0.5, 2.0, 2.0, 1.5, 0.7])
     cone, center = 0.08, (0.01, -0.005)
     sw = ma.SourceSweep(wl, lens['lens_periphery_summary'], lens['lens_center_summary'],
                         lens['hexgridset'], x, x, u, u)
-    assert [len(g['members']) for g in sw._group(sources)] == [3, 1, 2]
+    groups = sw._group(sources)
+    assert [len(g['members']) for g in groups] == [3, 1, 2, 2] and groups[3].get('mixed')
     got = sw.run(sources, weights=weights, cone=cone, cone_center=center, keep_each=True)
     P_ref, pin_ref = 0, []
     for k, (sx, sy, sz, pol) in enumerate(sources):
@@ -505,6 +508,43 @@ def test_polarisation_batch_equals_single_sources(ma):
             for g, w in zip(F, singles[m][:4]):
                 assert np.abs(g - w).max() <= 1e-14 * scale
             assert abs(pw[m] * (x[1] - x[0]) ** 2 - singles[m][6]) <= 1e-13 * abs(singles[m][6])
+
+
+def test_position_batch_equals_single_sources(ma):
+    """f4(b): members of a batch at DIFFERENT source positions (and polarisations) are synthesised back
+    to back into their field sets by the same kernels a single call runs: fields bit-identical to
+    three drop-in calls, incident powers equal; wavelength / source kind must still agree"""
+    from metalens_amd import _lib
+    from metalens_amd.nearfield import nearfield_params
+    wl = 580e-9
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    R = lens['lens_periphery_summary']['r_max_list'][-1]
+    f = lens['source_distance']
+    ctx = _lib.default_context()
+    common = (wl, lens['lens_periphery_summary'], lens['lens_center_summary'], lens['hexgridset'])
+    x = np.linspace(-R, R, 384)
+    srcs = [(0.3e-6, -0.2e-6, -f, 'x'), (-1.1e-6, 0.4e-6, -1.03 * f, 'z'), (0.0, 0.9e-6, -0.98 * f, 'y')]
+    singles = [ma.build_nearfield(sx, sy, sz, pol, *common, x_pts=x, y_pts=x, ctx=ctx) for sx, sy, sz, pol in srcs]
+    params = (_lib.NearfieldParams * 3)()
+    for m, (sx, sy, sz, pol) in enumerate(srcs):
+        params[m] = nearfield_params(sx, sy, sz, pol, wl, singles[0][7], 1e-30, ma.constants.c0, ma.constants.Z0)
+    xs = _lib.f64(x)
+    for rep in range(2):       # (the first pass into the three-set buffer also stores the zeros; the second runs from the lists)
+        _lib.check(ctx.lib.ml_nearfield_batch_async(ctx.handle, params, 3, _lib.dptr(xs), xs.size, _lib.dptr(xs), xs.size))
+        pw = np.zeros(3)
+        _lib.check(ctx.lib.ml_nearfield_powers(ctx.handle, _lib.dptr(pw), 3))
+        for m in range(3):
+            _lib.check(ctx.lib.ml_fields_select(ctx.handle, m))
+            F = [np.empty((x.size, x.size), dtype=np.complex128) for _ in range(4)]
+            _lib.check(ctx.lib.ml_fields_download(ctx.handle, *[_lib.dptr(a) for a in F]))
+            for g, w in zip(F, singles[m][:4]):
+                assert np.array_equal(g, w), (rep, m)
+            assert abs(pw[m] * (x[1] - x[0]) ** 2 - singles[m][6]) <= 1e-13 * abs(singles[m][6])
+    # a plane wave and a dipole do not share a batch
+    bad = (_lib.NearfieldParams * 2)()
+    bad[0] = params[0]
+    bad[1] = nearfield_params(0.0, 0.0, -float('inf'), 'x', wl, singles[0][7], 1e-30, ma.constants.c0, ma.constants.Z0)
+    assert ctx.lib.ml_nearfield_batch_async(ctx.handle, bad, 2, _lib.dptr(xs), xs.size, _lib.dptr(xs), xs.size) != 0
 
 
 @pytest.mark.parametrize('reduce', ['amplitudes', 'vectors'])

@@ -77,7 +77,10 @@ def test_sweep_groups_consecutive_polarisations_of_one_position():
             (1e-6, 0, f, 'x'), (0, 0, f, 'y'), (0, 0, f, 'z'),                      # position changes
             (0, 0, -float('inf'), 'x'), (0, 0, -float('inf'), 'y')]                # plane waves
     groups = sw._group(srcs)
-    assert [len(g['members']) for g in groups] == [3, 1, 1, 2, 2]
+    # (the two single sources at different positions travel as one position batch)
+    assert [len(g['members']) for g in groups] == [3, 2, 2, 2]
+    assert groups[1].get('mixed') and groups[1]['positions'] == [(0, 0, f), (1e-6, 0, f)]
+    assert not groups[0].get('mixed') and not groups[2].get('mixed')
     assert all(len(g['members']) <= MAX_BATCH for g in groups)
     assert [k for g in groups for k, _ in g['members']] == list(range(len(srcs)))
     import pytest
