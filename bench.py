@@ -78,21 +78,26 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
-def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False):
-    """roofline object of the synthesis: ALGORITHMIC bytes per step (64 B per sample and source: the
-    four complex fields written once) / the launch time, against the 8 TB/s of HBM, with the counter
-    traffic beside it; and, where the configuration has a counter profile, what
-    actually bounds the kernel: vector-instruction issue (``valu``)."""
+def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False, full_grid_bytes=None):
+    """roofline object of the synthesis: ALGORITHMIC bytes per step - 64 B (the four complex fields
+    written once) per sample and source the launches PROCESS, i.e. per sample inside the
+    lens circle: the zeros outside it are stored once per geometry, not per step - / the launch time,
+    against the 8 TB/s of HBM, with the counter traffic beside it; and, where the configuration has a
+    counter profile, what actually bounds the kernel: vector-instruction issue (``valu``).
+    ``frac_full_grid`` = the same with every sample of the window counted (the figure of rounds 1-4)."""
     hbm_gbs = nf_bytes / (avg_ms * 1e-3) / 1e9
     insts = pmc_nf.get('SQ_INSTS_VALU')
     roof = {
         'bound': 'hbm', 'kernel': 'nearfield_ring_kernel + nearfield_centre_kernel (one synthesis)',
         'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / HBM_PEAK_GBS,
         'traffic': pmc_nf.get('traffic_bytes'), 'avg_launch_ms': avg_ms, 'bytes_per_launch': nf_bytes,
-        'note': 'achieved = 64 B per aperture sample (Ex, Ey, Hx, Hy written once; SURVEY.md 8(d)) / the '
-                'HIP-event time of the synthesis launches of a step; traffic = FETCH_SIZE x 2 + WRITE_SIZE '
-                'of the same launches (profiles/pmc_table.json).  The kernel is not bound by HBM but by '
-                'vector-instruction issue and the latency of its dependent loads: see `valu`'}
+        'note': 'achieved = 64 B per aperture sample INSIDE THE LENS (Ex, Ey, Hx, Hy written once; SURVEY.md '
+                '8(d); the samples a steady-state launch processes) / the HIP-event time of the synthesis '
+                'launches of a step; traffic = FETCH_SIZE x 2 + WRITE_SIZE of the same launches '
+                '(profiles/pmc_table.json).  The kernel is not bound by HBM but by vector-instruction issue '
+                'and the latency of its dependent loads: see `valu`'}
+    if full_grid_bytes:
+        roof['frac_full_grid'] = full_grid_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     if insts:
         # SQ_INSTS_VALU wave-instructions per launch (counter) x 4 cycles / (1024 SIMDs x 2.4 GHz) = the
         # time the launch needs if every SIMD issues back to back
@@ -102,20 +107,24 @@ def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False):
     return roof
 
 
-def pmc_key(gpus, aperture, farfield, precision, method, zoom, pols):
+def pmc_key(gpus, aperture, farfield, precision, method, zoom, pols, orders='survey'):
     return ('gpus=%d,aperture=%d,farfield=%d,precision=%s,method=%s,zoom=%g,pols=%d'
-            % (gpus, aperture, farfield, precision, method, zoom, pols))
+            % (gpus, aperture, farfield, precision, method, zoom, pols)) + (',orders=%s' % orders if orders != 'survey' else '')
 
 
-def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0):
+def build_workload(aperture, farfield, diameter, na, wavelength, zoom, n_glass=0, orders='survey'):
     import metalens_amd as ma
     from metalens_amd import layout, synthetic
     degree = math.pi / 180
+    # 'survey': the three orders (0,0), (-1,0), (+1,0) in every table, what SURVEY.md 8(d) prescribes for the
+    # synthetic tables; 'physical': per collection and direction the orders characterize() would record
+    # (grating.lua:417-423: every order that propagates in air there) - 7 to 11 per ring collection
+    order_args = {} if orders == 'survey' else {'periphery_orders': 'physical', 'center_orders': 'physical'}
     lens = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet),
                                layout.make_design, radius=diameter / 2, numerical_aperture=na,
                                wavelength=wavelength, switch_angle=12 * degree, num_gratings=24,
                                num_entries=12, n_glass=n_glass,
-                               design_kwargs={'wavelength': wavelength} if n_glass else None)
+                               design_kwargs={'wavelength': wavelength} if n_glass else None, **order_args)
     pitch = wavelength / 2.2
     x = (np.arange(aperture) - (aperture - 1) / 2) * pitch
     # far-field grid: M x M directions centred on the collimated beam, `zoom` FFT-lattice
@@ -297,6 +306,10 @@ def main():
                     help='N > 1: how the aperture rows are dealt to the ranks (auto: interleaved blocks '
                          'where the x direction grid sits on the FFT lattice, else mirrored pairs, else '
                          'contiguous blocks)')
+    ap.add_argument('--orders', choices=('survey', 'physical'), default='survey',
+                    help="diffraction orders in the synthetic tables: survey = (0,0), (-1,0), (+1,0) everywhere "
+                         "(SURVEY.md 8(d)); physical = what characterize() would record, per collection and "
+                         "direction (7 to 11 orders per ring collection of the default lens)")
     ap.add_argument('--cold', type=int, default=1,
                     help='1: also time single steps on a sample grid the context has not seen '
                          '(ms_first_step_new_geometry); N = 1 only')
@@ -331,7 +344,7 @@ def main():
         base = side
         side = int(round(base * math.sqrt(world) / 16)) * 16
         diameter = diameter * side / base
-    lens, x, u = build_workload(side, args.farfield, diameter, na, wavelength, args.zoom, n_glass)
+    lens, x, u = build_workload(side, args.farfield, diameter, na, wavelength, args.zoom, n_glass, args.orders)
     ux, uy = u, u
     if args.pair_list:
         rng = np.random.default_rng(7)
@@ -533,7 +546,11 @@ def main():
                    'centre_cells': int(len(lens['lens_center_summary'])),
                    'parallelism': par, 'sharding': hp.sharding, 'sources_per_step': n_pols,
                    'replicas': replica_table,
-                   'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]}},
+                   'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]},
+                   # the table's order sets and the synthesis kernels they select (ml_nearfield_kernel_info)
+                   'orders': args.orders,
+                   'orders_per_table': [len(o) for o in getattr(ctx, 'table_orders', [])],
+                   'nearfield_kernels': ctx.nearfield_kernels()},
         # the same K steps again, args.blocks times in all: spread of the measurement
         'ms_per_step_blocks': block_ms, 'ms_per_step_median': float(np.median(block_ms)),
         'priming_steps': prime + 2,
@@ -551,7 +568,7 @@ def main():
                                    for k, v in prof.items() if v['launches']}
     line['kernel_timing'] = {'mode': args.profile, 'timed_every_n_steps': every}
     local_rows = hp.x_local.size
-    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols)
+    key = pmc_key(world, side, u.size, args.precision, args.method, args.zoom, n_pols, args.orders)
     line['config']['pmc_key'] = key
     pmc = load_pmc_table().get(key, {})
     # counters recorded for other kernel sources are quoted with a flag, not silently
@@ -612,8 +629,14 @@ def main():
     nf = prof['nearfield']
     if nf['launches']:
         # one field set (4 complex128 planes) per member of a polarisation batch
-        nf_bytes = 64.0 * local_rows * side * n_pols
-        roofs['nearfield'] = nearfield_roof(nf['total_ms'] / nf['launches'], nf_bytes, pmc.get('nearfield', {}), stale)
+        # samples of this rank's rows inside the lens circle (the kernels' own test r <= outer radius)
+        r_lens = float(lens['lens_periphery_summary']['r_max_list'][-1])
+        d2 = r_lens ** 2 - hp.x_local ** 2
+        in_lens = float(sum(int(np.count_nonzero(np.abs(x) <= h)) for h in np.sqrt(d2[d2 >= 0])))
+        line['config']['samples_in_lens'] = in_lens
+        roofs['nearfield'] = nearfield_roof(nf['total_ms'] / nf['launches'], 64.0 * in_lens * n_pols,
+                                            pmc.get('nearfield', {}), stale,
+                                            full_grid_bytes=64.0 * local_rows * side * n_pols)
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]

@@ -373,6 +373,19 @@ int ml_nearfield_tie_answers(ml_ctx *ctx, const int64_t *sample_ids, const int32
 int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violations,
                         int max_violations, int *n_violations);
 
+/* Which synthesis kernels the LAST synthesis on this context took (the tables decide; replaces the
+ * per-order loops of nearfield.py:263-327 and :390-441 either way):
+ *   *family           1: every table in use holds orders (ox, 0), |ox| <= 5 only - what characterize()
+ *                        emits for a round lens (grating.lua:417-423) - and the kernels that build an
+ *                        order's phasor as E0 X^ox run, each grating collection over its OWN order list;
+ *                     0: some table holds an order with oy != 0 (or |ox| > 5): the general kernels,
+ *                        which evaluate every order's phase argument on its own
+ *   *ring_orders_max  family 1: order slots of the widest ring collection - its lowest to its highest
+ *                     order, a hole in the list counted (0 for family 0)
+ *   *centre_orders    family 1: order slots of the centre table
+ * Any pointer may be NULL.                                                                       */
+int ml_nearfield_kernel_info(ml_ctx *ctx, int *family, int *ring_orders_max, int *centre_orders);
+
 #ifdef __cplusplus
 }
 #endif

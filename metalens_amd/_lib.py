@@ -44,7 +44,7 @@ SYMBOLS = (
     'ml_farfield_interleave_block', 'ml_farfield_transform_interleaved_async',
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_farfield_total_power', 'ml_host_alloc', 'ml_host_free',
-    'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather',
+    'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather', 'ml_nearfield_kernel_info',
 )
 
 
@@ -145,6 +145,8 @@ def load():
         lib.ml_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
         lib.ml_comm_set_reduce.argtypes = [c_void_p, c_int]
         lib.ml_farfield_gather.argtypes = [c_void_p]
+    if hasattr(lib, 'ml_nearfield_kernel_info'):
+        lib.ml_nearfield_kernel_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.ml_profile_enable.argtypes = [c_void_p, c_int]
     lib.ml_profile_reset.argtypes = [c_void_p]
     lib.ml_profile_get.argtypes = [c_void_p, c_int, POINTER(c_int64), _dp]
@@ -307,6 +309,17 @@ class Context:
         check(self.lib.ml_farfield_plan_kernels(self.handle, byref(s1), byref(s2)))
         names = ('gemm', 'folded', 'fft')
         return names[s1.value], names[s2.value]
+
+    def nearfield_kernels(self):
+        """which synthesis kernels the last synthesis took: {'family': 'orders-along-x' (every table holds
+        orders (ox, 0), |ox| <= 5: per-collection order lists, phasors by products) or 'general',
+        'ring_orders_max', 'centre_orders'}"""
+        fam, ring, cen = c_int(0), c_int(0), c_int(0)
+        if not hasattr(self.lib, 'ml_nearfield_kernel_info'):   # (A/B runs against an older build)
+            return {'family': 'unknown', 'ring_orders_max': None, 'centre_orders': None}
+        check(self.lib.ml_nearfield_kernel_info(self.handle, byref(fam), byref(ring), byref(cen)))
+        return {'family': 'orders-along-x' if fam.value else 'general', 'ring_orders_max': ring.value,
+                'centre_orders': cen.value}
 
     def profile(self, on=True, kernels=None, every=1):
         """time kernel launches with HIP events; ``kernels`` = names to time (default all),

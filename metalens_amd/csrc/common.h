@@ -118,30 +118,35 @@ struct TableDesc {
 // (ring_rec: two 16-byte loads per lane),
 //   r_center, period | 2 pi / period, bits: offset of the ring's table in ring_tab (bits 0-39),
 //   bit 40 = the period lies outside its table's period range (nearfield.py:302-305)
-// SIMPLE order sets (every table: ox in {-1, 0, 1}, oy = 0 - nearfield_simple.hip): ring_tab holds
-// CELL BLOCKS instead, complex [ring][i0 < n0 - 1][i1 < n1 - 1][order 3][node 2 x 2][amplitude 4] - the
-// 48 complex a sample in table cell (i0, i1) interpolates from, contiguous (768 bytes: one wave-wide
-// load stages a block), canonical order slots (an order the collection lacks is a block of zeros);
-// bits 0-31 of `bits` = the ring's first BLOCK, bit 32 = the period flag.
+// SIMPLE order sets (every table of the lens: orders (ox, 0) with |ox| <= 5 - what characterize()
+// emits for a round lens, grating.lua:417-423; nearfield_simple.hip): ring_tab holds CELL BLOCKS
+// instead, complex [ring][i0 < n0 - 1][i1 < n1 - 1][order slot < n_slots][node 2 x 2][amplitude 4] - the
+// 16 n_slots complex a sample in table cell (i0, i1) interpolates from, contiguous, n_slots = the
+// orders of the ring's OWN collection, lowest first (CollDesc::ox_lo).  Blocks are
+// addressed in UNITS of 16 complex (256 bytes): bits 0-31 of `bits` = the ring's first unit,
+// bit 32 = the period flag; the block of cell c starts at unit first + c n_slots.
 // and about the ring's GRATING COLLECTION, which almost every wave shares among all its lanes: a
 // CollDesc per collection IN USE (dense numbering, ml_upload_layout), held in the kernel arguments
 // so that a wave reads it with scalar loads - the geometry records carry the dense number.
 // ring_ok holds 4 doubles per order of the ring's table (general order sets only):
 //   ox 2 pi / period, oy 2 pi / lateral, ox, oy;  ring_ok_off[ring] = the ring's offset in it.
 constexpr int MAX_RING_COLLS = 16;   // grating collections in use by the rings of one lens
+constexpr int SIMPLE_MAX_OX = 5;                       // |ox| of a simple order set (grating.lua:417 searches -5 ... 5)
+constexpr int SIMPLE_MAX_SLOTS = 2 * SIMPLE_MAX_OX + 1;
+constexpr int SIMPLE_NARROW_SLOTS = 4;                 // up to here a collection's blocks are staged whole, six at a fixed pitch (nearfield_simple.hip)
 struct CollDesc {
     double uni_ax[6];   // uniform (ux', uy') axes: first, step, 1 / step per axis (flags bit 0)
     int n0, n1, n_orders;
     int flags;          // bit 0 = axes uniform
-    // simple order sets (nearfield_simple.hip; CANONICAL order o = 0: (0, 0), 1: (-1, 0), 2: (+1, 0)):
+    // simple order sets (nearfield_simple.hip): the collection's orders are (ox, 0), ox = ox_lo ...
+    // ox_lo + n_slots - 1; slot s of a cell block is order ox_lo + s, and `present` bit s says whether
+    // the collection's data holds it (a list with holes has all-zero blocks in them; characterize()
+    // produces none: the orders that propagate at a direction are a contiguous run)
     double lim0, lim1;  // n0 - 2, n1 - 2: the last table cell per axis
-    int present;        // bit o: canonical order o is in the collection's data
-    int order_of;       // 4 bits per canonical order: its index in the collection's own order list
-                        // (the `order` of a bound-violation report)
+    int n_slots, ox_lo, present, pad;
 };
-constexpr int SIMPLE_ORDERS = 3;                       // canonical orders of a simple order set
-constexpr int CELL_BLOCK = SIMPLE_ORDERS * 16;         // complex per (ring, table cell) block: [order][node 2 x 2][amplitude 4]
-// centre table, simple order sets: complex [order 3][i0 < n0 - 1][i1 < n1 - 1][group of 20 types][node 2 x 2][amplitude 4][20]
+constexpr int UNIT = 16;                               // complex per unit of a cell block: [node 2 x 2][amplitude 4] of one order
+// centre table, simple order sets: complex [order slot][i0 < n0 - 1][i1 < n1 - 1][group of 20 types][node 2 x 2][amplitude 4][20]
 // - per order, table cell and group of CENTER_GROUP cell types the 16 x 20 complex the samples of that
 // cell and group interpolate from, contiguous (5 KiB: five wave-wide loads stage a block); types past
 // the table's K are zeros
@@ -279,7 +284,7 @@ struct ml_ctx {
     ml::DevBuf table_desc;   // TableDesc[MAX_SLOTS + 1], last = centre
     ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
-    bool simple_orders = false;   // every present table: ox in {-1, 0, 1}, oy = 0 (refresh_table_desc)
+    bool simple_orders = false;   // every table in use: orders (ox, 0), |ox| <= 5 only (refresh_ring_locations)
     double ring_bounds_all[4] = {0, 0, 0, 0};   // intersection of the ring tables' (ux', uy') bounds (NfArgs)
 
     // layout
@@ -296,7 +301,7 @@ struct ml_ctx {
     std::vector<ml::TableDesc> h_table_desc;                   // host copy of table_desc
     ml::DevBuf ring_tab, ring_ok, ring_ok_off;   // fast-kernel per-ring tables (offsets into ring_tab: ring_rec)
     ml::DevBuf center_qmajor;                                  // fast-kernel centre table [order][n0][n1][4][K]
-    int center_present = 0, center_order_of = 0;               // simple order sets: as CollDesc::present / order_of
+    int center_n_slots = 0, center_lo = 0, center_present_mask = 0;                     // simple order sets: as CollDesc::n_slots / ox_lo (no holes: see refresh_ring_locations)
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     ml::DevBuf ring_lutrec;          // fast kernel: coarser buckets that carry the boundaries
     int lutrec_buckets = 0;

@@ -70,15 +70,9 @@ static int refresh_table_desc(ml_ctx *ctx) {
     if (!ctx->tables_dirty) return ML_OK;
     std::vector<TableDesc> h(MAX_SLOTS + 1);
     memset(h.data(), 0, h.size() * sizeof(TableDesc));
-    ctx->simple_orders = true;
     for (int s = 0; s <= MAX_SLOTS; ++s) {
         const TableSlot &t = (s == MAX_SLOTS) ? ctx->center : ctx->slots[s];
         if (!t.present) continue;
-        for (int o = 0; o < t.n_orders; ++o) {
-            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI)), oy = std::lrint(t.h_order_k[2 * o + 1] / (2 * M_PI));
-            if (ox < -1 || ox > 1 || oy != 0) ctx->simple_orders = false;
-        }
-        if (t.n_orders > 15) ctx->simple_orders = false;   // (a collection descriptor holds 15 order codes)
         TableDesc &d = h[s];
         d.axis0 = t.axis0.as<double>();
         d.axis1 = t.axis1.as<double>();
@@ -164,16 +158,48 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     // (v[..., i2] * (1 - t2) + v[..., i2 + 1] * t2), complex [order][n0][n1][4], and the
     // per-ring order wavenumbers ox*2*pi/grating_period, oy*2*pi/lateral_period
     // (nearfield.py:268-269: per-sample expressions of per-ring constants).
-    // SIMPLE order sets: cell blocks (common.h) - per ring and table cell the 48 complex a sample in
-    // that cell interpolates from, contiguous, orders in canonical slots.  tab_off counts BLOCKS then.
-    const bool simple = ctx->simple_orders;
-    auto canon_slots = [](const TableSlot &t, int *slot_of) {   // canonical order -> index in t's list, -1: absent
-        slot_of[0] = slot_of[1] = slot_of[2] = -1;
-        for (int o = 0; o < t.n_orders; ++o) {
-            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI));
-            slot_of[ox == 0 ? 0 : ox < 0 ? 1 : 2] = o;
-        }
+    // SIMPLE order sets: cell blocks (common.h) - per ring and table cell the 16 n_slots complex a sample
+    // in that cell interpolates from, contiguous, the collection's orders from the lowest ox upwards.
+    // tab_off counts UNITS of 16 complex then.
+    // A lens is SIMPLE when every table it uses - the collections of its rings and, if it has centre
+    // cells, the centre table - holds orders (ox, 0) with |ox| <= SIMPLE_MAX_OX only.
+    struct Canon {
+        int n = 0, lo = 0, present = 0;   // slots lo ... lo + n - 1; bit s: the data holds order lo + s
+        int idx[SIMPLE_MAX_SLOTS];        // slot -> index in the table's own order list, -1: a hole (zeros)
     };
+    auto canon_orders = [](const TableSlot &t, Canon &L) {   // false: not a simple order set
+        L = Canon();
+        int lo = SIMPLE_MAX_OX + 1, hi = -SIMPLE_MAX_OX - 1;
+        for (int o = 0; o < t.n_orders; ++o) {
+            const long ox = std::lrint(t.h_order_k[2 * o] / (2 * M_PI)), oy = std::lrint(t.h_order_k[2 * o + 1] / (2 * M_PI));
+            if (oy != 0 || ox < -SIMPLE_MAX_OX || ox > SIMPLE_MAX_OX) return false;
+            lo = std::min(lo, (int)ox);
+            hi = std::max(hi, (int)ox);
+        }
+        L.lo = lo;
+        L.n = hi - lo + 1;
+        for (int s = 0; s < L.n; ++s) L.idx[s] = -1;
+        for (int o = 0; o < t.n_orders; ++o) {
+            const int s = (int)std::lrint(t.h_order_k[2 * o] / (2 * M_PI)) - lo;
+            if (L.idx[s] >= 0) return false;   // (an order listed twice)
+            L.idx[s] = o;
+            L.present |= 1 << s;
+        }
+        return true;
+    };
+    Canon canon[MAX_RING_COLLS], canon_center;
+    bool simple = true;
+    for (int c = 0; c < ctx->n_colls; ++c) simple = canon_orders(ctx->slots[ctx->coll_slot[c]], canon[c]) && simple;
+    if (ctx->center.present) simple = canon_orders(ctx->center, canon_center) && simple;
+    if (simple != ctx->simple_orders) {
+        // which patch lists exist and what a synthesis leaves behind depend on the kernel family
+        ctx->geo_key[0] = -1;
+        ctx->n_active[0] = -1;
+        ctx->zero_key[1] = -1;
+    }
+    ctx->simple_orders = simple;
+    int dense_of[MAX_SLOTS];
+    for (int c = 0; c < ctx->n_colls; ++c) dense_of[ctx->coll_slot[c]] = c;
     std::vector<long long> tab_off(ctx->n_rings);
     std::vector<int32_t> ok_off(ctx->n_rings);
     size_t tab_total = 0, ok_total = 0;
@@ -181,30 +207,31 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
         tab_off[r] = (long long)tab_total;
         ok_off[r] = (int32_t)ok_total;
-        tab_total += simple ? (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0)
+        tab_total += simple ? (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0) * canon[dense_of[ctx->h_ring_gc[r]]].n
                             : (size_t)t.n_orders * t.n0 * t.n1 * 4;
         ok_total += (size_t)t.n_orders * 4;
     }
-    if (simple) ML_REQUIRE(tab_total < (1ull << 31), "ring tables of %zu cell blocks: too large", tab_total);
-    std::vector<double> tab(tab_total * 2 * (simple ? CELL_BLOCK : 1)), ok(ok_total);
+    if (simple) ML_REQUIRE(tab_total < (1ull << 27), "ring tables of %zu block units: too large", tab_total);   // (nearfield_simple.hip parks block | collection << 27)
+    // (simple: a wave that straddles two collections stages every block at the larger one's size -
+    // the tail of the array is padded by a largest block so that the surplus stays inside it)
+    std::vector<double> tab((tab_total + (simple ? SIMPLE_MAX_SLOTS + 1 : 0)) * 2 * (simple ? UNIT : 1), 0.0), ok(ok_total);
     for (int r = 0; r < ctx->n_rings; ++r) {
         const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
         const double w1 = t2[r], w0 = 1 - t2[r];
         if (simple) {
-            int slot_of[SIMPLE_ORDERS];
-            canon_slots(t, slot_of);
-            double *dst = tab.data() + (size_t)tab_off[r] * CELL_BLOCK * 2;
+            const Canon &L = canon[dense_of[ctx->h_ring_gc[r]]];
+            double *dst = tab.data() + (size_t)tab_off[r] * UNIT * 2;
             for (int c0 = 0; c0 < t.n0 - 1; ++c0)
                 for (int c1 = 0; c1 < t.n1 - 1; ++c1)
-                    for (int oc = 0; oc < SIMPLE_ORDERS; ++oc)
+                    for (int oc = 0; oc < L.n; ++oc)
                         for (int nd = 0; nd < 4; ++nd) {
                             const int a = (c0 + (nd >> 1)) * t.n1 + c1 + (nd & 1);
-                            if (slot_of[oc] < 0) {
+                            if (L.idx[oc] < 0) {   // a hole in the list
                                 for (int q = 0; q < 8; ++q) *dst++ = 0.0;
                                 continue;
                             }
                             const double *lo = t.h_values.data() +
-                                               ((((size_t)slot_of[oc] * t.n0 * t.n1 + a) * t.n2 + i2[r]) * 4) * 2;
+                                               ((((size_t)L.idx[oc] * t.n0 * t.n1 + a) * t.n2 + i2[r]) * 4) * 2;
                             const double *hi = lo + 8;
                             for (int q = 0; q < 8; ++q) *dst++ = lo[q] * w0 + hi[q] * w1;
                         }
@@ -242,16 +269,10 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         C.flags = d.uniform ? 1 : 0;
         C.lim0 = t.n0 - 2;
         C.lim1 = t.n1 - 2;
-        C.present = C.order_of = 0;
-        if (simple) {
-            int slot_of[SIMPLE_ORDERS];
-            canon_slots(t, slot_of);
-            for (int oc = 0; oc < SIMPLE_ORDERS; ++oc)
-                if (slot_of[oc] >= 0) {
-                    C.present |= 1 << oc;
-                    C.order_of |= slot_of[oc] << (4 * oc);
-                }
-        }
+        C.n_slots = simple ? canon[c].n : 0;
+        C.ox_lo = simple ? canon[c].lo : 0;
+        C.present = simple ? canon[c].present : 0;
+        C.pad = 0;
         for (int k = 0; k < 4; k += 2) {   // a NaN bound leaves the range empty: every sample then reads its own
             ctx->ring_bounds_all[k] = t.bounds[k] >= ctx->ring_bounds_all[k] ? t.bounds[k]
                                       : t.bounds[k] == t.bounds[k] ? ctx->ring_bounds_all[k] : INFINITY;
@@ -280,23 +301,23 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     // centre table for the fast kernel: [order][n0][n1][4][K] instead of [order][n0][n1][K][4],
     // so that the K cell types of one amplitude are contiguous (lanes of a wave hold many
     // different cell types; this way one load instruction touches 3 cache lines, not 12)
-    // Simple order sets: CELL BLOCKS (common.h CENTER_BLOCK) - complex [order 3][i0][i1][group][node 4][amplitude 4][20]:
-    // orders in canonical slots (zeros for an order the set lacks), per table cell and group of 20 cell
-    // types the 320 complex its samples interpolate from, contiguous.
+    // Simple order sets: CELL BLOCKS (common.h CENTER_BLOCK) - complex [order slot][i0][i1][group][node 4][amplitude 4][20]:
+    // the table's orders from the lowest ox upwards, per table cell and group of 20 cell types the 320
+    // complex its samples interpolate from, contiguous (a hole in the list: zeros).
     std::vector<double> cq;
-    ctx->center_present = ctx->center_order_of = 0;
+    ctx->center_n_slots = ctx->center_lo = ctx->center_present_mask = 0;
     if (ctx->center.present && simple) {
         const TableSlot &t = ctx->center;
-        int slot_of[SIMPLE_ORDERS];
-        canon_slots(t, slot_of);
+        const Canon &L = canon_center;
+        ctx->center_n_slots = L.n;
+        ctx->center_lo = L.lo;
+        ctx->center_present_mask = L.present;
         const int groups = (t.n2 + CENTER_GROUP - 1) / CENTER_GROUP;
         const size_t cells = (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0);
-        cq.assign((size_t)SIMPLE_ORDERS * cells * groups * CENTER_BLOCK * 2, 0.0);
-        for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
-            const int o = slot_of[oc];
+        cq.assign((size_t)L.n * cells * groups * CENTER_BLOCK * 2, 0.0);
+        for (int oc = 0; oc < L.n; ++oc) {
+            const int o = L.idx[oc];
             if (o < 0) continue;
-            ctx->center_present |= 1 << oc;
-            ctx->center_order_of |= o << (4 * oc);
             for (int c0 = 0; c0 < t.n0 - 1; ++c0)
                 for (int c1 = 0; c1 < t.n1 - 1; ++c1)
                     for (int g = 0; g < groups; ++g) {
@@ -1045,6 +1066,20 @@ int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violatio
             }
     }
     if (n_violations) *n_violations = count;
+    return ML_OK;
+}
+
+int ml_nearfield_kernel_info(ml_ctx *ctx, int *family, int *ring_orders_max, int *centre_orders) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    if (ctx->tables_dirty || !ctx->have_layout) {
+        set_error("no near field has been synthesised from the current tables and layout");
+        return ML_ESTATE;
+    }
+    int widest = 0;
+    for (int c = 0; c < ctx->n_colls; ++c) widest = std::max(widest, ctx->h_coll[c].n_slots);
+    if (family) *family = ctx->simple_orders ? 1 : 0;
+    if (ring_orders_max) *ring_orders_max = ctx->simple_orders ? widest : 0;
+    if (centre_orders) *centre_orders = ctx->simple_orders ? ctx->center_n_slots : 0;
     return ML_OK;
 }
 

@@ -169,8 +169,9 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     for (int k = 0; k < 3; ++k) a.n_active[k] = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;
-    a.center_present = ctx->center_present;
-    a.center_order_of = ctx->center_order_of;
+    a.center_n_slots = ctx->center_n_slots;
+    a.center_lo = ctx->center_lo;
+    a.center_present = ctx->center_present_mask;
     for (int k = 0; k < 4; ++k) a.ring_bounds_all[k] = ctx->ring_bounds_all[k];
     a.fields = ctx->fields.as<double>();
     a.partial_power = ctx->partial_power.as<double>();

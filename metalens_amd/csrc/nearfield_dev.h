@@ -99,10 +99,10 @@ struct NfArgs {
     // the listed centre kernel that the power is not its business this time
     const int *list_count;
     int first_pass;
-    // every table of the lens holds orders ox = -1, 0, 1 with oy = 0 only: the kernels that build
-    // an order's phasor by one product run (nearfield_fast.hip order_phasor), else the general ones
+    // every table of the lens holds orders (ox, 0), |ox| <= 5, only: the kernels that build an
+    // order's phasor by products run (nearfield_simple.hip), else the general ones
     int simple_orders;
-    int center_present, center_order_of;   // centre table, simple order sets: as CollDesc::present / order_of
+    int center_n_slots, center_lo, center_present;   // centre table, simple order sets: as CollDesc::n_slots / ox_lo / present
     // the (ux', uy') range every ring table covers (intersection of their bounds: lo0, hi0, lo1, hi1);
     // a sample inside it cannot trip a table bound, and only the others read their ring's own bounds
     double ring_bounds_all[4];
@@ -453,7 +453,7 @@ __device__ __forceinline__ void store_fields(const NfArgs &a, int member, int i,
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a);
 // writes the number of per-block power partials it produces to *n_partials
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
-// nearfield_simple.hip: the kernels of the round lens' order set (ox in {-1, 0, 1}, oy = 0)
+// nearfield_simple.hip: the kernels of a round lens' order sets (orders (ox, 0), |ox| <= 5, per collection)
 int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a);
 // the source-independent records of the current (grid, layout, tie answers)
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a);

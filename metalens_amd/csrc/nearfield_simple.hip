@@ -1,40 +1,60 @@
-// Near-field synthesis for the order set of a round lens (reference nearfield.py:208-477 per
-// aperture sample): every table of the lens - ring collections and centre - holds diffraction
-// orders ox in {-1, 0, 1}, oy = 0 only, i.e. every order of a round lens' rings that propagates in
-// air.  Any other order set runs the general kernels of nearfield_fast.hip; the source-independent
-// decisions of a sample (ring, sector, nearest cell) come from the records of
-// nearfield_geometry_kernel either way.
+// Near-field synthesis for the order sets of a round lens (reference nearfield.py:208-477 per
+// aperture sample): every table of the lens - ring collections and centre - holds orders (ox, 0) with
+// |ox| <= 5 only, each collection its OWN list of them.  That is what characterize() emits for the
+// rings of a round lens: it keeps every (ox, oy) in [-5, 5]^2 that propagates in air at some tabulated
+// direction (grating.lua:417-423), and around the design direction u_x ~ lambda / period that is
+// (1 + ox)^2 u_x^2 < 1 - (-1, 0) the design order, (0, 0) and (-2, 0) always, (+1, 0) and (-3, 0)
+// inside 30 degrees, and so on inwards - while oy != 0 needs a lateral period above a wavelength,
+// which a lens that is to diffract into one order along y does not have.  Any other order set
+// (oy != 0) runs the general kernels of nearfield_fast.hip; the source-independent decisions of a
+// sample (ring, sector, nearest cell) come from the records of nearfield_geometry_kernel either way.
 //
-// What the restricted order set buys (the kernel is bound by fp64 vector ISSUE: every vector
+// What the restricted order sets buy (the kernel is bound by fp64 vector ISSUE: every vector
 // instruction holds its SIMD for four cycles, so the budget is instructions per sample):
-//   * CANONICAL order slots 0: (0,0), 1: (-1,0), 2: (+1,0) in every table (ctx.hip; an order a
-//     collection lacks is a block of zeros): the order loop is three straight-line copies with
-//     the order known at compile time - no order codes, selects or loop control;
+//   * CANONICAL order slots per collection - by |ox|, the negative one first: 0, -1, +1, -2, +2, ...,
+//     whichever of them the collection's data holds (CollDesc::ox_list, ctx.hip): the order loop runs
+//     over the slots of the wave's own collection with the order in a SCALAR register - a collection
+//     of three orders pays for three, its neighbour of five for five;
 //   * the phasor of order (ox, 0) at a sample is exp(i ((k u_x' + ox G) x' + k u_y' y'))
 //     (nearfield.py:268-269,291; centre :391-409) = E0 * X^ox with E0 the order-(0,0) phasor - into
 //     which the propagation phasor exp(i k |grating centre - source|) is folded, its exact ~1e4 rad
 //     argument reduced to [-pi/4, pi/4] + quadrants first - and X = exp(i G x'): two sincos per
-//     sample, the +-1 orders one product each;
-//   * k_x' of order (ox, 0) = k u_x' + ox (2 pi / period), the reference's own expression
-//     (ox*2*pi/grating_period is exactly +-(2 pi / period) for ox = +-1);
-//   * CELL BLOCKS (common.h): the 48 complex a sample in table cell (i0, i1) of its ring
+//     sample, then one product per order and one more per |ox| level beyond the first (X^2, X^3, ...);
+//   * k_x' of order (ox, 0) = k u_x' + ox (2 pi / period) in one rounding - the reference's own
+//     expression for |ox| <= 2 (ox*2*pi/grating_period is exactly ox (2 pi / period) there), within an
+//     ulp of it beyond;
+//   * CELL BLOCKS (common.h): the 16 n_slots complex a sample in table cell (i0, i1) of its ring
 //     interpolates from are contiguous, so a (ring, cell) block is named by ONE 32-bit number -
 //     the key the lanes of a patch are matched by, and, read back from the lead lane, the scalar
-//     base of the one wave-wide load that stages the block through LDS (lane l < 48 fetches
-//     element l): no per-slot stride / order-count read-backs, no per-lane address arithmetic;
+//     base of the wave-wide loads that stage the block through LDS (lane l fetches element l): no
+//     per-slot stride / order-count read-backs, no per-lane address arithmetic;
 //   * one source (NP = 1): the two polarisation weights ride in the interpolation weights.
 // Amplitude-type arithmetic (direction cosines, incident amplitudes, interpolation, the 2 x 2
 // polarisation algebra, small-argument sin / cos) is accurate to a few ulp; what feeds LARGE phases
 // - x', y', the propagation distance and k * distance - follows the reference operation by
 // operation (this file is compiled with -ffp-contract=off; every fma() here is deliberate).
 #include <algorithm>
+#include <type_traits>
 
 #include "nearfield_math.h"
 
 namespace ml {
 
-constexpr int SK_SLOTS = 6;                     // distinct (ring, cell) blocks staged per round
-constexpr int SK_PITCH = CELL_BLOCK + 1;        // +1: blocks start in different 16-byte bank slots
+constexpr int SK_SLOTS = 6;                     // distinct (ring, cell) blocks staged per round, at most
+// complex in the ring kernel's block buffer.  Twenty waves of a CU (five per SIMD) could have 8 KB each
+// of its 160 KB - but at exactly that size a wave that ends leaves a hole only an identical neighbour
+// fits and the measured occupancy drops by 6 %: a lens of narrow collections (up to SIMPLE_NARROW_SLOTS
+// orders: six blocks at a fixed pitch) takes 6.2 KB, the wide instantiation ML_RING_LDS_WIDE complex
+#ifndef ML_RING_LDS_WIDE
+#define ML_RING_LDS_WIDE 448
+#endif
+constexpr int RING_LDS_NARROW = SK_SLOTS * (SIMPLE_NARROW_SLOTS * UNIT + 1), RING_LDS = ML_RING_LDS_WIDE;
+// order slots per pass of the wide instantiation: what n blocks leave each other of the buffer,
+// (RING_LDS / n - 1) / 16 for n = 1 ... 6 blocks, four bits each
+constexpr unsigned slots_per_pass(int n) { return (unsigned)((RING_LDS / n - 1) / UNIT < 15 ? (RING_LDS / n - 1) / UNIT : 15); }
+constexpr unsigned UPP_TABLE = slots_per_pass(1) | slots_per_pass(2) << 4 | slots_per_pass(3) << 8 | slots_per_pass(4) << 12 |
+                               slots_per_pass(5) << 16 | slots_per_pass(6) << 20;
+static_assert(slots_per_pass(SK_SLOTS) >= 1, "block buffer too small");
 constexpr int SK_TYPES = 20;                    // centre: cell types per staged block (the reference's default K, lens_center.py:28)
 static_assert(SK_TYPES == CENTER_GROUP, "the centre table's cell blocks hold groups of SK_TYPES types");
 
@@ -133,21 +153,49 @@ struct OrderFactors {
     c2 ph;
 };
 
-template <int OX>
-__device__ __forceinline__ bool order_setup(const OrderShared &S, const Consts &K, double &kx, double &kt2) {
-    kx = OX == 0 ? S.kx0 : OX > 0 ? S.kx0 + S.G : S.kx0 - S.G;
-    kt2 = kx * kx + S.ky2;
-    return kt2 <= K.kvac2;   // propagating in air (nearfield.py:279-280, 398)
+// (double)ox of a wave-uniform |ox| <= 5, put together on the SCALAR unit (a v_cvt_f64_i32 is a vector
+// instruction): the high words of 1.0 ... 5.0 are 0x3ff00000 + (0, 4, 6, 8, 9) << 18
+__device__ __forceinline__ double small_int_as_double(int ox) {
+    const unsigned m = (unsigned)(ox < 0 ? -ox : ox);
+    unsigned hi = m ? 0x3ff00000u + (((0x98640u >> (4 * (m - 1))) & 15u) << 18) : 0u;
+    hi |= ox < 0 ? 0x80000000u : 0u;
+    return __longlong_as_double((long long)((unsigned long long)hi << 32));
 }
 
-template <int OX>
-__device__ __forceinline__ void order_factors_s(OrderFactors &f, const OrderShared &S, const Consts &K, double kx,
+// The orders of a collection are walked UPWARDS from its lowest, ox = lo, lo + 1, ..., hi, with the
+// order's phasor and k_x' carried along: ph <- ph X and k_x' <- k_x' + G per step (one complex product
+// and one addition per order, whatever |ox|), started at E0 conj(X)^|lo| and k u_x' + lo G.  Nothing
+// of an order list is decoded per order: the loop knows a slot count and a bit mask of the slots
+// the collection's data really holds.
+struct OrderWalk {
+    c2 ph;       // E0 X^ox
+    double kx;   // k u_x' + ox G (ox = lo: one rounding, the reference's expression up to |ox| = 2; then summed)
+};
+__device__ __forceinline__ void walk_start(OrderWalk &w, const OrderShared &S, int lo) {   // lo: wave-uniform
+    w.ph = S.E0;
+#pragma nounroll
+    for (int l = lo; l < 0; ++l) w.ph = cmulf_conj(w.ph, S.X);
+#pragma nounroll
+    for (int l = 0; l < lo; ++l) w.ph = cmulf(w.ph, S.X);
+    w.kx = fma(small_int_as_double(lo), S.G, S.kx0);
+}
+__device__ __forceinline__ void walk_step(OrderWalk &w, const OrderShared &S) {
+    w.ph = cmulf(w.ph, S.X);
+    w.kx += S.G;
+}
+
+// E-from-H factors of the walk's current order; false: evanescent in air (nearfield.py:279-280, 398)
+__device__ __forceinline__ bool order_setup(const OrderShared &S, const Consts &K, double kx, double &kt2) {
+    kt2 = kx * kx + S.ky2;
+    return kt2 <= K.kvac2;
+}
+__device__ __forceinline__ void order_factors_s(OrderFactors &f, const OrderShared &S, const Consts &K, const OrderWalk &w,
                                                 double kt2) {
     const double g = K.efh * rsqrt_fast(K.kg2 - kt2);   // Z0 / (n k_glass kz)
-    f.cxy = (kx * S.ky) * g;
-    f.cxx = (K.kg2 - kx * kx) * g;
+    f.cxy = (w.kx * S.ky) * g;
+    f.cxx = (K.kg2 - w.kx * w.kx) * g;
     f.cyy = (S.ky2 - K.kg2) * g;
-    f.ph = OX == 0 ? S.E0 : OX > 0 ? cmulf(S.E0, S.X) : cmulf_conj(S.E0, S.X);
+    f.ph = w.ph;
 }
 
 // V = U ph; H += V; E += factors x V (U_fy <-> H along x', U_fx <-> H along y')
@@ -172,14 +220,15 @@ __device__ __forceinline__ void order_accumulate(AccS &acc, const OrderFactors &
 // along y' <-> x table, along x' <-> y table), so that the interpolation yields
 // U_fy = sum_p Hw_p a_fy,p and U_fx = sum_p Hw_p a_fx,p directly.  NP > 1: wa = the interpolation
 // weights, the members' polarisation weights in Hwx / Hwy.
-template <int OX, int NP, int STRIDE>
+// `w` = the walk at this order; `mine`: the lane belongs to the pass (its collection, its round).
+template <int NP, int STRIDE>
 __device__ __forceinline__ void order_simple(AccS *acc, const double2 *blk, const double *wa, const double *wb,
                                              const double *Hwx, const double *Hwy, const OrderShared &S,
-                                             const Consts &K) {
-    double kx, kt2;
-    if (!order_setup<OX>(S, K, kx, kt2)) return;
+                                             const Consts &K, const OrderWalk &w, bool mine) {
+    double kt2;
+    if (!((int)order_setup(S, K, w.kx, kt2) & (int)mine)) return;   // (one mask for both)
     OrderFactors f;
-    order_factors_s<OX>(f, S, K, kx, kt2);
+    order_factors_s(f, S, K, w, kt2);
     if (NP == 1) {
         double ufy_r, ufy_i, ufx_r, ufx_i;
 #pragma unroll
@@ -248,15 +297,15 @@ __device__ __forceinline__ void locate_axis(const double *axis, int n, double x,
 // the bound reports of a sample outside its table, per order in the reference's check order
 // (nearfield.py:294-305, 412-419): rare path, entered by the whole wave only if some lane needs it
 template <bool RING>
-__device__ __forceinline__ void report_orders(const NfArgs &a, double kvac2, double kx0, double G, double ky, int present,
-                                              int order_of, int slot, double u, double v, double period) {
+__device__ __forceinline__ void report_orders(const NfArgs &a, double kvac2, double kx0, double G, double ky, int n_slots,
+                                              int lo, unsigned present, int slot, double u, double v, double period) {
     const TableDesc &T = RING ? a.tables[slot] : a.center_desc;
     const double ky2 = ky * ky;
-#pragma unroll
-    for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
-        const double kx = oc == 0 ? kx0 : oc == 2 ? kx0 + G : kx0 - G;
-        if (((present >> oc) & 1) && kx * kx + ky2 <= kvac2)
-            check_bounds(a, T, slot, (order_of >> (4 * oc)) & 15, u, v, period, RING);
+    for (int oc = 0; oc < n_slots; ++oc) {
+        if (!((present >> oc) & 1u)) continue;
+        const double kx = fma((double)(lo + oc), G, kx0);
+        // (the order's index in the table's own, sorted list = the slots present below it)
+        if (kx * kx + ky2 <= kvac2) check_bounds(a, T, slot, __popc(present & ((1u << oc) - 1u)), u, v, period, RING);
     }
 }
 
@@ -324,7 +373,6 @@ __device__ __forceinline__ void staged_wait() {
 }
 
 constexpr int CB = CENTER_BLOCK;   // complex per staged centre block
-constexpr int RING_LDS = SK_SLOTS * SK_PITCH;   // complex: the ring blocks of a round
 
 typedef int int2v __attribute__((ext_vector_type(2)));
 
@@ -356,11 +404,10 @@ enum { PART_RING = 1, PART_CENTRE = 2 };
 #define ML_NF_KEEP_ROT 0
 #endif
 
-template <int NP, int PART, bool LISTED>
+template <int NP, int PART, bool LISTED, bool WIDE>
 __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab, double2 *s_tab1, int bx, int by) {
     const int lane = threadIdx.x;
     const unsigned lane_off = (unsigned)lane * 16u;
-    const ml_nearfield_params &p = a.p;
     Consts K;
     load_consts(a, K);
     const int i = by * 8 + (lane >> 3);   // x index
@@ -469,6 +516,7 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     const int grp = which / SK_TYPES;
     const int cblk = (i0 * (T.n1 - 1) + i1) * groups + grp;   // the sample's block of order 0
     const size_t order_blocks = (size_t)(T.n0 - 1) * (T.n1 - 1) * groups;
+    const int n_slots = a.center_n_slots;
     OrderShared S;   // (centre samples only; no defaults: each costs a move and a select)
     double wa[4], wb[4];
     if (cen) {
@@ -511,22 +559,21 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         todo &= ~__ballot(mine);
         const double2 *src = a.center_tab + (size_t)(unsigned)kl * CB;
         stage_block<CB / 64>(src, s_tab, lane_off);
-#pragma unroll
-        for (int oc = 0; oc < SIMPLE_ORDERS; ++oc) {
-            if (oc + 1 < SIMPLE_ORDERS) {
-                stage_block<CB / 64>(src + (oc + 1) * order_blocks * CB, ((oc + 1) & 1) ? s_tab1 : s_tab, lane_off);
+        OrderShared R = S;
+        asm volatile("" : "+v"(R.kx0));   // (see the ring samples' order loop)
+        OrderWalk W;
+        walk_start(W, R, a.center_lo);
+#pragma nounroll
+        for (int oc = 0; oc < n_slots; ++oc) {   // wave-uniform
+            const double2 *cur = (oc & 1) ? s_tab1 : s_tab;
+            if (oc + 1 < n_slots) {
+                stage_block<CB / 64>(src + (size_t)(oc + 1) * order_blocks * CB, (oc & 1) ? s_tab : s_tab1, lane_off);
                 staged_wait<CB / 64>();
             } else {
                 staged_wait<0>();
             }
-            if (mine) {
-                OrderShared R = S;
-                asm volatile("" : "+v"(R.kx0));   // (see the ring samples' order loop)
-                const double2 *blk = ((oc & 1) ? s_tab1 : s_tab) + mine_off;
-                if (oc == 0) order_simple<0, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, K);
-                if (oc == 1) order_simple<-1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, K);
-                if (oc == 2) order_simple<1, NP, SK_TYPES>(acc, blk, wa, wb, Hy_i, Hx_i, R, K);
-            }
+            if ((a.center_present >> oc) & 1) order_simple<NP, SK_TYPES>(acc, cur + mine_off, wa, wb, Hy_i, Hx_i, R, K, W, mine);
+            walk_step(W, R);
             // (every LDS read of this order has come back - its values were used - before the
             // load that overwrites its buffer is issued, one iteration on)
             __builtin_amdgcn_sched_barrier(0);
@@ -534,8 +581,8 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     }
     if (__ballot(cen && out_c)) {
         if (cen && out_c)
-            report_orders<false>(a, K.kvac2, K.kvac * ux, T.center_g[0], K.kvac * uy, a.center_present, a.center_order_of,
-                                 MAX_SLOTS, ux, uy, 0.0);
+            report_orders<false>(a, K.kvac2, K.kvac * ux, T.center_g[0], K.kvac * uy, a.center_n_slots, a.center_lo,
+                                 (unsigned)a.center_present, MAX_SLOTS, ux, uy, 0.0);
     }
     if (cen && K.premod) {
         // input modulation of the far-field plan's stage 1, applied here for free (NfArgs)
@@ -572,6 +619,11 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     }
     double uxp, uyp, t0, t1, xp, yp;
     int cell = 0;
+    // the grating collection being worked on and its order list, in scalar registers: slot count,
+    // lowest order, which slots its data holds (CollDesc)
+    int c_cur = -1, ns = 1, lo = 0;
+    unsigned present = 0;
+    bool several = false;   // the wave's ring samples belong to more than one collection (wave-uniform)
     if (peri) {
         ML_MARK(3, cs.x + r0.x + r1.x);   // (ring waves: the ring's record and rotation have arrived)
         // phase-critical: local coordinates, exact operation order (nearfield.py:200-201)
@@ -587,31 +639,79 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         const bool mc = peri && cell_type == c0;
         pm &= ~__ballot(mc);
         const CollDesc &C = a.coll[c0];   // wave-uniform index: scalar loads
+        // (the whole descriptor in ONE round of scalar loads, pinned: fetched where it is used, the flag
+        // test, the axes and the order list each wait for a round trip of their own)
+        double ax0 = C.uni_ax[0], ax2 = C.uni_ax[2], ax3 = C.uni_ax[3], ax5 = C.uni_ax[5], lim0 = C.lim0, lim1 = C.lim1;
+        int flags = C.flags, n1m1 = C.n1 - 1, c_ns = C.n_slots, c_lo = C.ox_lo, c_present = C.present;
+        asm volatile("" : "+s"(ax0), "+s"(ax2), "+s"(ax3), "+s"(ax5), "+s"(lim0), "+s"(lim1), "+s"(flags), "+s"(n1m1),
+                     "+s"(c_ns), "+s"(c_lo), "+s"(c_present));
+        if (c_cur < 0) {
+            c_cur = c0;
+            ns = c_ns;
+            lo = c_lo;
+            present = (unsigned)c_present;
+        } else {
+            several = true;
+        }
         if (mc) {
             int i0, i1;
-            if (C.flags & 1) {
-                locate_uniform(C.uni_ax, C.lim0, C.lim1, uxp, uyp, i0, t0, i1, t1);
+            if (flags & 1) {
+                const double uni[6] = {ax0, 0.0, ax2, ax3, 0.0, ax5};
+                locate_uniform(uni, lim0, lim1, uxp, uyp, i0, t0, i1, t1);
             } else {
                 const TableDesc &T = a.tables[a.gc[idx - 1]];
                 locate_axis(T.axis0, T.n0, uxp, i0, t0);
                 locate_axis(T.axis1, T.n1, uyp, i1, t1);
             }
-            cell = i0 * (C.n1 - 1) + i1;
+            // (i0 (n1 - 1) + i1) n_slots, in units of 16 complex; 24-bit products (full rate): tables of
+            // up to 4096 x 4096 cells
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(cell) : "v"(i0), "s"(n1m1), "v"(i1));
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(cell) : "v"(cell), "s"(c_ns));
         }
     }
-    // the sample's (ring, table cell) block: what the lanes of the wave are matched by
+    // the sample's (ring, table cell) block, by its first unit: what the lanes of the wave are matched by
     const int blk = peri ? (int)(__double_as_longlong(r1.y) & 0x7fffffffll) + cell : -1;
+    // the table-bound tests do not depend on the order: evaluated once; only a failure takes the
+    // reporting path (per order, in the reference's check order).  A sample inside the range
+    // EVERY ring table covers, on a ring whose period its table covers (bit 32 of the ring record),
+    // cannot fail; only the others read their table's bounds.  (In front of the block matching: the four
+    // bounds leave their scalar registers before the matching needs its own.)
+    bool outside = false;
+    if (peri) {
+        outside = (int)(uxp < K.b0) | (int)(uxp > K.b1) | (int)(uyp < K.b2) | (int)(uyp > K.b3) |
+                  (int)((__double_as_longlong(r1.y) >> 32) & 1);
+        if (outside) {
+            const double *b = a.tables[a.gc[idx - 1]].bounds;
+            const double period = r0.y;
+            outside = (int)(uxp < b[0]) | (int)(uxp > b[1]) | (int)(uyp < b[2]) | (int)(uyp > b[3]) |
+                      (int)(period < b[4]) | (int)(period > b[5]);
+        }
+    }
     // ---- LDS-staged cell blocks.  The 64 samples of a patch fall into 2-4 rings and almost always
     // one table cell: the wave finds its distinct blocks and fetches each ONCE - block number from
-    // the lead lane -> scalar base, lane l < 48 loads element l straight into LDS - and every lane
-    // reads its block from there (equal addresses broadcast: a wave-wide 16-byte read costs 4 cycles
-    // instead of the 16 of a gather through the vector memory path).  A round = SK_SLOTS distinct
-    // blocks; one round unless a wave spans many rings.
-    unsigned long long todo = __ballot(blk >= 0);
-    int myslot;
-    auto match_and_stage = [&]() {
+    // the lead lane -> scalar base, lane l loads element l straight into LDS - and every lane reads
+    // its block from there (equal addresses broadcast: a wave-wide 16-byte read costs 4 cycles
+    // instead of the 16 of a gather through the vector memory path).
+    // A ROUND serves up to SK_SLOTS distinct blocks of ONE collection (one round unless a wave spans
+    // many rings or straddles two collections).  The buffer holds RING_LDS complex: a round of n blocks
+    // of a collection with more orders than fit at once goes through it in PASSES of `upp` order slots
+    // per block - all blocks, some orders - so that every order is evaluated once per round however
+    // many blocks there are (staging all orders of as many blocks as fit would evaluate the whole order
+    // list again for every further group of blocks: eleven orders, three rings = twenty-two for eleven).
+    // Collections of up to SMALL_SLOTS orders - the three-order tables of SURVEY.md 8(d), the outer collections
+    // of a real lens - always fit with six blocks at a FIXED pitch, in one pass: that case is compiled on
+    // its own (begin_round / finish_round with SMALL = true: constant LDS addresses, one staging load per
+    // block, the order loop unrolled over its four possible slots), so that it pays nothing for the
+    // generality of the other.
+    unsigned long long todo = __ballot(peri && cell_type == c_cur);      // lanes of the current collection not served yet
+    unsigned coll_done = 1u << (c_cur & 31);   // collections whose lanes have been (or are being) served: bit per dense number
+    int myslot, n_blocks, upp, pitch;
+    int lead[SK_SLOTS];
+    constexpr int SMALL_SLOTS = SIMPLE_NARROW_SLOTS, SMALL_PITCH = SMALL_SLOTS * UNIT + 1;
+    static_assert(SK_SLOTS * SMALL_PITCH <= RING_LDS_NARROW, "six small blocks fit");
+    auto match = [&]() {
         myslot = -1;
-        int lead[SK_SLOTS];
+        n_blocks = 0;
         unsigned long long rest = todo;
 #pragma unroll
         for (int s = 0; s < SK_SLOTS; ++s) {
@@ -619,41 +719,53 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
             if (rest) {   // wave-uniform
                 const int kl = __builtin_amdgcn_readlane(blk, __ffsll((long long)rest) - 1);
                 // every lane with this block is served now (so no served lane can match a later
-                // lead, whose block differs) and kl >= 0 excludes the lanes without a block
+                // lead, whose block differs); lanes without a block hold -1
                 const bool mine = blk == kl;
                 if (mine) myslot = s;
                 rest &= ~__ballot(mine);
                 lead[s] = kl;
+                n_blocks = s + 1;
             }
         }
         todo = rest;
-        if (lane < CELL_BLOCK) {
+    };
+    // one pass' loads: order slots [s0, s0 + min(upp, ns - s0)) of every block of the round
+    auto stage = [&](int s0) {
+        const int len = min(upp, ns - s0) * UNIT;   // complex per block in this pass (wave-uniform)
 #pragma unroll
-            for (int s = 0; s < SK_SLOTS; ++s)
-                if (lead[s] >= 0)
-                    stage_block<1>(K.ring_tab + (size_t)(unsigned)lead[s] * CELL_BLOCK, s_tab + s * SK_PITCH, lane_off);
+        for (int m = 0; m * 64 < UNIT * SIMPLE_MAX_SLOTS; ++m)
+            if (m * 64 < len && lane < len - m * 64) {   // (the first test is wave-uniform)
+#pragma unroll
+                for (int s = 0; s < SK_SLOTS; ++s)
+                    if (lead[s] >= 0)
+                        stage_block<1>(K.ring_tab + (size_t)(unsigned)(lead[s] + s0) * UNIT + m * 64,
+                                       s_tab + s * pitch + m * 64, lane_off);
+            }
+    };
+    // a round's blocks matched and its (first) loads issued
+    auto begin_round = [&](auto small) {
+        match();
+        if constexpr (decltype(small)::value) {
+            if (lane < ns * UNIT) {
+#pragma unroll
+                for (int s = 0; s < SK_SLOTS; ++s)
+                    if (lead[s] >= 0)
+                        stage_block<1>(K.ring_tab + (size_t)(unsigned)lead[s] * UNIT, s_tab + s * SMALL_PITCH, lane_off);
+            }
+        } else {
+            // order slots per pass (UPP_TABLE), capped by the slot count
+            // (wave-uniform by construction; said so, for the scalar operands of the staging loads)
+            upp = __builtin_amdgcn_readfirstlane(min(ns, (int)((UPP_TABLE >> (4 * (n_blocks - 1))) & 15u)));
+            pitch = upp * UNIT + 1;   // (+1: blocks start in different 16-byte bank slots)
+            stage(0);
         }
     };
     ML_MARK(9, blk);     // (ring waves: table cell located, block matching next)
-    match_and_stage();   // the first round's blocks are on their way during the arithmetic below
+    begin_round(std::integral_constant<bool, !WIDE>());   // the first pass' blocks are on their way during the arithmetic below
     ML_MARK(6, myslot);  // (ring waves: blocks matched, loads issued)
-    bool outside = false;
     OrderShared S;
     double wa[4], wb[4], Hw_x[NP], Hw_y[NP];
     if (peri) {
-        const long long bits = __double_as_longlong(r1.y);
-        // the table-bound tests do not depend on the order: evaluated once; only a failure takes the
-        // reporting path (per order, in the reference's check order).  A sample inside the range
-        // EVERY ring table covers, on a ring whose period its table covers (bit 32 of the ring record),
-        // cannot fail; only the others read their table's bounds.
-        outside = (int)(uxp < K.b0) | (int)(uxp > K.b1) |
-                  (int)(uyp < K.b2) | (int)(uyp > K.b3) | (int)((bits >> 32) & 1);
-        if (outside) {
-            const double *b = a.tables[a.gc[idx - 1]].bounds;
-            const double period = r0.y;
-            outside = (int)(uxp < b[0]) | (int)(uxp > b[1]) | (int)(uyp < b[2]) | (int)(uyp > b[3]) |
-                      (int)(period < b[4]) | (int)(period > b[5]);
-        }
         // E0 = order (0, 0)'s phasor (its argument in the reference's own operation order,
         // nearfield.py:268-269,291 with ox = oy = 0) times the phase-critical propagation phasor
         // from the grating centre (:337-341, exact argument), through ONE sincos: the large angle
@@ -692,25 +804,68 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
 #pragma unroll
     for (int m = 0; m < NP; ++m) pr[m] = {0, 0, 0, 0, 0, 0, 0, 0};
     ML_MARK(4, wa[0] + pr[0].Exr);   // (ring waves: phasors and weights done)
-    while (true) {
-        staged_wait<0>();
-        if (myslot >= 0) {
-            const double2 *b = s_tab + myslot * SK_PITCH;
-            // (nothing below changes from round to round, and the compiler would hoist the three
-            // orders' factors in front of the loop - sixty live registers - if it knew)
-            OrderShared R = S;
-            asm volatile("" : "+v"(R.kx0));
-            // (the three orders one after the other: scheduled together, all 48 LDS reads are put in
-            // flight at once and what they displace is spilled)
-            order_simple<0, NP, 1>(pr, b, wa, wb, Hw_x, Hw_y, R, K);
-            __builtin_amdgcn_sched_barrier(0);
-            order_simple<-1, NP, 1>(pr, b + 16, wa, wb, Hw_x, Hw_y, R, K);
-            __builtin_amdgcn_sched_barrier(0);
-            order_simple<1, NP, 1>(pr, b + 32, wa, wb, Hw_x, Hw_y, R, K);
+    // the orders of a round's lanes
+    auto finish_round = [&](auto small) {
+        // (nothing below changes from round to round, and the compiler would hoist the orders'
+        // factors in front of the loop - sixty live registers - if it knew)
+        OrderShared R = S;
+        asm volatile("" : "+v"(R.kx0));
+        OrderWalk W;
+        walk_start(W, R, lo);
+        const bool mine = myslot >= 0;
+        if constexpr (decltype(small)::value) {
+            const double2 *b = s_tab + max(myslot, 0) * SMALL_PITCH;
+            staged_wait<0>();
+#pragma unroll
+            for (int sl = 0; sl < SMALL_SLOTS; ++sl) {
+                if (sl < ns) {   // wave-uniform
+                    if (sl) {
+                        walk_step(W, R);
+                        // (keeps the step where it is: hoisted out of its branch, the phasors of all four
+                        // slots would be worked out - and held - up front)
+                        asm volatile("" : "+v"(W.ph.r), "+v"(W.ph.i), "+v"(W.kx));
+                    }
+                    if ((present >> sl) & 1u) order_simple<NP, 1>(pr, b + sl * UNIT, wa, wb, Hw_x, Hw_y, R, K, W, mine);
+                    // (one order after the other: scheduled together, their LDS reads are put in flight at
+                    // once and what they displace is spilled)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            int boff;   // the lane's block in the buffer (complex)
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(boff) : "v"(max(myslot, 0)), "s"(pitch));
+            const double2 *b = s_tab + boff;
+            for (int s0 = 0;;) {   // passes (one, unless the round's blocks do not fit the buffer with all their orders)
+                staged_wait<0>();
+                const int cnt = min(upp, ns - s0);
+#pragma nounroll
+                for (int sl = 0; sl < cnt; ++sl) {   // wave-uniform
+                    if ((present >> (s0 + sl)) & 1u) order_simple<NP, 1>(pr, b + sl * UNIT, wa, wb, Hw_x, Hw_y, R, K, W, mine);
+                    walk_step(W, R);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                s0 += upp;
+                if (s0 >= ns) break;   // wave-uniform
+                stage(s0);             // (this pass' LDS reads are done: the sched_barrier above)
+            }
         }
-        if (!todo) break;   // wave-uniform
+    };
+    while (true) {   // rounds
+        finish_round(std::integral_constant<bool, !WIDE>());
+        if (!todo) {   // wave-uniform
+            if (!several) break;
+            const unsigned long long later = __ballot(peri && !((coll_done >> cell_type) & 1u));
+            if (!later) break;
+            // the next collection among the wave's lanes: its list by scalar loads
+            c_cur = __builtin_amdgcn_readlane(cell_type, __ffsll((long long)later) - 1);
+            coll_done |= 1u << c_cur;
+            ns = a.coll[c_cur].n_slots;
+            lo = a.coll[c_cur].ox_lo;
+            present = (unsigned)a.coll[c_cur].present;
+            todo = __ballot(peri && cell_type == c_cur);
+        }
         __builtin_amdgcn_sched_barrier(0);   // (this round's LDS reads are done before the next round's loads go out)
-        match_and_stage();
+        begin_round(std::integral_constant<bool, !WIDE>());
     }
     ML_MARK(5, pr[0].Exr + pr[0].Hyi);   // orders done
     if (__ballot(outside)) {
@@ -723,8 +878,8 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
             if (!K.plane_wave) incidence(K, a.x_pts[i], a.y_pts[j], vx, vy, vz, vinv);
             rotate_dir(vx, vy, K.rot_table[ix.y], vxp, vyp);
             const double2 *rr = K.ring_rec + (size_t)ring * 2;
-            report_orders<true>(a, K.kvac2, K.kvac * vxp, rr[1].x, K.kvac * vyp, C->present, C->order_of, a.gc[ring], vxp, vyp,
-                                rr[0].y);
+            report_orders<true>(a, K.kvac2, K.kvac * vxp, rr[1].x, K.kvac * vyp, C->n_slots, C->ox_lo, (unsigned)C->present,
+                                a.gc[ring], vxp, vyp, rr[0].y);
         }
     }
     if (peri) {
@@ -766,16 +921,17 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
 // LISTED: the launch is a list of patches (`list`, a leading kernel argument of its own so that the
 // pointer can arrive in scalar registers with the wave - kernarg preload, see the Makefile - and the
 // list entry is the FIRST load of the wave, not the third of a dependent chain); else the whole grid
-template <int NP, bool LISTED>
+// WIDE: some ring collection of the lens holds more than SMALL_SLOTS = 4 orders
+template <int NP, bool LISTED, bool WIDE>
 __global__ __launch_bounds__(64, NP == 1 ? ML_NF_RING_MINW : 3) void nearfield_ring_kernel(const int2 *list, const NfArgs a) {
-    __shared__ double2 s_tab[RING_LDS];
+    __shared__ double2 s_tab[WIDE ? RING_LDS : RING_LDS_NARROW];
     int bx = blockIdx.x, by = blockIdx.y;
     if (LISTED) {
         const int2 pb = list[blockIdx.x];
         bx = pb.x;
         by = pb.y;
     }
-    synthesize_patch<NP, PART_RING, LISTED>(a, s_tab, s_tab, bx, by);
+    synthesize_patch<NP, PART_RING, LISTED, WIDE>(a, s_tab, s_tab, bx, by);
 }
 
 template <int NP, bool LISTED>
@@ -790,7 +946,7 @@ __global__ __launch_bounds__(64, 3) void nearfield_centre_kernel(const int2 *lis
         bx = pb.x;
         by = pb.y;
     }
-    synthesize_patch<NP, PART_CENTRE, LISTED>(a, s_tab, s_tab1, bx, by);
+    synthesize_patch<NP, PART_CENTRE, LISTED, false>(a, s_tab, s_tab1, bx, by);
 }
 
 #ifdef ML_PHASE_TIMERS
@@ -800,7 +956,7 @@ extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
 }
 #endif
 
-template <int NP>
+template <int NP, bool WIDE>
 static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
     // (the two kernels write disjoint samples and could run side by side: with the centre kernel forked
@@ -811,7 +967,7 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
         // every patch's power); the centre kernel works from its list, whose length only the device
         // knows yet - a launch over all patch numbers in which the surplus workgroups leave at once
         // (87 -> 45 us at 4096^2 against the full-grid centre kernel)
-        hipLaunchKernelGGL((nearfield_ring_kernel<NP, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
+        hipLaunchKernelGGL((nearfield_ring_kernel<NP, false, WIDE>), full, dim3(64), 0, ctx->stream, nullptr, a);
         NfArgs c = a;
         c.list_count = a.active_count + (size_t)2 * a.count_stride;
         c.first_pass = 1;
@@ -819,7 +975,7 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
                            a.active_list + (size_t)2 * a.list_stride, c);
     } else {
         if (a.n_active[1] > 0)
-            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true, WIDE>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)1 * a.list_stride, a);
         if (a.n_active[2] > 0)
             hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, ctx->stream,
@@ -830,7 +986,11 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
 }
 
 int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a) {
-    return a.n_pol == 1 ? launch_parts<1>(ctx, a) : a.n_pol == 2 ? launch_parts<2>(ctx, a) : launch_parts<3>(ctx, a);
+    // (the widest ring collection decides which instantiation runs; every collection runs its own order count in either)
+    bool wide = false;
+    for (int c = 0; c < ctx->n_colls; ++c) wide = wide || ctx->h_coll[c].n_slots > SIMPLE_NARROW_SLOTS;
+    if (wide) return a.n_pol == 1 ? launch_parts<1, true>(ctx, a) : a.n_pol == 2 ? launch_parts<2, true>(ctx, a) : launch_parts<3, true>(ctx, a);
+    return a.n_pol == 1 ? launch_parts<1, false>(ctx, a) : a.n_pol == 2 ? launch_parts<2, false>(ctx, a) : launch_parts<3, false>(ctx, a);
 }
 
 }  // namespace ml

@@ -41,12 +41,30 @@ def _smooth_amp(ux, uy, s, ox, oy, pol, amp, seed):
     return complex(mag * math.cos(phase), mag * math.sin(phase))
 
 
-def _records(ux_axis, uy_axis, s, orders, wavelength_in_nm, seed, phase0=0.0):
+def propagating_orders(ux, uy, wavelength, grating_period, lateral_period, search=5):
+    """The orders characterize() records at one direction of incidence: every (ox, oy) in
+    [-search, search]^2 whose diffracted wave propagates in air,
+    (kx + ox Gx)^2 + (ky + oy Gy)^2 < kvac^2 (reference grating.lua:406-423, strict)."""
+    gx, gy = wavelength / grating_period, wavelength / lateral_period
+    return [(ox, oy) for ox in range(-search, search + 1) for oy in range(-search, search + 1)
+            if (ux + ox * gx) ** 2 + (uy + oy * gy) ** 2 < 1]
+
+
+def _records(ux_axis, uy_axis, s, orders, wavelength_in_nm, seed, phase0=0.0, periods=None):
+    """``orders`` = a fixed list, or 'physical': per direction the orders that propagate there for
+    the grating's ``periods`` = (grating_period, lateral_period) - what S4 would have been asked
+    for; the table packer zero-fills the rest (reference grating.py:1207-1214)"""
     rot = complex(math.cos(phase0), math.sin(phase0))
     recs = []
     for ux in ux_axis:
         for uy in uy_axis:
-            for ox, oy in orders:
+            if ux ** 2 + uy ** 2 >= 1:   # (grating.lua:398: no incident wave there)
+                continue
+            here = orders
+            if isinstance(orders, str):
+                assert orders == 'physical'
+                here = propagating_orders(ux, uy, wavelength_in_nm * nm, *periods)
+            for ox, oy in here:
                 for pol in ('x', 'y'):
                     e = {'wavelength_in_nm': float(wavelength_in_nm), 'ux': float(ux),
                          'uy': float(uy), 'ox': ox, 'oy': oy, 'x_or_y': pol}
@@ -88,7 +106,8 @@ def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavel
     for i, period in enumerate(np.linspace(p_min, p_max, num_gratings)):
         period = float(period)
         angle = math.asin(target_wavelength / period)
-        recs = _records(ux_axis, uy_axis, i / max(1, num_gratings - 1), orders, wl_nm, seed)
+        recs = _records(ux_axis, uy_axis, i / max(1, num_gratings - 1), orders, wl_nm, seed,
+                        periods=(period, L0 * math.tan(angle)))
         if drop_every:
             recs = [r for j, r in enumerate(recs) if (j + i) % drop_every != drop_every - 1]
         gratings.append(Grating(lateral_period=L0 * math.tan(angle), cyl_height=cyl_height,
@@ -110,7 +129,8 @@ def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=55
     x_amp = []
     for k in range(num_entries):
         phase0 = 2 * pi * k / num_entries
-        recs = _records(axis, axis, k / max(1, num_entries - 1), orders, wl_nm, seed, phase0)
+        recs = _records(axis, axis, k / max(1, num_entries - 1), orders, wl_nm, seed, phase0,
+                        periods=(sep * 3 ** 0.5, sep))
         gratings.append(Grating(grating_period=sep * 3 ** 0.5, lateral_period=sep,
                                 cyl_height=cyl_height, n_glass=n_glass, n_tio2=n_tio2,
                                 data=recs))
@@ -129,6 +149,9 @@ def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 *
 
     ``classes`` = ``(Grating, GratingCollection, HexGridSet)``;
     ``make_design`` = this package's ``layout.make_design`` or the reference's.
+    ``periphery_orders`` / ``center_orders``: a list of (ox, oy), or 'physical' - the orders
+    characterize() would record (``propagating_orders``), per collection and direction;
+    ``periphery_orders`` may also be a list of such lists, one per collection (cycled).
     Returns a dict with the design inputs and both summaries.
     """
     Grating, GratingCollection, HexGridSet = classes
@@ -138,11 +161,15 @@ def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 *
     n_col = max(1, int(math.ceil((edge_angle - switch_angle) / max_collection_span)))
     bounds = np.linspace(switch_angle, edge_angle + 0.2 * degree, n_col + 1)
     collections = []
+    per_collection = (not isinstance(periphery_orders, str)
+                      and isinstance(periphery_orders[0][0], (tuple, list)))
     for i in range(n_col):
         lo, hi = float(bounds[i]), float(bounds[i + 1])
         gc = make_collection(Grating, GratingCollection, lo, hi, wavelength, n_glass=n_glass,
                              num_gratings=num_gratings, seed=i, axis_warp=axis_warp,
-                             u_steps=u_steps, orders=periphery_orders)
+                             u_steps=u_steps,
+                             orders=periphery_orders[i % len(periphery_orders)] if per_collection
+                             else periphery_orders)
         collections.append([(lo, hi), gc])
     hgs = make_hexgridset(Grating, HexGridSet, wavelength, n_glass=n_glass,
                           num_entries=num_entries, axis_warp=axis_warp, u_steps=u_steps,

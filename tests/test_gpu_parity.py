@@ -864,9 +864,13 @@ def test_bench_line_contract():
         assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] <= 1 and r['peak'] > 0
         assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['avg_launch_ms'] > 0 and 'traffic' in r
         if r['kernel'].startswith('nearfield'):
-            # 64 B per sample written; what binds the kernel (vector-instruction issue) rides beside it where the
-            # configuration has a counter profile
-            assert r['bound'] == 'hbm' and abs(r['bytes_per_launch'] - 64.0 * 512 * 512) < 1
+            # 64 B per sample the launches process - the samples inside the lens circle - written once; the figure
+            # over the whole window beside it; what binds the kernel (vector-instruction issue) rides along where
+            # the configuration has a counter profile
+            n_in = d['config']['samples_in_lens']
+            assert 0.5 * 512 * 512 < n_in < 512 * 512       # (the 120 um lens in its 512^2 window at pitch lambda/2.2)
+            assert r['bound'] == 'hbm' and abs(r['bytes_per_launch'] - 64.0 * n_in) < 1
+            assert abs(r['frac_full_grid'] - r['frac'] * 512 * 512 / n_in) < 1e-9
             assert 'valu' not in r or 0 < r['valu']['issue_frac'] <= 1
         else:
             assert 'traffic_frac' in r
@@ -1279,7 +1283,7 @@ def test_general_order_sets_vs_oracle(ma, per, cen, pol, sz):
     periphery, dipole and plane wave, against the oracle."""
     from oracle import nearfield_oracle
     import math
-    from metalens_amd import layout, synthetic
+    from metalens_amd import _lib, layout, synthetic
     wl = 580e-9
     lens = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design,
                                radius=40e-6, numerical_aperture=0.4, wavelength=wl,
@@ -1299,6 +1303,7 @@ def test_general_order_sets_vs_oracle(ma, per, cen, pol, sz):
                     lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'],
                     x_pts=x, y_pts=y)
         got = ma.build_nearfield(**args)
+        assert _lib.default_context().nearfield_kernels()['family'] == 'general'
         want = nearfield_oracle.build_nearfield(**args)
         scale = max(np.abs(w).max() for w in want[:4])
         assert scale > 0
@@ -1306,6 +1311,70 @@ def test_general_order_sets_vs_oracle(ma, per, cen, pol, sz):
             assert int(np.count_nonzero((g == 0) != (w == 0))) == 0
             assert np.abs(g - w).max() <= TOL * scale
         assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
+
+
+ORDER_LISTS = {
+    # what characterize() would record for this lens (grating.lua:417-423): eleven orders in the inner
+    # collection, seven in the outer, three in the centre, zero-filled where an order does not propagate
+    'physical': ('physical', 'physical'),
+    # the review's reading: {-3 ... +1} inside 30 degrees, {-2, -1, 0} outside, (0, 0) in the centre
+    'inside-outside': ((((-3, 0), (-2, 0), (-1, 0), (0, 0), (1, 0)), ((-2, 0), (-1, 0), (0, 0))), ((0, 0),)),
+    # lists with holes and one-sided lists: no (0, 0) at all; only positive orders; a lone high order
+    'holes': ((((-1, 0), (2, 0), (-4, 0)), ((1, 0), (2, 0), (3, 0), (5, 0))), ((-1, 0), (1, 0))),
+    'one-order': ((((-5, 0),), ((0, 0), (-1, 0), (1, 0), (-2, 0), (2, 0), (-3, 0), (3, 0), (-4, 0), (4, 0), (-5, 0), (5, 0))),
+                  ((0, 0), (-2, 0), (2, 0), (-3, 0))),
+}
+
+
+@pytest.mark.parametrize('which', sorted(ORDER_LISTS))
+@pytest.mark.parametrize('pol,sz', [('x', -1.0), ('z', -1.0), ('y', -float('inf'))])
+def test_per_collection_order_lists_vs_oracle(ma, which, pol, sz):
+    """Tables holding any orders (ox, 0) with |ox| <= 5, every collection its own list, take the
+    product-phasor kernels (nearfield_simple.hip) - a collection of three orders runs three, its
+    neighbour of eleven runs eleven.  Windows in the centre, across the switch radius, across the
+    boundary between two collections of DIFFERENT lists (waves that hold lanes of both) and at the
+    rim, dipoles and a plane wave, against the oracle."""
+    from oracle import nearfield_oracle
+    import math
+    from metalens_amd import _lib, layout, synthetic
+    wl = 580e-9
+    per, cen = ORDER_LISTS[which]
+    lens = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design,
+                               radius=40e-6, numerical_aperture=0.4, wavelength=wl,
+                               switch_angle=9 * math.pi / 180, num_gratings=20, num_entries=12,
+                               design_kwargs={'wavelength': wl}, periphery_orders=per, center_orders=cen)
+    assert len(lens['collections']) == 2
+    S = lens['lens_periphery_summary']
+    gc_of_ring = np.asarray(S['gratingcollection_index_here_list'])
+    first_outer = int(np.argmax(gc_of_ring == 1))
+    r_join = float(np.asarray(S['r_min_list'])[first_outer])   # where the second collection starts
+    rsw = lens['r_for_switch']
+    pitch = wl / 2.2
+    windows = ((1e-6, -2e-6), (rsw * math.cos(0.7), rsw * math.sin(0.7)),
+               (r_join * math.cos(2.1), r_join * math.sin(2.1)), (-36e-6, 14e-6))
+    if sz == -float('inf'):
+        windows = windows[:1]   # a normally incident plane wave is outside the rings' tables (as in the reference)
+    for cx, cy in windows:
+        x = cx + (np.arange(40) - 20) * pitch
+        y = cy + (np.arange(56) - 28) * pitch
+        args = dict(source_x=0.3e-6, source_y=-0.2e-6,
+                    source_z=sz if sz == -float('inf') else -lens['source_distance'], source_pol=pol,
+                    wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                    lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'],
+                    x_pts=x, y_pts=y)
+        got = ma.build_nearfield(**args)
+        info = _lib.default_context().nearfield_kernels()
+        assert info['family'] == 'orders-along-x', info
+        want = nearfield_oracle.build_nearfield(**args)
+        # (a normally incident plane wave on a centre table without (0, 0): no order propagates, all zeros)
+        scale = max(max(np.abs(w).max() for w in want[:4]), 1e-300)
+        for g, w in zip(got[:4], want[:4]):
+            assert int(np.count_nonzero((g == 0) != (w == 0))) == 0
+            assert np.abs(g - w).max() <= TOL * scale
+        assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
+    # (slots run from a collection's lowest order to its highest: a hole in the list is a slot of zeros)
+    spans = [[e['ox'] for g in gc.grating_list for e in g.data] for _, gc in lens['collections']]
+    assert info['ring_orders_max'] == max(max(v) - min(v) + 1 for v in spans)
 
 
 @pytest.mark.parametrize('entries,pols', [(12, 'x'), (27, 'y'), (45, 'xyz'), (5, 'z')])

@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'metalens_amd', 'csrc')
-KERNEL = '_ZN2ml21nearfield_ring_kernelILi1ELb1EEEvPK15HIP_vector_typeIiLj2EENS_6NfArgsE'
+KERNEL = '_ZN2ml21nearfield_ring_kernelILi1ELb1ELb0EEEvPK15HIP_vector_typeIiLj2EENS_6NfArgsE'
 # program order of the stamps (nearfield_simple.hip ML_MARK) and what ends at each
 PHASES = ['prologue: constants pinned, coordinates, record load issued',
           'record arrives (incident direction, field and power worked meanwhile)',
