@@ -17,9 +17,12 @@ Workloads
           512 x 512 bins of the aperture's FFT lattice, fp64.  (--aperture 2048 --farfield 256
           is BASELINE configs[1].)
   N > 1   BASELINE configs[2], a FIXED problem tiled over the ranks ("scaling": "strong"):
-          2 mm NA 0.94 lens, 8192 x 8192 -> 512 x 512, aperture rows sharded as mirrored pairs,
-          one RCCL all-reduce of the two projected amplitudes.  --scaling weak instead grows
+          2 mm NA 0.94 lens, 8192 x 8192 -> 512 x 512, aperture rows dealt to the ranks in interleaved
+          blocks, one RCCL reduce-scatter of the two projected amplitudes.  --scaling weak instead grows
           the N = 1 workload with the rank count (side * sqrt(N), lens scaled alike).
+          `--gpus 1 --scaling strong` runs the same fixed problem on one GPU (the N = 1 point of the
+          curve), and every N > 1 line carries it too: `multi_gpu.one_gpu_same_workload` = rank 0
+          alone on the whole aperture, timed after the timed region.
   --replicas wavelength   BASELINE configs[3]: every rank runs the whole N = 1 aperture at its
           own wavelength (450 / 532 / 635 nm, cycled) with explicit n_glass; no collective in the
           data path.
@@ -328,7 +331,8 @@ def main():
 
     replicas = args.replicas == 'wavelength'
     scaling = args.scaling or ('strong' if world > 1 and not replicas else 'weak')
-    tiled = world > 1 and scaling == 'strong' and not replicas
+    # (--gpus 1 --scaling strong: configs[2]'s fixed problem on ONE GPU - the N = 1 point of a strong-scaling curve)
+    tiled = scaling == 'strong' and not replicas and (world > 1 or args.scaling == 'strong')
     side = args.aperture or (8192 if tiled else 4096)
     diameter = args.diameter or (2e-3 if tiled else 1e-3)
     na = args.na or (0.94 if tiled else 0.5)
@@ -453,6 +457,30 @@ def main():
         dist.barrier(ctx)
         no_coll_ms = 1e3 * float(dist.allreduce_host(ctx, [time.perf_counter() - t0], 'max')[0]) / args.steps
         hp.step()      # (the far field fetched below is the reduced one again)
+        hp.sync()
+    # ---- ... and the SAME workload on one GPU: rank 0 alone on the whole aperture (no shard, no collective), so
+    # that value(N) / one_gpu_same_workload.value is a strong-scaling ratio of ONE problem whatever the driver
+    # ran at --gpus 1
+    one_gpu = None
+    if world > 1 and not replicas and tiled and not args.pair_list:
+        if rank == 0:
+            hp_1 = HotPath(source, wavelength, lens['lens_periphery_summary'], lens['lens_center_summary'],
+                           lens['hexgridset'], x, x, ux, uy, ctx=ctx, rank=0, world=1, precision=args.precision,
+                           reduce='none', fuse_modulation=bool(args.fuse_modulation), method=args.method)
+            for _ in range(3):
+                hp_1.step()
+            hp_1.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                hp_1.step()
+            hp_1.sync()
+            dt1 = time.perf_counter() - t0
+            one_gpu = {'ms_per_step': 1e3 * dt1 / args.steps,
+                       'value': float(side) * side * float(u.size) * u.size * args.steps / dt1,
+                       'note': 'rank 0 alone on the whole %dx%d aperture, %d steps after 3 of warm-up, while the '
+                               'other ranks wait' % (side, side, args.steps)}
+        dist.barrier(ctx)
+        hp.step()      # (the far field fetched below is the sharded, reduced one again)
         hp.sync()
     per_rank = None
     if world > 1 and not replicas:
@@ -663,6 +691,7 @@ def main():
             # reduction that still held the amplitude slot (comm_wait), the collective on its own stream
             'per_rank_ms': per_rank,
             'ms_per_step_no_collective': no_coll_ms,
+            'one_gpu_same_workload': one_gpu,
             'note': 'ms_per_step - ms_per_step_no_collective = what the collective costs a step; per_rank_ms '
                     'tells a slow rank (decomposition) from a slow link (collective / comm_wait)'}
     if rel_err is not None:

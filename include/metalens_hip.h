@@ -264,6 +264,13 @@ int ml_comm_info(ml_ctx *ctx, int *n_ranks, int *rank, int *backend);
 #define ML_REDUCE_SCATTER 0
 #define ML_REDUCE_ALL 1
 int ml_comm_set_reduce(ml_ctx *ctx, int mode);
+/* Channels (workgroups) RCCL may use for this context's collectives: the step's one collective moves a
+ * few MB beside the next step's synthesis, and every CU it occupies is one the synthesis loses.  Set
+ * BEFORE ml_comm_init; applies to the communicator that call creates and to nothing else
+ * (ncclConfig_t::maxCTAs through ncclCommInitRankConfig - the process environment is not touched, so
+ * other RCCL users in the process keep their own settings; an RCCL without that entry point runs
+ * uncapped).  Default 4; 0 = leave the choice to RCCL.                                              */
+int ml_comm_set_max_channels(ml_ctx *ctx, int channels);
 /* all-gather of the reduced amplitude blocks and power rows (collective: every rank calls it);
  * a no-op when every rank already holds everything                                                */
 int ml_farfield_gather(ml_ctx *ctx);

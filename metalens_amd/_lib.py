@@ -45,6 +45,7 @@ SYMBOLS = (
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_farfield_total_power', 'ml_host_alloc', 'ml_host_free',
     'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather', 'ml_nearfield_kernel_info',
+    'ml_comm_set_max_channels',
 )
 
 
@@ -145,6 +146,8 @@ def load():
         lib.ml_comm_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
         lib.ml_comm_set_reduce.argtypes = [c_void_p, c_int]
         lib.ml_farfield_gather.argtypes = [c_void_p]
+    if hasattr(lib, 'ml_comm_set_max_channels'):
+        lib.ml_comm_set_max_channels.argtypes = [c_void_p, c_int]
     if hasattr(lib, 'ml_nearfield_kernel_info'):
         lib.ml_nearfield_kernel_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.ml_profile_enable.argtypes = [c_void_p, c_int]

@@ -22,6 +22,7 @@ struct RcclApi {
     void *handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t *, int, ncclUniqueId, int, ncclConfig_t *) = nullptr;   // (optional)
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
                               ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t,
@@ -62,6 +63,7 @@ static int load_rccl() {
     ML_SYM(CommDestroy, "ncclCommDestroy")
     ML_SYM(GetErrorString, "ncclGetErrorString")
 #undef ML_SYM
+    g_rccl.CommInitRankConfig = reinterpret_cast<decltype(g_rccl.CommInitRankConfig)>(dlsym(h, "ncclCommInitRankConfig"));
     g_rccl.handle = h;
     return ML_OK;
 }
@@ -248,8 +250,9 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     // The step's collective (a few MB per rank) runs on its own stream BESIDE the next step's synthesis,
     // whose waves fill every SIMD's register file: each CU a collective kernel occupies is a CU the
     // synthesis loses.  Four channels carry the payload in well under a step; RCCL's default
-    // takes several times as many workgroups.  The caller's own NCCL_MAX_NCHANNELS wins.
-    setenv("NCCL_MAX_NCHANNELS", "4", 0);
+    // takes several times as many workgroups.  The cap belongs to THIS communicator (ncclConfig_t::maxCTAs,
+    // ml_comm_set_max_channels): the process environment - and with it every other RCCL user in the
+    // process - is left alone.
     ML_TRY(load_rccl());
     ncclUniqueId u;
     memcpy(&u, id, 128);
@@ -262,7 +265,14 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
     fflush(stdout);
     const int saved_stdout = dup(1);
     if (saved_stdout >= 0) dup2(2, 1);
-    const ncclResult_t rc = g_rccl.CommInitRank(&comm, n_ranks, u, rank);
+    ncclResult_t rc;
+    if (ctx->comm_max_channels > 0 && g_rccl.CommInitRankConfig) {
+        ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
+        config.maxCTAs = ctx->comm_max_channels;
+        rc = g_rccl.CommInitRankConfig(&comm, n_ranks, u, rank, &config);
+    } else {
+        rc = g_rccl.CommInitRank(&comm, n_ranks, u, rank);
+    }
     fflush(stdout);
     if (saved_stdout >= 0) {
         dup2(saved_stdout, 1);
@@ -310,6 +320,14 @@ int ml_comm_set_reduce(ml_ctx *ctx, int mode) {
     ML_REQUIRE(ctx, "ctx is NULL");
     ML_REQUIRE(mode == ML_REDUCE_SCATTER || mode == ML_REDUCE_ALL, "unknown reduction mode %d", mode);
     ctx->reduce_by_allreduce = mode == ML_REDUCE_ALL;
+    return ML_OK;
+}
+
+int ml_comm_set_max_channels(ml_ctx *ctx, int channels) {
+    ML_REQUIRE(ctx, "ctx is NULL");
+    ML_REQUIRE(channels >= 0 && channels <= 256, "channel cap %d out of range [0, 256]", channels);
+    ML_REQUIRE(!ctx->comm, "the cap belongs to the communicator: set it before ml_comm_init");
+    ctx->comm_max_channels = channels;
     return ML_OK;
 }
 

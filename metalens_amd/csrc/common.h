@@ -378,6 +378,7 @@ struct ml_ctx {
     bool reduce_in_flight = false;
     bool reduce_by_allreduce = false;   // ml_comm_set_reduce: all-reduce instead of reduce-scatter (comparison runs)
     void *comm = nullptr;
+    int comm_max_channels = 4;   // ncclConfig_t::maxCTAs of the communicator ml_comm_init makes (0: RCCL's own choice)
     int n_ranks = 1, rank = 0;
     // ML_COMM_BACKEND=file: TEST backend, all-reduce through files in /tmp (several ranks may
     // then share one GPU, which RCCL refuses); never used unless asked for

@@ -1451,6 +1451,12 @@ static int accumulate_impl(ml_ctx *ctx, double weight, double cone_u, double con
         set_error("nothing projected: call ml_farfield_transform and ml_farfield_project first");
         return ML_ESTATE;
     }
+    if (pl.amp_rows && !pl.amp_gathered) {
+        // after a reduce-scatter a rank holds the power of ITS block of direction rows only: sums over
+        // the whole map would mix it with stale rows
+        set_error("the power map is reduce-scattered over the ranks: call ml_farfield_gather before summing it");
+        return ML_ESTATE;
+    }
     ML_HIP(hipSetDevice(ctx->device));
     ML_TRY(comm_join(ctx, false));
     const size_t n = (size_t)pl.mx * (pl.pair_list ? 1 : pl.my);

@@ -14,6 +14,7 @@ from math import pi
 
 import numpy as np
 
+from . import constants
 from .constants import nm, um
 
 #: nearest-neighbour pillar separation of the centre lattice and design
@@ -94,11 +95,16 @@ def design_center(hgs, source_distance, radius, pitch=DEFAULT_PITCH,
 
 
 def design_periphery(collections, source_distance, radius,
-                     wavelength=DEFAULT_WAVELENGTH):
+                     wavelength=None, units=None):
     """``lens_periphery_summary`` for ``collections =
     [[(angle_start, angle_end), GratingCollection], ...]``: one ring per Fresnel
     zone beyond the first switch angle, out to the first ring whose outer edge
-    passes ``radius`` (reference design_collimator.py:148-228)."""
+    passes ``radius`` (reference design_collimator.py:148-228).  ``units``: the
+    caller's unit system (constants.as_units; default SI) - the default wavelength
+    and the 2 um of margin are lengths."""
+    units = constants.as_units(units)
+    um = constants.um * (units.nm / constants.nm)   # (exactly 1e-6 in SI)
+    wavelength = 580 * units.nm if wavelength is None else wavelength
     if len(collections) == 0:
         raise AssertionError('need at least one collection')
     for a, b in zip(collections[:-1], collections[1:]):
@@ -139,12 +145,18 @@ def design_periphery(collections, source_distance, radius,
             'num_around_circle_list': np.array([r[3] for r in rings])}
 
 
-def make_design(collections, source_distance, radius, hgs, pitch=DEFAULT_PITCH,
-                wavelength=DEFAULT_WAVELENGTH):
+def make_design(collections, source_distance, radius, hgs, pitch=None,
+                wavelength=None, units=None):
     """Periphery + centre of a round lens; returns
     ``(lens_periphery_summary, lens_center_summary, r_for_switch)``
     (reference design_collimator.py:273-313; the centre stops 300 nm short of
-    the first ring)."""
+    the first ring).  ``units``: the caller's unit system (constants.as_units;
+    default SI): the defaults - pitch 320 nm, wavelength 580 nm
+    (design_collimator.py:34,50) - and the 300 nm are lengths."""
+    units = constants.as_units(units)
+    nm = units.nm
+    pitch = 320 * nm if pitch is None else pitch
+    wavelength = 580 * nm if wavelength is None else wavelength
     if len(collections) > 0:
         for _, gc in collections:
             if gc.lens_type != 'round':
@@ -152,7 +164,7 @@ def make_design(collections, source_distance, radius, hgs, pitch=DEFAULT_PITCH,
             for g in gc.grating_list:
                 if (g.n_tio2, g.n_glass, g.cyl_height) != (hgs.n_tio2, hgs.n_glass, hgs.cyl_height):
                     raise AssertionError('centre and periphery materials differ')
-        periphery = design_periphery(collections, source_distance, radius, wavelength)
+        periphery = design_periphery(collections, source_distance, radius, wavelength, units)
         r_for_switch = periphery['r_min_list'][0]
         if not r_for_switch < radius:
             raise AssertionError('no room for the periphery')

@@ -12,7 +12,12 @@ the inputs (packing.py) and converts the kernel's bound-check report back into
 the reference's exceptions.  There is no CPU path.
 
 Extra keyword-only arguments (not in the reference):
-``c0``, ``Z0``  physical constants, default ``metalens_amd.constants`` (SURVEY.md D8);
+``units``       the caller's unit system: an object with ``nm``, ``c0``, ``Z0`` (``C``, ``m``), e.g. the
+                ``numericalunits`` module the reference's own callers hold; default SI
+                (``metalens_amd.constants``).  Decides the table key ``int(round(wavelength / nm))``
+                (nearfield.py:111), the default ``c0`` / ``Z0`` / dipole moment and the nanometres of
+                the period bound errors;
+``c0``, ``Z0``  physical constants in the caller's units, default those of ``units`` (SURVEY.md D8);
 ``ctx``         the ``_lib.Context`` (GPU) to use, default the process-wide one;
 ``download``    if False the fields stay resident on the GPU for the far-field
                 transform and ``None`` is returned in their place.
@@ -22,7 +27,6 @@ from math import pi
 import numpy as np
 
 from . import _lib, constants, packing, ties
-from .constants import nm
 from .grating import n_glass as tabulated_n_glass
 from .prepared import PreparedLens
 
@@ -85,7 +89,7 @@ def nearfield_params(source_x, source_y, source_z, source_pol, wavelength, n_gla
     return p
 
 
-def _raise_violation(v, ctx):
+def _raise_violation(v, ctx, nm=constants.nm):
     """first violated bound -> the reference's ValueError (nearfield.py:294-305,412-419)"""
     msg = _CHECK_MESSAGES[v.check]
     if v.check >= 4:
@@ -95,8 +99,8 @@ def _raise_violation(v, ctx):
 
 def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
                     lens_periphery_summary, lens_center_summary, hexgridset,
-                    x_pts=None, y_pts=None, dipole_moment=1e-30 * constants.C * constants.m,
-                    *, c0=None, Z0=None, ctx=None, download=True):
+                    x_pts=None, y_pts=None, dipole_moment=None,
+                    *, units=None, c0=None, Z0=None, ctx=None, download=True):
     """Ex, Ey, Hx, Hy just past the lens for a dipole at (source_x, source_y,
     source_z<0) polarised along ``source_pol`` in 'x','y','z', or for a normally
     incident plane wave if ``source_z == -inf`` (then ``dipole_moment`` is the
@@ -104,9 +108,12 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
     power_passing_through_lens, n_glass)`` like the reference (nearfield.py:480)."""
     assert source_z < 0
     assert source_pol in ('x', 'y', 'z')
-    c0 = constants.c0 if c0 is None else c0
-    Z0 = constants.Z0 if Z0 is None else Z0
-    wavelength_in_nm = int(round(wavelength / nm))
+    units = constants.as_units(units)
+    c0 = units.c0 if c0 is None else c0
+    Z0 = units.Z0 if Z0 is None else Z0
+    if dipole_moment is None:
+        dipole_moment = constants.default_dipole_moment(units)   # 1e-30 C m (nearfield.py:68)
+    wavelength_in_nm = int(round(wavelength / units.nm))
     # a PreparedLens in place of the periphery summary (prepared.py): hashed and uploaded once
     prepared = lens_periphery_summary if isinstance(lens_periphery_summary, PreparedLens) else None
     if prepared is not None:
@@ -168,7 +175,7 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
         raise _lib.MetalensHipError('nearest-cell ties were still being reported after three '
                                     'passes (%d samples)' % ties.pending(ctx).size)
     if n_viol.value:
-        _raise_violation(viol[0], ctx)
+        _raise_violation(viol[0], ctx, units.nm)
     power_passing_through_lens = power.value * (x_pts[1] - x_pts[0]) * (y_pts[1] - y_pts[0])
     if not download:
         return None, None, None, None, x_pts, y_pts, power_passing_through_lens, n_glass
@@ -180,8 +187,8 @@ def build_nearfield(source_x, source_y, source_z, source_pol, wavelength,
 
 def build_nearfield_big(source_x, source_y, source_z, source_pol, wavelength,
                         lens_periphery_summary, lens_center_summary, hexgridset,
-                        x_pts=None, y_pts=None, dipole_moment=1e-30 * constants.C * constants.m,
-                        *, c0=None, Z0=None, ctx=None, pts_at_a_time=1e7):
+                        x_pts=None, y_pts=None, dipole_moment=None,
+                        *, units=None, c0=None, Z0=None, ctx=None, pts_at_a_time=1e7):
     """Strip driver with the reference's tiling contract (nearfield.py:482-516):
     y-strips of ``int(pts_at_a_time / len(x_pts))`` samples, fields concatenated,
     strip powers added.  Like the reference it needs explicit ``x_pts`` and
@@ -198,7 +205,7 @@ def build_nearfield_big(source_x, source_y, source_z, source_pol, wavelength,
         ex, ey, hx, hy, _, _, p_now, n_glass = build_nearfield(
             source_x, source_y, source_z, source_pol, wavelength, lens_periphery_summary,
             lens_center_summary, hexgridset, x_pts=x_pts, y_pts=y_pts[start:end],
-            dipole_moment=dipole_moment, c0=c0, Z0=Z0, ctx=ctx)
+            dipole_moment=dipole_moment, units=units, c0=c0, Z0=Z0, ctx=ctx)
         Ex[:, start:end] = ex
         Ey[:, start:end] = ey
         Hx[:, start:end] = hx

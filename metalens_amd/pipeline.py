@@ -10,7 +10,6 @@ are the same kernels with host arrays at the boundary.
 import numpy as np
 
 from . import _lib, constants, dist, packing, ties
-from .constants import nm
 from .grating import n_glass as tabulated_n_glass
 from .nearfield import _check_axis, _raise_violation, nearfield_params
 
@@ -27,9 +26,9 @@ def _check_source(source):
 
 class HotPath:
     def __init__(self, source, wavelength, lens_periphery_summary, lens_center_summary,
-                 hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=1e-30,
+                 hexgridset, x_pts, y_pts, ux, uy, pair_list=False, dipole_moment=None,
                  c0=None, Z0=None, ctx=None, rank=0, world=1, precision=None,
-                 reduce='amplitudes', fuse_modulation=True, method=None, sharding='auto'):
+                 reduce='amplitudes', fuse_modulation=True, method=None, sharding='auto', units=None):
         """``reduce`` (multi-GPU only): 'amplitudes' sums the two projected complex amplitudes over
         the ranks - by a reduce-scatter over blocks of direction rows, each rank taking the power of
         its block (``results()`` gathers the whole map); the radiation vectors in ``results()`` are
@@ -51,13 +50,17 @@ class HotPath:
         if hasattr(self.ctx.lib, 'ml_comm_set_reduce'):
             _lib.check(self.ctx.lib.ml_comm_set_reduce(self.ctx.handle, int(allreduce)))
         self.rank, self.world = rank, world
-        self.c0 = constants.c0 if c0 is None else c0
-        self.Z0 = constants.Z0 if Z0 is None else Z0
+        # ``units``: the caller's unit system (nearfield.build_nearfield); default SI
+        self.units = constants.as_units(units)
+        self.c0 = self.units.c0 if c0 is None else c0
+        self.Z0 = self.units.Z0 if Z0 is None else Z0
+        if dipole_moment is None:
+            dipole_moment = constants.default_dipole_moment(self.units)
         source_x, source_y, source_z, source_pol = _check_source(source)
         _check_axis(x_pts, wavelength)
         _check_axis(y_pts, wavelength)
         S = lens_periphery_summary
-        wl_nm = int(round(wavelength / nm))
+        wl_nm = int(round(wavelength / self.units.nm))
         n_glass = S['gratingcollection_list'][0].grating_list[0].n_glass
         if n_glass == 0:
             n_glass = tabulated_n_glass(wl_nm)
@@ -250,13 +253,14 @@ class HotPath:
         if self.world > 1 or dist.force_rccl():
             left = float(dist.allreduce_host(ctx, [left], 'max')[0])
         if n_viol.value:
-            _raise_violation(viol[0], ctx)
+            _raise_violation(viol[0], ctx, self.units.nm)
         if left:
             raise ValueError('a sample on another rank fell outside the characterisation tables '
                              '(that rank reports the value and the bound)')
         # the step's reduce-scatter left every rank with the sum of ITS block of direction rows: the
         # whole map on every rank is a collective of its own, paid here and not per step
-        if (self.world > 1 or dist.force_rccl()) and self.reduce == 'amplitudes':
+        # (an older build of the library, METALENS_HIP_LIB for A/B runs, has no reduce-scatter and nothing to gather)
+        if (self.world > 1 or dist.force_rccl()) and self.reduce == 'amplitudes' and hasattr(lib, 'ml_farfield_gather'):
             _lib.check(lib.ml_farfield_gather(ctx.handle))
         P = np.empty(self.shape)
         a_theta = np.empty(self.shape, dtype=np.complex128)

@@ -17,17 +17,17 @@ caller accepts: the arrays are not edited in place while the handle is in use - 
 after editing."""
 import numpy as np
 
-from . import _lib, packing
-from .constants import nm
+from . import _lib, constants, packing
 
 
 class PreparedLens:
-    def __init__(self, lens_periphery_summary, lens_center_summary, hexgridset, wavelength, ctx=None):
+    def __init__(self, lens_periphery_summary, lens_center_summary, hexgridset, wavelength, ctx=None, units=None):
         self.lens_periphery_summary = lens_periphery_summary
         self.lens_center_summary = lens_center_summary
         self.hexgridset = hexgridset
         self.wavelength = wavelength
-        self.wavelength_in_nm = int(round(wavelength / nm))
+        # (``units``: the caller's unit system, as for build_nearfield - what a nanometre is decides the table key)
+        self.wavelength_in_nm = int(round(wavelength / constants.as_units(units).nm))
         self.ctx = ctx or _lib.default_context()
         self.tokens = None
         self.refresh()

@@ -20,7 +20,6 @@ What a sweep shares:
 import numpy as np
 
 from . import _lib, constants, packing, ties
-from .constants import nm
 from .grating import n_glass as tabulated_n_glass
 from .nearfield import _check_axis, _raise_violation, nearfield_params
 from .pipeline import _check_source
@@ -31,17 +30,20 @@ MAX_SLOTS = 4096       # ML_MAX_SWEEP_SLOTS
 
 class SourceSweep:
     def __init__(self, wavelength, lens_periphery_summary, lens_center_summary, hexgridset,
-                 x_pts, y_pts, ux, uy, dipole_moment=1e-30, c0=None, Z0=None, ctx=None,
-                 precision=None, method=None):
+                 x_pts, y_pts, ux, uy, dipole_moment=None, c0=None, Z0=None, ctx=None,
+                 precision=None, method=None, units=None):
         self.ctx = ctx or _lib.default_context()
         self.ctx.set_precision(precision or 'f64')
         self.ctx.set_method(method or 'auto')
-        self.c0 = constants.c0 if c0 is None else c0
-        self.Z0 = constants.Z0 if Z0 is None else Z0
+        self.units = constants.as_units(units)   # the caller's unit system (nearfield.build_nearfield); default SI
+        self.c0 = self.units.c0 if c0 is None else c0
+        self.Z0 = self.units.Z0 if Z0 is None else Z0
+        if dipole_moment is None:
+            dipole_moment = constants.default_dipole_moment(self.units)
         _check_axis(x_pts, wavelength)
         _check_axis(y_pts, wavelength)
         S = lens_periphery_summary
-        wl_nm = int(round(wavelength / nm))
+        wl_nm = int(round(wavelength / self.units.nm))
         n_glass = S['gratingcollection_list'][0].grating_list[0].n_glass
         if n_glass == 0:
             n_glass = tabulated_n_glass(wl_nm)
@@ -188,7 +190,7 @@ class SourceSweep:
             n_viol = _lib.c_int(0)
             _lib.check(lib.ml_nearfield_result(ctx.handle, None, viol, 8, _lib.byref(n_viol)))
             if n_viol.value:
-                _raise_violation(viol[0], ctx)
+                _raise_violation(viol[0], ctx, self.units.nm)
             for m, (k, pol) in enumerate(g['members']):
                 power_in[k] = pw[m] * self.dxp * self.dyp
             if keep_each:   # the projections of this group's members, one at a time (tests)

@@ -15,7 +15,8 @@ from math import pi
 
 import numpy as np
 
-from .constants import nm, degree
+from . import constants
+from .constants import degree
 
 PERIPHERY_ORDERS = ((0, 0), (-1, 0), (1, 0))
 CENTER_ORDERS = ((0, 0), (-1, 0), (1, 0))
@@ -50,7 +51,7 @@ def propagating_orders(ux, uy, wavelength, grating_period, lateral_period, searc
             if (ux + ox * gx) ** 2 + (uy + oy * gy) ** 2 < 1]
 
 
-def _records(ux_axis, uy_axis, s, orders, wavelength_in_nm, seed, phase0=0.0, periods=None):
+def _records(ux_axis, uy_axis, s, orders, wavelength_in_nm, seed, phase0=0.0, periods=None, nm=constants.nm):
     """``orders`` = a fixed list, or 'physical': per direction the orders that propagate there for
     the grating's ``periods`` = (grating_period, lateral_period) - what S4 would have been asked
     for; the table packer zero-fills the rest (reference grating.py:1207-1214)"""
@@ -84,14 +85,18 @@ def _warp_axis(axis, warp):
 
 
 def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavelength,
-                    cyl_height=550 * nm, n_glass=0, n_tio2=0, num_gratings=24, u_steps=5,
-                    local_lateral_period=330 * nm, orders=PERIPHERY_ORDERS, seed=0,
-                    drop_every=0, axis_warp=0.0):
+                    cyl_height=None, n_glass=0, n_tio2=0, num_gratings=24, u_steps=5,
+                    local_lateral_period=None, orders=PERIPHERY_ORDERS, seed=0,
+                    drop_every=0, axis_warp=0.0, units=None):
     """A 'round'-lens GratingCollection covering incidence angles
     ``[angle_lo, angle_hi]`` (radians) with ``num_gratings`` periods.
 
     ``drop_every`` > 0 removes every n-th record to exercise the table packer's
-    zero-fill rule (reference grating.py:1207-1214)."""
+    zero-fill rule (reference grating.py:1207-1214).  ``units``: the unit system the lengths are in
+    (constants.as_units; default SI); the default pillar height is 550 nm, the default lateral period 330 nm."""
+    nm = constants.as_units(units).nm
+    cyl_height = 550 * nm if cyl_height is None else cyl_height
+    local_lateral_period = 330 * nm if local_lateral_period is None else local_lateral_period
     wl_nm = int(round(target_wavelength / nm))
     margin = 0.6 * degree
     p_min = target_wavelength / math.sin(min(angle_hi + margin, 89 * degree))
@@ -107,7 +112,7 @@ def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavel
         period = float(period)
         angle = math.asin(target_wavelength / period)
         recs = _records(ux_axis, uy_axis, i / max(1, num_gratings - 1), orders, wl_nm, seed,
-                        periods=(period, L0 * math.tan(angle)))
+                        periods=(period, L0 * math.tan(angle)), nm=nm)
         if drop_every:
             recs = [r for j, r in enumerate(recs) if (j + i) % drop_every != drop_every - 1]
         gratings.append(Grating(lateral_period=L0 * math.tan(angle), cyl_height=cyl_height,
@@ -117,12 +122,15 @@ def make_collection(Grating, GratingCollection, angle_lo, angle_hi, target_wavel
                              lens_type='round', grating_list=gratings)
 
 
-def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=550 * nm,
+def make_hexgridset(Grating, HexGridSet, wavelength, sep=None, cyl_height=None,
                     n_glass=0, n_tio2=0, num_entries=12, u_steps=5, orders=CENTER_ORDERS,
-                    seed=100, axis_warp=0.0):
+                    seed=100, axis_warp=0.0, units=None):
     """A HexGridSet of ``num_entries`` cells whose normal-incidence phase
     sweeps 0..2pi, characterised over ux,uy in [-0.499, 0.501]
-    (reference lens_center.py:88-90)."""
+    (reference lens_center.py:88-90).  ``units`` as for ``make_collection``; default separation 320 nm."""
+    nm = constants.as_units(units).nm
+    sep = 320 * nm if sep is None else sep
+    cyl_height = 550 * nm if cyl_height is None else cyl_height
     wl_nm = int(round(wavelength / nm))
     axis = _warp_axis(np.linspace(-0.499, 0.501, u_steps), axis_warp)
     gratings = []
@@ -130,7 +138,7 @@ def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=55
     for k in range(num_entries):
         phase0 = 2 * pi * k / num_entries
         recs = _records(axis, axis, k / max(1, num_entries - 1), orders, wl_nm, seed, phase0,
-                        periods=(sep * 3 ** 0.5, sep))
+                        periods=(sep * 3 ** 0.5, sep), nm=nm)
         gratings.append(Grating(grating_period=sep * 3 ** 0.5, lateral_period=sep,
                                 cyl_height=cyl_height, n_glass=n_glass, n_tio2=n_tio2,
                                 data=recs))
@@ -140,10 +148,10 @@ def make_hexgridset(Grating, HexGridSet, wavelength, sep=320 * nm, cyl_height=55
                       grating_list=gratings, x_amp_list=x_amp)
 
 
-def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 * nm,
+def make_lens(classes, make_design, radius, numerical_aperture, wavelength=None,
               switch_angle=12 * degree, n_glass=0, num_gratings=24, num_entries=12,
               max_collection_span=9 * degree, design_kwargs=None, axis_warp=0.0, u_steps=5,
-              periphery_orders=PERIPHERY_ORDERS, center_orders=CENTER_ORDERS):
+              periphery_orders=PERIPHERY_ORDERS, center_orders=CENTER_ORDERS, units=None):
     """A complete synthetic round lens of ``radius`` and ``numerical_aperture``
     for an on-axis source at the focal distance ``radius / tan(asin(NA))``.
 
@@ -152,12 +160,16 @@ def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 *
     ``periphery_orders`` / ``center_orders``: a list of (ox, oy), or 'physical' - the orders
     characterize() would record (``propagating_orders``), per collection and direction;
     ``periphery_orders`` may also be a list of such lists, one per collection (cycled).
+    ``units``: the unit system ``radius`` and ``wavelength`` are in (constants.as_units; default
+    SI; ``make_design`` then needs its own ``units`` in ``design_kwargs``).
     Returns a dict with the design inputs and both summaries.
     """
     Grating, GratingCollection, HexGridSet = classes
+    nm = constants.as_units(units).nm
+    wavelength = 580 * nm if wavelength is None else wavelength
     source_distance = radius / math.tan(math.asin(numerical_aperture))
     # the outermost ring is the first whose outer edge passes `radius`
-    edge_angle = math.atan((radius + 4e-6) / source_distance)
+    edge_angle = math.atan((radius + 4e-6 * (nm / constants.nm)) / source_distance)   # (+ 4 um)
     n_col = max(1, int(math.ceil((edge_angle - switch_angle) / max_collection_span)))
     bounds = np.linspace(switch_angle, edge_angle + 0.2 * degree, n_col + 1)
     collections = []
@@ -167,13 +179,13 @@ def make_lens(classes, make_design, radius, numerical_aperture, wavelength=580 *
         lo, hi = float(bounds[i]), float(bounds[i + 1])
         gc = make_collection(Grating, GratingCollection, lo, hi, wavelength, n_glass=n_glass,
                              num_gratings=num_gratings, seed=i, axis_warp=axis_warp,
-                             u_steps=u_steps,
+                             u_steps=u_steps, units=units,
                              orders=periphery_orders[i % len(periphery_orders)] if per_collection
                              else periphery_orders)
         collections.append([(lo, hi), gc])
     hgs = make_hexgridset(Grating, HexGridSet, wavelength, n_glass=n_glass,
                           num_entries=num_entries, axis_warp=axis_warp, u_steps=u_steps,
-                          orders=center_orders)
+                          orders=center_orders, units=units)
     for _, gc in collections:
         gc.build_interpolators()
     hgs.build_interpolators()

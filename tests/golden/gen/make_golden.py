@@ -242,6 +242,47 @@ def main():
         neg['bad_wavelength_msg'] = np.array(str(e.args[0]))
     save('negative_cases.npz', lens='lensB.npz', **neg, **META)
 
+    # ------------------------------------------------- lenses C and D: other order sets
+    # Every fixture above tabulates the orders (0,0), (-1,0), (+1,0).  characterize() records, per
+    # direction, every order that propagates in air (grating.lua:417-423): lens C carries exactly
+    # those lists (eleven orders in the inner collection, seven in the outer, three in the centre,
+    # absent entries zero-filled by build_interpolators); lens D a five-order and a three-order
+    # collection ({-3 ... +1} inside, {-2, -1, 0} outside) around a one-order centre.
+    for tag, per, cen in (('C', 'physical', 'physical'),
+                          ('D', (((-3, 0), (-2, 0), (-1, 0), (0, 0), (1, 0)), ((-2, 0), (-1, 0), (0, 0))),
+                           ((0, 0),))):
+        lens = synthetic.make_lens(REF_CLASSES, ref_design.make_design, radius=60 * um,
+                                   numerical_aperture=0.42, wavelength=wl, switch_angle=10 * degree,
+                                   num_gratings=12, num_entries=8, periphery_orders=per,
+                                   center_orders=cen)
+        S = lens['lens_periphery_summary']
+        assert len(S['gratingcollection_list']) == 2
+        f = lens['source_distance']
+        rsw = lens['r_for_switch']
+        gc_of_ring = np.asarray(S['gratingcollection_index_here_list'])
+        r_join = float(np.asarray(S['r_min_list'])[int(np.argmax(gc_of_ring == 1))])
+        wins = {
+            'center': window(-4 * um, 3 * um, 40, 48, wl),
+            'straddle': window(rsw * math.cos(2.2), rsw * math.sin(2.2), 48, 40, wl),
+            'join': window(r_join * math.cos(-1.1), r_join * math.sin(-1.1), 48, 40, wl),
+            'edge': window(60.5 * um * math.cos(0.4), 60.5 * um * math.sin(0.4), 40, 48, wl),
+        }
+        cells = lens['lens_center_summary']
+        keep = np.zeros(len(cells), dtype=bool)
+        for wx, wy in wins.values():
+            c = crop_cells(cells, wx, wy)
+            keep |= np.isin(cells[:, 0] + 1j * cells[:, 1], c[:, 0] + 1j * c[:, 1])
+        cells = cells[keep]
+        name = 'lens%s.npz' % tag
+        save(name, **golden_io.pack_lens(S, cells, lens['hexgridset']), source_distance=f,
+             r_for_switch=rsw, r_join=r_join, **META)
+        srcs = {'onaxis_x': (0.0, 0.0, -f, 'x'), 'offaxis_z': (2 * um, -3 * um, -f * 0.97, 'z'),
+                'offaxis_y': (-1.5 * um, 1 * um, -f, 'y'), 'plane_x': (0.0, 0.0, -inf, 'x')}
+        for wname, sname in (('center', 'plane_x'), ('center', 'offaxis_z'), ('straddle', 'onaxis_x'),
+                             ('join', 'onaxis_x'), ('join', 'offaxis_y'), ('edge', 'offaxis_z')):
+            wx, wy = wins[wname]
+            run_case('nearfield_%s_%s_%s.npz' % (tag, wname, sname), name, lens, cells, srcs[sname], wx, wy)
+
     # ------------------------------------------------- raw scipy RGI samples
     rng = np.random.default_rng(12345)
     ax0 = np.array([-0.3, -0.1, 0.05, 0.2, 0.45])

@@ -14,7 +14,9 @@ import golden_io
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-12
-CASES = sorted(os.path.basename(p) for p in glob.glob(golden_io.golden_path('nearfield_B_*.npz')))
+# lens B: the three-order tables; lens C: the orders characterize() would record (eleven / seven per ring
+# collection, three in the centre); lens D: a five-order and a three-order collection, one order in the centre
+CASES = sorted(os.path.basename(p) for p in glob.glob(golden_io.golden_path('nearfield_[BCD]_*.npz')))
 
 
 @pytest.fixture(scope='module')
@@ -791,6 +793,10 @@ def test_plain_bench_gpus_n_starts_its_own_ranks(tmp_path, world):
     line = json.loads(lines[0])
     assert line['n_gpus'] == world and line['multi_gpu']['ranks_reported_by_backend'] == world
     assert line['config']['sharding'].startswith('interleaved')
+    # the line carries the SAME workload on one GPU (rank 0 alone on the whole aperture): the N = 1 point
+    # of the strong-scaling curve, whatever the driver ran at --gpus 1
+    ref = line['multi_gpu']['one_gpu_same_workload']
+    assert ref['ms_per_step'] > 0 and abs(ref['value'] - 2048.0 ** 2 * 64 ** 2 / (ref['ms_per_step'] * 1e-3)) < 1e-6 * ref['value']
     a, b = np.load(one), np.load(many)
     for key in ('a_theta', 'a_phi'):
         assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), key

@@ -11,7 +11,9 @@ from oracle import farfield_oracle, nearfield_oracle, rgi
 
 TOL = 1e-14   # relative to the largest field magnitude of the case (measured: <= 5e-15)
 
-CASES = sorted(os.path.basename(p) for p in glob.glob(golden_io.golden_path('nearfield_B_*.npz')))
+# lens B: the three-order tables; lens C: the orders characterize() would record (eleven / seven per ring
+# collection, three in the centre); lens D: a five-order and a three-order collection, one order in the centre
+CASES = sorted(os.path.basename(p) for p in glob.glob(golden_io.golden_path('nearfield_[BCD]_*.npz')))
 
 
 def run_oracle(case, **override):
