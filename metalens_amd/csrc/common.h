@@ -204,6 +204,7 @@ struct CellRec {
 struct ZfftAxis {
     bool ok = false;
     int N_eff = 0, j0 = 0, pad1 = 0, pad2 = 0;
+    int jstep = 1;   // output j is bin (j + j0) jstep of the N_eff-sample lattice (zfft_core.h Geo::jstep)
     // split > 1 (lattices beyond 8192 samples): `split` launches over interleaved sub-sequences of
     // N_eff / split samples; wk / kbin then belong to the SHORT lattice and pj holds [split][M]
     int split = 1;
@@ -433,6 +434,7 @@ int zfold_splits(int T, int ksplit);
 // zfft.hip: output-pruned FFT along one axis for lattice-commensurate direction grids
 struct ZfftCall {
     int N_eff, n_valid, M, j0, pad1, pad2;
+    int jstep = 1;
     const double *in;           // complex
     int64_t in_s1, in_s2, in_es;
     int in_rb, a0, h0, a1, h1;
@@ -451,16 +453,16 @@ struct ZfftCall {
 };
 int zfft_split(int N_eff);   // sub-sequences a lattice of N_eff samples is transformed in (0: none)
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
-                       long double tol, int *N_eff, int *j0);
+                       long double tol, int *N_eff, int *j0, int *jstep);
 int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M,
-                      int j0, int N_eff, int c);
-void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2);
+                      int j0, int N_eff, int c, int jstep = 1);
+void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2, int jstep = 1);
 // the column pass of an interleaved shard: s short transforms per column in one workgroup; c.pj holds
 // [s][M] phasors, sub-sequence i starts sub_off elements behind sub-sequence i - 1
 // (stuff > 1: the transforms have c.N_eff / stuff samples and run zero-stuffed at c.N_eff)
 int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off, int stuff);
 int zfft_build_interleave_tables(hipStream_t stream, double *wk, double *pj, int *kbin, int M, int j0, int Nsub,
-                                 int N, int c, int first, int block);
+                                 int N, int c, int first, int block, int jstep = 1);
 int zfft_run(hipStream_t stream, const ZfftCall &c);
 // comm.hip
 void comm_release(ml_ctx *ctx);

@@ -493,8 +493,8 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
     ax.ok = false;
     const long double kappa = (long double)pl.n_glass / (long double)pl.wavelength;
     const long double p_max = 0.5L * (n + 1) * fabsl((long double)step);
-    int N_eff = 0, j0 = 0;
-    if (!zfft_commensurate(n, step, kappa, u, m, symmetry_tolerance(kappa, p_max, u, m), &N_eff, &j0))
+    int N_eff = 0, j0 = 0, jstep = 1;
+    if (!zfft_commensurate(n, step, kappa, u, m, symmetry_tolerance(kappa, p_max, u, m), &N_eff, &j0, &jstep))
         return ML_OK;
     int split = zfft_split(N_eff);
     // 8192 < N_eff <= 16384 with at most 1024 wanted bins: one launch in two residue passes (every
@@ -513,14 +513,15 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
     // (tw1 is shared by every axis and every lattice; with split > 1 the per-bin tables belong to the
     // sub-sequences' lattice and pj[i][.] carries sub-sequence i's bins to the full one)
     ML_TRY(zfft_build_tables(ctx->stream, pl.fft_tw1.as<double>(), ax.wk.as<double>(),
-                             ax.pj.as<double>(), ax.kbin.as<int>(), m, j0, N_eff, n - n / 2));
+                             ax.pj.as<double>(), ax.kbin.as<int>(), m, j0, N_eff, n - n / 2, jstep));
     if (split > 1)
         ML_TRY(zfft_build_interleave_tables(ctx->stream, ax.wk.as<double>(), ax.pj.as<double>(),
-                                            ax.kbin.as<int>(), m, j0, N_eff / split, N_eff, n - n / 2, 0, split));
-    zfft_choose_pads(N_eff / split, m, j0, &ax.pad1, &ax.pad2);
+                                            ax.kbin.as<int>(), m, j0, N_eff / split, N_eff, n - n / 2, 0, split, jstep));
+    zfft_choose_pads(N_eff / split, m, j0, &ax.pad1, &ax.pad2, jstep);
     ax.split = split;
     ax.N_eff = N_eff;
     ax.j0 = j0;
+    ax.jstep = jstep;
     ax.ok = true;
     return ML_OK;
 }
@@ -941,6 +942,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.n_valid = ny;
             c.M = my;
             c.j0 = pl.fft_y.j0;
+            c.jstep = pl.fft_y.jstep;
             c.pad1 = pl.fft_y.pad1;
             c.pad2 = pl.fft_y.pad2;
             c.in = ctx->set_ptr();
@@ -1026,8 +1028,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             ML_TRY(pl.il_pj.reserve((size_t)s * mx * 2 * sizeof(double)));
             ML_TRY(zfft_build_interleave_tables(ctx->stream, pl.il_wk.as<double>(), pl.il_pj.as<double>(),
                                                 pl.il_kbin.as<int>(), mx, pl.fft_x.j0, Nsub, N,
-                                                pl.nx_total - pl.nx_total / 2, s * sh.rank, s));
-            zfft_choose_pads(Nsub, mx, pl.fft_x.j0, &pl.il_pad1, &pl.il_pad2);
+                                                pl.nx_total - pl.nx_total / 2, s * sh.rank, s, pl.fft_x.jstep));
+            zfft_choose_pads(Nsub, mx, pl.fft_x.j0, &pl.il_pad1, &pl.il_pad2, pl.fft_x.jstep);
             memcpy(pl.il_key, key, sizeof key);
         }
         {
@@ -1036,6 +1038,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.n_valid = n_have;
             c.M = mx;
             c.j0 = pl.fft_x.j0;
+        c.jstep = pl.fft_x.jstep;
+            c.jstep = pl.fft_x.jstep;
             c.pad1 = pl.il_pad1;
             c.pad2 = pl.il_pad2;
             c.in = pl.stage1.as<double>();
@@ -1075,6 +1079,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         c.n_valid = pl.nx_total;
         c.M = mx;
         c.j0 = pl.fft_x.j0;
+        c.jstep = pl.fft_x.jstep;
         c.pad1 = pl.fft_x.pad1;
         c.pad2 = pl.fft_x.pad2;
         c.in = pl.stage1.as<double>();

@@ -483,6 +483,7 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
     a.g.pad1 = c.pad1;
     a.g.pad2 = c.pad2;
     a.g.ip = 0;
+    a.g.jstep = c.jstep;
     a.in = reinterpret_cast<const cd *>(c.in);
     a.in_s1 = c.in_s1;
     a.in_s2 = c.in_s2;
@@ -534,10 +535,10 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
 //     pj[i][j] = exp(+2 pi i (c - s r - i) k_j / N)
 __global__ __launch_bounds__(256) void zfft_interleave_tables_kernel(cd *wk, cd *pj, int *kbin, int M, int j0,
                                                                      int Nsub, int N, int c, int first,
-                                                                     int block) {
+                                                                     int block, int jstep) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= M) return;
-    const long long kj = (long long)e + j0;
+    const long long kj = ((long long)e + j0) * jstep;
     long long k = kj % Nsub;
     if (k < 0) k += Nsub;
     kbin[e] = (int)k;
@@ -553,17 +554,17 @@ __global__ __launch_bounds__(256) void zfft_interleave_tables_kernel(cd *wk, cd 
 }
 
 int zfft_build_interleave_tables(hipStream_t stream, double *wk, double *pj, int *kbin, int M, int j0, int Nsub,
-                                 int N, int c, int first, int block) {
+                                 int N, int c, int first, int block, int jstep) {
     hipLaunchKernelGGL(zfft_interleave_tables_kernel, dim3((M + 255) / 256), dim3(256), 0, stream,
                        reinterpret_cast<cd *>(wk), reinterpret_cast<cd *>(pj), kbin, M, j0, Nsub, N, c, first,
-                       block);
+                       block, jstep);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
 
 // tables of one axis: tw1 (shared by all axes), wk / pj / kbin per plan axis
 __global__ __launch_bounds__(256) void zfft_tables_kernel(cd *tw1, cd *wk, cd *pj, int *kbin, int M,
-                                                          int j0, int N, int c) {
+                                                          int j0, int N, int c, int jstep) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e < 256) {
         const int n1 = e >> 4, k2 = e & 15;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256) void zfft_tables_kernel(cd *tw1, cd *wk, cd *p
         tw1[e] = zf::mk(co, s);
     }
     if (e < M) {
-        const long long kj = (long long)e + j0;          // true bin (may be negative)
+        const long long kj = ((long long)e + j0) * jstep;   // true bin (may be negative)
         long long k = kj % N;
         if (k < 0) k += N;
         kbin[e] = (int)k;
@@ -593,17 +594,17 @@ __global__ __launch_bounds__(256) void zfft_tables_kernel(cd *tw1, cd *wk, cd *p
 // interleaved sub-sequences of N_eff / s samples (decimation in time: X[k] = sum_i W_N^(i k) X_i[k
 // mod N / s]), each by one launch of the one-level kernel that adds its bins - carried to the full
 // lattice by a per-bin phasor - to the result.  Smallest s that brings R3 / s to <= 32; 0 if none
-// up to 8 does (lattices beyond 65536 samples, or R3 with no such divisor).
+// up to 16 does (R3 with no such divisor).
 int zfft_split(int N_eff) {
     if (N_eff % 256) return 0;
     const int R3 = N_eff / 256;
-    for (int s = 1; s <= 8; ++s)
+    for (int s = 1; s <= 16; ++s)
         if (R3 % s == 0 && R3 / s <= 32) return s;
     return 0;
 }
 
 bool zfft_commensurate(int n, double step, long double kappa, const double *u, int M,
-                       long double tol, int *N_eff, int *j0) {
+                       long double tol, int *N_eff, int *j0, int *jstep) {
     if (M < 2 || n < 2) return false;
     const long double du = ((long double)u[M - 1] - (long double)u[0]) / (M - 1);
     const long double turns = kappa * fabsl((long double)step) * du;   // per (sample, bin)
@@ -611,32 +612,45 @@ bool zfft_commensurate(int n, double step, long double kappa, const double *u, i
     if (step < 0) return false;
     const long double inv = 1.0L / turns;
     if (!(inv < 1e7L)) return false;
-    const long N = lrintl(inv);
-    if (N < n || N < M || N % 256 != 0) return false;
-    const int R3 = (int)(N / 256);
+    const long N = lrintl(inv);                        // the lattice the directions sit on
+    if (N < n || N < M) return false;
+    // The kernels transform 256 R3 samples.  A lattice that is not a multiple of 256 long - the
+    // reference's default grids are the smallest 2^a 3^b 5^c above a goal (nearfield.py:30-36: 400, 1920,
+    // 2000 ...) - runs on the s-times finer lattice of N s samples, s = 256 / gcd(N, 256), the aperture
+    // zero-padded: its every s-th bin is a bin of the lattice asked for (Geo::jstep)
+    long g = 256, r = N % 256;
+    while (r) {
+        const long t = g % r;
+        g = r;
+        r = t;
+    }
+    const long s = 256 / g, Ne = N * s;
+    if (Ne > (1L << 20)) return false;
+    const int R3 = (int)(Ne / 256);
     // one workgroup holds 8192 samples in LDS (257 * R3 * 16 bytes, R3 <= 32); longer lattices are
-    // split into up to 8 interleaved sub-sequences, one launch each (zfft_split)
-    if (R3 < 1 || zfft_split((int)N) == 0) return false;
+    // split into up to 16 interleaved sub-sequences, one launch each (zfft_split)
+    if (R3 < 1 || zfft_split((int)Ne) == 0) return false;
     const long double du_exact = 1.0L / (kappa * fabsl((long double)step) * N);
     const long jj = lrintl((long double)u[0] / du_exact);
-    if (labs(jj) > (1L << 30)) return false;
+    if (labs(jj) > (1L << 30) / s) return false;
     // worst phase error over the grid at the outermost sample
     const long double p_max = 0.5L * n * fabsl((long double)step) + fabsl((long double)step);
     long double worst = 0;
     for (int j = 0; j < M; ++j)
         worst = fmaxl(worst, fabsl((long double)u[j] - (jj + j) * du_exact));
     if (2 * M_PIl * kappa * p_max * worst > tol) return false;
-    *N_eff = (int)N;
+    *N_eff = (int)Ne;
     *j0 = (int)jj;
+    *jstep = (int)s;
     return true;
 }
 
 int zfft_build_tables(hipStream_t stream, double *tw1, double *wk, double *pj, int *kbin, int M, int j0,
-                      int N_eff, int c) {
+                      int N_eff, int c, int jstep) {
     const int n = M > 256 ? M : 256;
     hipLaunchKernelGGL(zfft_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, stream,
                        reinterpret_cast<cd *>(tw1), reinterpret_cast<cd *>(wk),
-                       reinterpret_cast<cd *>(pj), kbin, M, j0, N_eff, c);
+                       reinterpret_cast<cd *>(pj), kbin, M, j0, N_eff, c, jstep);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }
@@ -672,6 +686,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     a.g.pad1 = c.pad1;
     a.g.pad2 = c.pad2;
     a.g.ip = 0;
+    a.g.jstep = c.jstep;
     a.in = reinterpret_cast<const cd *>(c.in);
     a.in_s1 = c.in_s1;
     a.in_s2 = c.in_s2;
@@ -734,7 +749,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
         if (P > 1 && R3 % P == 0) {
             const int R3P = R3 / P, NTp = 16 * R3P, M = a.g.M;
             FftArgs ap = a;
-            zfft_choose_pads(c.N_eff / P, M, c.j0, &ap.g.pad1, &ap.g.pad2);
+            zfft_choose_pads(c.N_eff / P, M, c.j0, &ap.g.pad1, &ap.g.pad2, c.jstep);
             zf::Geo gp = ap.g;
             gp.R3 = R3P;
             const size_t bytes = ((size_t)zf::lds_elems(gp) + 256 + M) * sizeof(cd);   // + twiddles + pass ratios
@@ -756,7 +771,7 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     if (a.g.R3 <= ML_ZFFT_IP && (a.g.R3 == 4 || a.g.R3 == 8 || a.g.R3 == 16 || a.g.R3 == 32)) {
         // the in-place layout answers to one padding, chosen for its four access patterns
         a.g.ip = 1;
-        zfft_choose_pads(-c.N_eff, c.M, c.j0, &a.g.pad1, &a.g.pad2);
+        zfft_choose_pads(-c.N_eff, c.M, c.j0, &a.g.pad1, &a.g.pad2, c.jstep);
         lds_bytes = ((size_t)zf::lds_elems(a.g) + 256) * sizeof(cd);
     }
     // PASS (a template argument so that profiles can tell the launches apart): 1 rows of the aperture,
@@ -783,13 +798,13 @@ int zfft_run(hipStream_t stream, const ZfftCall &c) {
     }
 }
 
-void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2) {
+void zfft_choose_pads(int N_eff, int M, int j0, int *pad1, int *pad2, int jstep) {
     // a few milliseconds of host time per new (lattice, window): remembered
-    static std::map<std::tuple<int, int, int>, std::pair<int, int>> memo;
-    const auto key = std::make_tuple(N_eff, M, j0);
+    static std::map<std::tuple<int, int, int, int>, std::pair<int, int>> memo;
+    const auto key = std::make_tuple(N_eff, M, j0, jstep);
     auto hit = memo.find(key);
     if (hit == memo.end()) {
-        zf::Geo g{std::abs(N_eff) / 256, std::abs(N_eff), M, j0, 0, 0, N_eff < 0 ? 1 : 0};   // (N_eff < 0: in place)
+        zf::Geo g{std::abs(N_eff) / 256, std::abs(N_eff), M, j0, 0, 0, N_eff < 0 ? 1 : 0, jstep};   // (N_eff < 0: in place)
         zf::choose_pads(g);
         if (memo.size() > 4096) memo.clear();
         hit = memo.emplace(key, std::make_pair(g.pad1, g.pad2)).first;

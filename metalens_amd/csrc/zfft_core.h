@@ -109,6 +109,11 @@ struct Geo {
     // read and the write, so the barrier between them goes, and the last stage finds the R3 residues
     // of a bin in R3 CONSECUTIVE elements.
     int ip;
+    // wanted bin of output j = (j + j0) jstep: 1 on the aperture's own lattice padded to 256 R3 samples;
+    // s > 1 when the aperture's lattice of N samples is NOT a multiple of 256 long and the transform runs
+    // on the s-times finer lattice of N s = 256 R3 samples (the aperture zero-padded), of which every
+    // s-th bin is a bin of the aperture's own (zfft.hip zfft_commensurate)
+    int jstep = 1;
 };
 ZF_HD int lds_elems(const Geo &g) {
     const int e1 = (16 * g.R3 + g.pad1) * 16, e2 = (256 + g.pad2) * g.R3;
@@ -120,8 +125,8 @@ ZF_HD int ex2ip_addr(const Geo &g, int n0, int k1, int k2) { return ex1_addr(g, 
 // wanted bin of output j, reduced to [0, N_eff)
 ZF_HD int bin_of(const Geo &g, int j) {
     const int N = 256 * g.R3;
-    int k = (j + g.j0) % N;
-    return k < 0 ? k + N : k;
+    long long k = ((long long)(j + g.j0) * g.jstep) % N;
+    return (int)(k < 0 ? k + N : k);
 }
 
 // ---- the phases, one thread each -------------------------------------------------------------

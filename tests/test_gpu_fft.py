@@ -53,6 +53,11 @@ def fields(nx, ny, seed):
     (20, 12288, 512, 12288, 24, 100, -12, -50),     # R3 = 48 -> two sub-sequences of R3 = 24
     (16, 20000, 256, 24576, 16, 90, -8, -45),       # R3 = 96 -> three of R3 = 32, zero-padded axis
     (16384, 12, 16384, 256, 70, 12, -35, -6),       # ... and along x (the column pass)
+    # lattices that are not multiples of 256 long (what good_fft_number hands out, nearfield.py:30-36):
+    (400, 1920, 400, 1920, 400, 256, -200, -128),   # 16 x 25 and 128 x 15: on the 16 / 2 times finer lattice
+    (960, 1152, 960, 1152, 100, 1152, -50, -576),   # 64 x 15, 128 x 9
+    (2000, 48, 2000, 300, 64, 20, -32, -10),        # 16 x 125: five sub-sequences of 6400; 4 x 75 -> 64 x 300
+    (90, 3600, 256, 3600, 16, 128, -8, -64),        # 16 x 225: nine sub-sequences
 ])
 def test_lattice_grids_take_the_fft_and_match_the_oracle(ma, ctx, nx, ny, nex, ney, mx, my, jx, jy):
     from oracle import farfield_oracle

@@ -10,8 +10,10 @@
 
 using zf::cd;
 
-static double run(int R3, int n_valid, int M, int j0, bool verbose, int ip = 0) {
-    zf::Geo g{R3, n_valid, M, j0, 0, 0, ip};
+// jstep > 1: the lattice asked for has 256 R3 / jstep samples (not a multiple of 256: the reference's
+// default grids) and the transform runs on the jstep-times finer one, every jstep-th bin wanted
+static double run(int R3, int n_valid, int M, int j0, bool verbose, int ip = 0, int jstep = 1) {
+    zf::Geo g{R3, n_valid, M, j0, 0, 0, ip, jstep};
     zf::choose_pads(g);
     const int NT = 16 * R3, N = 256 * R3;
     std::vector<cd> in(N), lds(zf::lds_elems(g));
@@ -79,9 +81,9 @@ static double run(int R3, int n_valid, int M, int j0, bool verbose, int ip = 0) 
     }
     const zf::LdsCost c = zf::lds_cost(g);
     if (verbose)
-        printf("%sR3=%2d N=%5d valid=%5d M=%4d j0=%5d pads=(%d,%d) lds=%6d B  err=%.2e  cycles ex1 w/r %ld/%ld "
+        printf("%s%sR3=%2d N=%5d valid=%5d M=%4d j0=%5d pads=(%d,%d) lds=%6d B  err=%.2e  cycles ex1 w/r %ld/%ld "
                "ex2 w/r %ld/%ld (ideal w %ld r %ld)\n",
-               ip ? "in place: " : "", R3, N, n_valid, M, j0, g.pad1, g.pad2, zf::lds_elems(g) * 16, worst / scale, c.ex1_write,
+               ip ? "in place: " : "", jstep > 1 ? "padded lattice: " : "", R3, N, n_valid, M, j0, g.pad1, g.pad2, zf::lds_elems(g) * 16, worst / scale, c.ex1_write,
                c.ex1_read, c.ex2_write, c.ex2_read, c.ideal_rw * 8 / 12, c.ideal_rw * 4 / 12);
     return worst / scale;
 }
@@ -154,6 +156,11 @@ int main() {
                             {16, 4096, 4096, -2048}, {5, 1280, 77, -3}, {12, 3072, 512, -256}};
     for (auto &c : cases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true));
     for (auto &c : cases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true, 1));   // exchange 2 in place
+    // lattices that are not multiples of 256 long, zero-padded to the next finer one that is:
+    // 400 = 6400 / 16, 1920 = 3840 / 2, 960 = 3840 / 4, 384 = 768 / 2, 1152 = 2304 / 2
+    const int scases[][5] = {{25, 400, 400, -200, 16}, {15, 1920, 300, -150, 2}, {15, 960, 960, -480, 4},
+                             {3, 384, 100, -50, 2},    {9, 1152, 64, 500, 2}};
+    for (auto &c : scases) worst = fmax(worst, run(c[0], c[1], c[2], c[3], true, 0, c[4]));
     const int pcases[][5] = {{16, 2, 4096, 512, -256}, {32, 2, 8192, 512, -256}, {8, 2, 2048, 256, -128},
                              {16, 4, 4000, 512, -256}, {32, 4, 8192, 300, 4000}, {12, 2, 3072, 100, -50}};
     for (auto &c : pcases) worst = fmax(worst, run_passes(c[0], c[1], c[2], c[3], c[4]));
