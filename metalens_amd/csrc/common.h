@@ -286,6 +286,7 @@ struct ml_ctx {
     ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
     bool simple_orders = false;   // every table in use: orders (ox, 0), |ox| <= 5 only (refresh_ring_locations)
+    int wide_mask = 0, narrow_exists = 0;   // simple order sets: NfArgs::wide_mask / narrow_exists
     double ring_bounds_all[4] = {0, 0, 0, 0};   // intersection of the ring tables' (ux', uy') bounds (NfArgs)
 
     // layout
@@ -340,8 +341,8 @@ struct ml_ctx {
     // per-sample geometry records (nearfield_fast.hip) and what they were built for:
     // (grid_serial, layout_serial, ovr_serial, samples)
     ml::DevBuf geo_ix, active_list, active_count, active_flag;
-    long geo_key[4] = {-1, -1, -1, -1};
-    int n_active[3] = {-1, 0, 0};   // entries of the three patch lists (NfArgs::active_list); [0] = -1: not read back yet
+    long geo_key[5] = {-1, -1, -1, -1, -1};
+    int n_active[4] = {-1, 0, 0, 0};   // entries of the four patch lists (NfArgs::active_list); [0] = -1: not read back yet
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores

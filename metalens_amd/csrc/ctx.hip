@@ -198,6 +198,15 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         ctx->zero_key[1] = -1;
     }
     ctx->simple_orders = simple;
+    // which ring collections go to the wide instantiation of the ring kernel (nearfield_simple.hip): part of
+    // what the patch lists were built for (nearfield.hip geo_key)
+    ctx->wide_mask = ctx->narrow_exists = 0;
+    for (int c = 0; simple && c < ctx->n_colls; ++c) {
+        if (canon[c].n > SIMPLE_NARROW_SLOTS)
+            ctx->wide_mask |= 1 << c;
+        else
+            ctx->narrow_exists = 1;
+    }
     int dense_of[MAX_SLOTS];
     for (int c = 0; c < ctx->n_colls; ++c) dense_of[ctx->coll_slot[c]] = c;
     std::vector<long long> tab_off(ctx->n_rings);
@@ -925,8 +934,8 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
         ++ctx->ovr_serial;
     }
     ML_TRY(ctx->geo_ix.reserve((size_t)blocks * 64 * 2 * sizeof(int)));   // patch-major, 64 per patch
-    ML_TRY(ctx->active_list.reserve((size_t)3 * blocks * 2 * sizeof(int)));           // three lists (NfArgs::active_list)
-    ML_TRY(ctx->active_count.reserve((size_t)3 * (blocks / 1024 + 4) * sizeof(int)));   // each: total + one per chunk of 1024 patches
+    ML_TRY(ctx->active_list.reserve((size_t)4 * blocks * 2 * sizeof(int)));           // four lists (NfArgs::active_list)
+    ML_TRY(ctx->active_count.reserve((size_t)4 * (blocks / 1024 + 4) * sizeof(int)));   // each: total + one per chunk of 1024 patches
     ML_TRY(ctx->active_flag.reserve((size_t)blocks * sizeof(int)));
     return nearfield_launch(ctx, p, n, nx, ny);
 }

@@ -166,9 +166,11 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.use_active = 0;
     a.list_count = nullptr;
     a.first_pass = 0;
-    for (int k = 0; k < 3; ++k) a.n_active[k] = 0;
+    for (int k = 0; k < 4; ++k) a.n_active[k] = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;
+    a.wide_mask = ctx->wide_mask;
+    a.narrow_exists = ctx->narrow_exists;
     a.center_n_slots = ctx->center_n_slots;
     a.center_lo = ctx->center_lo;
     a.center_present = ctx->center_present_mask;
@@ -202,7 +204,9 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     }
     // the per-sample records depend on the grid, the layout and the tie answers: rebuilt when one
     // of them changes (the samples the kernel cannot settle are counted from zero each time)
-    const long geo_key[4] = {ctx->grid_serial, ctx->layout_serial, ctx->ovr_serial, (long)nx * ny};
+    // (... and, for the lists, on which collections are the wide ring instantiation's)
+    const long geo_key[5] = {ctx->grid_serial, ctx->layout_serial, ctx->ovr_serial, (long)nx * ny,
+                             ctx->simple_orders ? (long)ctx->wide_mask : -2};
     if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
         ProfScope scope(ctx, ML_K_TWIDDLE);
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
@@ -222,17 +226,17 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
         // numbers come back from the GPU once per geometry (three 4-byte copies, one synchronisation);
         // the power partials of the others stay at the zeros written here.
         if (ctx->n_active[0] < 0) {
-            const int lo = ctx->simple_orders ? 1 : 0, hi = ctx->simple_orders ? 2 : 0;
-            for (int k = 0; k < 3; ++k) ctx->n_active[k] = 0;
+            const int lo = ctx->simple_orders ? 1 : 0, hi = ctx->simple_orders ? 3 : 0;
+            for (int k = 0; k < 4; ++k) ctx->n_active[k] = 0;
             for (int k = lo; k <= hi; ++k)
                 ML_HIP(hipMemcpyAsync(&ctx->n_active[k], ctx->active_count.as<int>() + (size_t)k * a.count_stride,
                                       sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
             ML_HIP(hipMemsetAsync(ctx->partial_power.p, 0, ctx->partial_power.bytes, ctx->stream));
             ML_HIP(hipStreamSynchronize(ctx->stream));
         }
-        if (ctx->n_active[0] + ctx->n_active[1] + ctx->n_active[2] > 0) {
+        if (ctx->n_active[0] + ctx->n_active[1] + ctx->n_active[2] + ctx->n_active[3] > 0) {
             a.use_active = 1;
-            for (int k = 0; k < 3; ++k) a.n_active[k] = ctx->n_active[k];
+            for (int k = 0; k < 4; ++k) a.n_active[k] = ctx->n_active[k];
         }
     }
     // members at ONE source position share everything but two real weights per sample and go through
@@ -255,7 +259,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
                 fill_nf_args(ctx, p + m, 1, nx, ny, am);
                 am.outside_is_zero = a.outside_is_zero;
                 am.use_active = a.use_active;
-                for (int k = 0; k < 3; ++k) am.n_active[k] = a.n_active[k];
+                for (int k = 0; k < 4; ++k) am.n_active[k] = a.n_active[k];
                 am.fields += (size_t)m * 4 * nx * ny * 2;
                 am.partial_power += (size_t)m * a.n_partials;
                 ML_TRY(nearfield_fast_launch(ctx, am, &n_partials));

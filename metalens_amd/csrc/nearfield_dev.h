@@ -87,12 +87,13 @@ struct NfArgs {
     int2 *geo_ix;      // [patch][64]: patch = by * patches_x + bx, 8 x 8 samples each
     // lists of 8 x 8 patches (written behind kernel 1, nearfield_geometry_launch): list k at
     // active_list + k list_stride with n_active[k] entries - 0: patches with a lens sample (general
-    // kernels), 1: with a ring sample, 2: with a centre sample (nearfield_simple.hip); use_active: the
-    // field kernels' grids are the lists instead of all patches
+    // kernels), 1: with a ring sample of a NARROW collection, 2: with a centre sample, 3: with a ring
+    // sample of a WIDE collection (nearfield_simple.hip: wide_mask); use_active: the field kernels'
+    // grids are the lists instead of all patches
     int2 *active_list;
     int *active_count, *active_flag;
     int list_stride, count_stride;
-    int use_active, n_active[3], patches_x;
+    int use_active, n_active[4], patches_x;
     // the first synthesis into a buffer runs the ring kernel over the WHOLE grid (it stores the zeros
     // outside the lens and sums every patch's incident power) and the centre kernel from its list with
     // the entry count read on the device (list_count; the host has not seen it yet): first_pass tells
@@ -102,6 +103,9 @@ struct NfArgs {
     // every table of the lens holds orders (ox, 0), |ox| <= 5, only: the kernels that build an
     // order's phasor by products run (nearfield_simple.hip), else the general ones
     int simple_orders;
+    // simple order sets: bit c = dense collection c holds more than SIMPLE_NARROW_SLOTS orders (its samples are
+    // the wide ring instantiation's); narrow_exists: some collection does not
+    int wide_mask, narrow_exists;
     int center_n_slots, center_lo, center_present;   // centre table, simple order sets: as CollDesc::n_slots / ox_lo / present
     // the (ux', uy') range every ring table covers (intersection of their bounds: lo0, hi0, lo1, hi1);
     // a sample inside it cannot trip a table bound, and only the others read their ring's own bounds

@@ -289,12 +289,17 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
     }
     // patches with at least one sample inside the lens: the field kernels visit only these once
     // the zeros of the others are in place.  Flags per patch here - bit 0 any lens sample, bit 1 any
-    // ring sample, bit 2 any centre sample - compacted into lists by active_compact_kernel (190 k
+    // ring sample of a narrow collection, bit 2 any centre sample, bit 3 any ring sample of a wide
+    // collection - compacted into lists by active_compact_kernel (190 k
     // waves adding to ONE counter took 2 ms)
-    const int any_ring = __any(idx >= 1 && idx <= a.n_rings), any_centre = __any(idx == 0);   // all lanes vote
+    // (ring samples by the instantiation of nearfield_simple.hip that takes their collection: NfArgs::wide_mask)
+    const bool ring = idx >= 1 && idx <= a.n_rings;
+    const bool wide = ring && ((a.wide_mask >> a.ring_coll[min(max(idx, 1), a.n_rings) - 1]) & 1);
+    const int any_ring = __any(ring), any_centre = __any(idx == 0);   // all lanes vote
+    const int any_narrow = __any(ring && !wide), any_wide = __any(wide);
     if (lane == 0)
         a.active_flag[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
-            ((any_ring | any_centre) ? 1 : 0) | (any_ring ? 2 : 0) | (any_centre ? 4 : 0);
+            ((any_ring | any_centre) ? 1 : 0) | (any_narrow ? 2 : 0) | (any_centre ? 4 : 0) | (any_wide ? 8 : 0);
 }
 
 // flags -> list of (bx, by) of the patches whose flags meet `mask`, in patch order.  Two small
@@ -776,7 +781,13 @@ int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     // the lists the field kernels of this lens launch from (NfArgs::active_list): every lens patch
     // for the general kernels; ring patches and centre patches for the two kernels of nearfield_simple.hip
     const int n_patches = (int)(grid.x * grid.y), chunks = (n_patches + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
-    for (int k = a.simple_orders ? 1 : 0; k <= (a.simple_orders ? 2 : 0); ++k) {
+    for (int k = a.simple_orders ? 1 : 0; k <= (a.simple_orders ? 3 : 0); ++k) {
+        // (a list nobody launches from: narrow ring patches of a lens without narrow collections, or wide ones
+        // of a lens without wide collections - its count stays at the zero written here)
+        if ((k == 1 && !a.narrow_exists) || (k == 3 && !a.wide_mask)) {
+            ML_HIP(hipMemsetAsync(a.active_count + (size_t)k * a.count_stride, 0, sizeof(int), ctx->stream));
+            continue;
+        }
         int *count = a.active_count + (size_t)k * a.count_stride;
         hipLaunchKernelGGL(active_count_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
                            1 << k, n_patches, count);

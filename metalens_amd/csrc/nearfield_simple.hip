@@ -470,10 +470,19 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     const int cell_type = idx >> REC_TYPE_SHIFT;   // (ring samples: the collection)
     idx &= (1 << REC_TYPE_SHIFT) - 1;
     const bool lens = idx <= K.n_rings;
-    const bool peri = lens && idx >= 1;
+    const bool peri_any = lens && idx >= 1;   // a ring sample
+    // ... of THIS instantiation: the collections of a lens are dealt to the two ring instantiations by their
+    // order count (NfArgs::wide_mask: bit per dense collection number), each launched over the patches
+    // that hold samples of its collections - a patch on the border between a narrow and a wide collection
+    // is visited by both, each storing its own samples
+    const bool peri = PART == PART_RING ? peri_any && (((a.wide_mask >> cell_type) & 1) != 0) == WIDE : peri_any;
     // who sums the patch's incident power and stores its zeros: see above
     // (the full-grid launch - the first synthesis into a buffer - visits every patch with the ring kernel)
-    const bool mine_too = PART == PART_RING || (LISTED && !a.first_pass && !__ballot(peri));   // wave-uniform
+    // (ring samples of a narrow collection: the narrow instantiation's patch; else of a wide one: the wide
+    // instantiation's; else the centre kernel's.  On the first synthesis into a buffer one ring instantiation
+    // - the narrow one if the lens has narrow collections - runs over the whole grid and does it for every patch)
+    const bool mine_too = PART == PART_RING ? (!WIDE || !a.narrow_exists || (LISTED && !a.first_pass && !__ballot(peri_any && !peri)))
+                                            : (LISTED && !a.first_pass && !__ballot(peri_any));   // wave-uniform
     if (mine_too) {
 #pragma unroll
         for (int m = 0; m < NP; ++m) wave_power_k(a, K, lens ? power_in[m] : 0.0, bx, by, m);
@@ -486,7 +495,7 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     ML_MARK(2, Hx_i[0]);   // incident field and power done
 
     if (PART == PART_CENTRE) {
-        if (!__ballot(lens && !peri)) return;   // (wave-uniform; only on the full-grid launch)
+        if (!__ballot(lens && !peri_any)) return;   // (wave-uniform; only on the full-grid launch)
     // ================= centre: the record holds the nearest hexagonal cell =================
     // The lanes of a patch sit in ~50 cells of up to K types, and (the direction of incidence
     // hardly changes over 2 um) almost always in ONE (ux, uy) cell of the centre table.  Per
@@ -496,7 +505,7 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     // way into the other buffer while order o is evaluated.  A round serves the lanes of one
     // (table cell, group of types); a wave that straddles a table cell, or a table of more
     // types, takes more rounds.
-    const bool cen = lens && !peri && aux >= 0;
+    const bool cen = lens && !peri_any && aux >= 0;
     AccS acc[NP];
 #pragma unroll
     for (int m = 0; m < NP; ++m) acc[m] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -597,7 +606,7 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         }
     }
 
-        if (lens && !peri) {
+        if (lens && !peri_any) {
 #pragma unroll
             for (int m = 0; m < NP; ++m)
                 store_fields_k(K, m, i, j, {acc[m].Exr, acc[m].Exi}, {acc[m].Eyr, acc[m].Eyi},
@@ -921,12 +930,14 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
 // LISTED: the launch is a list of patches (`list`, a leading kernel argument of its own so that the
 // pointer can arrive in scalar registers with the wave - kernarg preload, see the Makefile - and the
 // list entry is the FIRST load of the wave, not the third of a dependent chain); else the whole grid
-// WIDE: some ring collection of the lens holds more than SMALL_SLOTS = 4 orders
+// WIDE: the instantiation for the ring collections of more than SIMPLE_NARROW_SLOTS = 4 orders (NfArgs::wide_mask)
 template <int NP, bool LISTED, bool WIDE>
 __global__ __launch_bounds__(64, NP == 1 ? ML_NF_RING_MINW : 3) void nearfield_ring_kernel(const int2 *list, const NfArgs a) {
     __shared__ double2 s_tab[WIDE ? RING_LDS : RING_LDS_NARROW];
     int bx = blockIdx.x, by = blockIdx.y;
     if (LISTED) {
+        // (first pass: the launch covers every patch number, the list's length is on the device)
+        if (a.list_count && (int)blockIdx.x >= *a.list_count) return;
         const int2 pb = list[blockIdx.x];
         bx = pb.x;
         by = pb.y;
@@ -956,27 +967,40 @@ extern "C" int ml_debug_phase_dump(unsigned long long *dst, size_t n_waves) {
 }
 #endif
 
-template <int NP, bool WIDE>
+template <int NP>
 static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
     const dim3 full((a.ny + 7) / 8, (a.nx + 7) / 8);
-    // (the two kernels write disjoint samples and could run side by side: with the centre kernel forked
+    const bool narrow = a.narrow_exists != 0, wide = a.wide_mask != 0;
+    // (the kernels write disjoint samples and could run side by side: with the centre kernel forked
     // off to a second stream and joined back by events the step measured 1.5 % SLOWER at 4096^2 and 5 %
     // at 2048^2 - the events cost more than the ring kernel's idle issue slots give)
     if (!a.use_active) {
-        // first synthesis into this buffer: the ring kernel visits every patch (zeros outside the lens,
-        // every patch's power); the centre kernel works from its list, whose length only the device
-        // knows yet - a launch over all patch numbers in which the surplus workgroups leave at once
-        // (87 -> 45 us at 4096^2 against the full-grid centre kernel)
-        hipLaunchKernelGGL((nearfield_ring_kernel<NP, false, WIDE>), full, dim3(64), 0, ctx->stream, nullptr, a);
+        // first synthesis into this buffer: ONE ring instantiation visits every patch (zeros outside the
+        // lens, every patch's power) - the narrow one if the lens has narrow collections; the other ring
+        // instantiation and the centre kernel work from their lists, whose lengths only the device knows
+        // yet - launches over all patch numbers in which the surplus workgroups leave at once
+        // (87 -> 45 us at 4096^2 against a full-grid centre kernel)
         NfArgs c = a;
-        c.list_count = a.active_count + (size_t)2 * a.count_stride;
         c.first_pass = 1;
+        if (narrow || !wide)
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, false, false>), full, dim3(64), 0, ctx->stream, nullptr, a);
+        else
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, false, true>), full, dim3(64), 0, ctx->stream, nullptr, a);
+        if (narrow && wide) {
+            c.list_count = a.active_count + (size_t)3 * a.count_stride;
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true, true>), dim3(full.x * full.y), dim3(64), 0, ctx->stream,
+                               a.active_list + (size_t)3 * a.list_stride, c);
+        }
+        c.list_count = a.active_count + (size_t)2 * a.count_stride;
         hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(full.x * full.y), dim3(64), 0, ctx->stream,
                            a.active_list + (size_t)2 * a.list_stride, c);
     } else {
         if (a.n_active[1] > 0)
-            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true, WIDE>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true, false>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)1 * a.list_stride, a);
+        if (a.n_active[3] > 0)
+            hipLaunchKernelGGL((nearfield_ring_kernel<NP, true, true>), dim3(a.n_active[3]), dim3(64), 0, ctx->stream,
+                               a.active_list + (size_t)3 * a.list_stride, a);
         if (a.n_active[2] > 0)
             hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)2 * a.list_stride, a);
@@ -986,11 +1010,7 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
 }
 
 int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a) {
-    // (the widest ring collection decides which instantiation runs; every collection runs its own order count in either)
-    bool wide = false;
-    for (int c = 0; c < ctx->n_colls; ++c) wide = wide || ctx->h_coll[c].n_slots > SIMPLE_NARROW_SLOTS;
-    if (wide) return a.n_pol == 1 ? launch_parts<1, true>(ctx, a) : a.n_pol == 2 ? launch_parts<2, true>(ctx, a) : launch_parts<3, true>(ctx, a);
-    return a.n_pol == 1 ? launch_parts<1, false>(ctx, a) : a.n_pol == 2 ? launch_parts<2, false>(ctx, a) : launch_parts<3, false>(ctx, a);
+    return a.n_pol == 1 ? launch_parts<1>(ctx, a) : a.n_pol == 2 ? launch_parts<2>(ctx, a) : launch_parts<3>(ctx, a);
 }
 
 }  // namespace ml
