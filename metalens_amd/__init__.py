@@ -10,7 +10,7 @@ from .lens_center import HexGridSet  # noqa: F401
 from .nearfield import build_nearfield, build_nearfield_big, good_fft_number  # noqa: F401
 from .pipeline import HotPath  # noqa: F401
 from .prepared import PreparedLens  # noqa: F401
-from .sweep import SourceSweep  # noqa: F401
+from .sweep import SourceSweep, WavelengthSweep  # noqa: F401
 from .nearfield_farfield import (FarfieldTransform, farfield_direct,  # noqa: F401
                                  farfield_from_nearfield, farfield_from_resident_nearfield,
                                  fft_direction_cosines)

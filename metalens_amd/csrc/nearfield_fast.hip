@@ -325,18 +325,31 @@ __device__ __forceinline__ int chunk_scan(int mine, int *s_wave, int &total) {
     return base + before;
 }
 
-__global__ __launch_bounds__(COMPACT_CHUNK) void active_count_kernel(const int *flag, int mask, int n_patches, int *count) {
+// blockIdx.y = which list: mask = masks[y] (0: a list nobody launches from - its count is written as 0),
+// count / list = the y-th of arrays count_stride / list_stride apart
+struct CompactLists {
+    int mask[4], first, n;   // lists first ... first + n - 1
+};
+
+__global__ __launch_bounds__(COMPACT_CHUNK) void active_count_kernel(const int *flag, CompactLists L, int n_patches, int *count,
+                                                                     int count_stride) {
     __shared__ int s_wave[COMPACT_CHUNK / 64];
+    const int mask = L.mask[blockIdx.y];
+    count += (size_t)(L.first + blockIdx.y) * count_stride;
     const int k = blockIdx.x * COMPACT_CHUNK + threadIdx.x;
     int total;
     chunk_scan(k < n_patches ? (flag[k] & mask) != 0 : 0, s_wave, total);
     if (threadIdx.x == 0) count[1 + blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int *flag, int mask, int n_patches,
-                                                                       int patches_x, int2 *list, int *count) {
+__global__ __launch_bounds__(COMPACT_CHUNK) void active_compact_kernel(const int *flag, CompactLists L, int n_patches,
+                                                                       int patches_x, int2 *list, int list_stride,
+                                                                       int *count, int count_stride) {
     __shared__ int s_wave[COMPACT_CHUNK / 64];
     __shared__ int s_before[COMPACT_CHUNK / 64];
+    const int mask = L.mask[blockIdx.y];
+    count += (size_t)(L.first + blockIdx.y) * count_stride;
+    list += (size_t)(L.first + blockIdx.y) * list_stride;
     // lens patches in the chunks before this one (a few hundred chunks at most)
     int part = 0;
     for (int c = threadIdx.x; c < (int)blockIdx.x; c += COMPACT_CHUNK) part += count[1 + c];
@@ -781,21 +794,23 @@ int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     // the lists the field kernels of this lens launch from (NfArgs::active_list): every lens patch
     // for the general kernels; ring patches and centre patches for the two kernels of nearfield_simple.hip
     const int n_patches = (int)(grid.x * grid.y), chunks = (n_patches + COMPACT_CHUNK - 1) / COMPACT_CHUNK;
-    for (int k = a.simple_orders ? 1 : 0; k <= (a.simple_orders ? 3 : 0); ++k) {
-        // (a list nobody launches from: narrow ring patches of a lens without narrow collections, or wide ones
-        // of a lens without wide collections - its count stays at the zero written here)
-        if ((k == 1 && !a.narrow_exists) || (k == 3 && !a.wide_mask)) {
-            ML_HIP(hipMemsetAsync(a.active_count + (size_t)k * a.count_stride, 0, sizeof(int), ctx->stream));
-            continue;
-        }
-        int *count = a.active_count + (size_t)k * a.count_stride;
-        hipLaunchKernelGGL(active_count_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
-                           1 << k, n_patches, count);
-        ML_HIP(hipGetLastError());
-        hipLaunchKernelGGL(active_compact_kernel, dim3(chunks), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag,
-                           1 << k, n_patches, (int)grid.x, a.active_list + (size_t)k * a.list_stride, count);
-        ML_HIP(hipGetLastError());
+    // (all the lists of the lens in ONE launch of each of the two kernels: blockIdx.y = list.  A list nobody
+    // launches from - narrow ring patches of a lens without narrow collections, wide ones of a lens without
+    // wide collections - gets the mask 0: nothing listed, count 0)
+    CompactLists L;
+    L.first = a.simple_orders ? 1 : 0;
+    L.n = a.simple_orders ? 3 : 1;
+    for (int y = 0; y < 4; ++y) L.mask[y] = 0;
+    for (int y = 0; y < L.n; ++y) {
+        const int k = L.first + y;
+        L.mask[y] = ((k == 1 && !a.narrow_exists) || (k == 3 && !a.wide_mask)) ? 0 : 1 << k;
     }
+    hipLaunchKernelGGL(active_count_kernel, dim3(chunks, L.n), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag, L, n_patches,
+                       a.active_count, a.count_stride);
+    ML_HIP(hipGetLastError());
+    hipLaunchKernelGGL(active_compact_kernel, dim3(chunks, L.n), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag, L,
+                       n_patches, (int)grid.x, a.active_list, a.list_stride, a.active_count, a.count_stride);
+    ML_HIP(hipGetLastError());
     return ML_OK;
 }
 

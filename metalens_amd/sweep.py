@@ -213,3 +213,65 @@ class SourceSweep:
         if keep_each:
             out['P_each'] = each
         return out
+
+
+class WavelengthSweep:
+    """Sources x WAVELENGTHS ("(source_x, source_y, source_pol, lambda) per
+    launch"; the tri-colour emitter of BASELINE configs[3] on ONE GPU).
+
+    A wavelength changes everything a context holds - the table key (nearfield.py:111), the sample
+    grid (pitch lambda / 2.2, :95-97), hence the geometry records, the far-field plan - so each
+    member wavelength gets a context of its own on the same GPU, and all of them stay resident
+    side by side: tables, layout, records, field sets and plans are uploaded / built ONCE per
+    wavelength, not once per (source, wavelength) visit as with one context re-used in turn (a
+    4096^2 member is 1.2 GB of a 288 GB GPU).  The members' passes are queued on their own streams;
+    nothing synchronises between them until the sums are fetched.
+
+    ``members`` = one dict per wavelength with the arguments of ``SourceSweep`` (``wavelength``,
+    ``lens_periphery_summary``, ``lens_center_summary``, ``hexgridset``, ``x_pts``, ``y_pts``,
+    ``ux``, ``uy`` and optionally ``dipole_moment``, ``c0``, ``Z0``, ``units``); the lens objects may
+    be shared between members (one collection list characterised at several wavelengths) or not."""
+
+    def __init__(self, members, device=None, precision=None, method=None):
+        if not members:
+            raise ValueError('a wavelength sweep needs at least one member')
+        self.contexts = [_lib.Context(device) for _ in members]
+        self.sweeps = [SourceSweep(ctx=ctx, precision=precision, method=method, **m)
+                       for ctx, m in zip(self.contexts, members)]
+        self.wavelengths = [m['wavelength'] for m in members]
+
+    def queue(self, sources):
+        """queue every member's whole sweep and return without synchronising (benchmarks; see
+        ``SourceSweep.queue`` for what is and is not re-checked)"""
+        for sw in self.sweeps:
+            sw.queue(sources)
+
+    def sync(self):
+        for ctx in self.contexts:
+            ctx.sync()
+
+    def run(self, sources, weights=None, spectrum=None, **kwargs):
+        """``SourceSweep.run`` per wavelength (same sources, weights and cone).  Returns a dict:
+        ``per_wavelength`` (the members' result dicts, in order) and ``efficiency`` = the spectrum-
+        weighted ``sum_l s_l sum_k total_P / sum_l s_l sum_k power_in`` (``spectrum`` = relative
+        spectral weights s_l, default equal); ``P_sum`` = the spectrum-weighted sum of the members'
+        maps when they share one direction grid (else absent)."""
+        sources = list(sources)
+        s = np.ones(len(self.sweeps)) if spectrum is None else np.asarray(spectrum, dtype=float)
+        if s.shape != (len(self.sweeps),):
+            raise ValueError('spectrum must have one weight per wavelength')
+        # (member after member: each run settles its own nearest-cell ties and reads its sums back;
+        # what a member left on its context - tables, layout, records, plan - is there for the next call)
+        out = [sw.run(sources, weights=weights, **kwargs) for sw in self.sweeps]
+        res = {'per_wavelength': out, 'wavelengths': list(self.wavelengths)}
+        num = sum(w * o['total_P'].sum() for w, o in zip(s, out))
+        den = sum(w * o['power_in'].sum() for w, o in zip(s, out))
+        res['efficiency'] = num / den if den else np.nan
+        first = self.sweeps[0]
+        if all(np.array_equal(sw.ux, first.ux) and np.array_equal(sw.uy, first.uy) for sw in self.sweeps):
+            res['P_sum'] = sum(w * o['P_sum'] for w, o in zip(s, out))
+        return res
+
+    def close(self):
+        for ctx in self.contexts:
+            ctx.close()

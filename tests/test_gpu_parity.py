@@ -408,6 +408,45 @@ def test_paper_lens_na094_windows_vs_oracle(ma, pol):
         assert abs(got[6] - want[6]) <= 1e-12 * abs(want[6])
 
 
+def test_wavelength_sweep_keeps_every_wavelength_resident(ma):
+    """sources x wavelengths on ONE GPU (BASELINE configs[3]'s three colours):
+    ``WavelengthSweep`` holds a context per wavelength - tables, layout, geometry records and plan of
+    450, 532 and 635 nm resident side by side - and gives, per wavelength, what a ``SourceSweep`` of
+    that wavelength alone gives; a second run uploads nothing"""
+    from metalens_amd import _lib
+    members, alone = [], []
+    sources = None
+    for wl_nm, n_glass in ((450, 0), (532, 1.4607), (635, 1.457)):
+        wl = wl_nm * 1e-9
+        lens = _synthetic_lens(30e-6, 0.4, wl, n_glass=n_glass, switch_deg=9.0)
+        n = ma.good_fft_number(2 * 31e-6 / (wl / 2.2))
+        x = (np.arange(n) - (n - 1) / 2) * (wl / 2.2)
+        u = np.linspace(-0.12, 0.12, 40)
+        members.append(dict(wavelength=wl, lens_periphery_summary=lens['lens_periphery_summary'],
+                            lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'],
+                            x_pts=x, y_pts=x, ux=u, uy=u))
+        # (one emitter for all colours: at the shortest focal distance of the three lenses)
+        f = lens['source_distance']
+        sources = sources or [(0.0, 0.0, -f, 'x'), (0.0, 0.0, -f, 'y'), (0.0, 0.0, -f, 'z'), (1e-6, 0.0, -f, 'x')]
+    for m in members:
+        alone.append(ma.SourceSweep(ctx=_lib.default_context(), **m).run(sources, cone=0.05))
+    ws = ma.WavelengthSweep(members)
+    got = ws.run(sources, cone=0.05, spectrum=(0.2, 0.5, 0.3))
+    tokens = [(c.tables_token, c.layout_token) for c in ws.contexts]
+    assert len({id(c) for c in ws.contexts}) == 3 and all(t[0] is not None for t in tokens)
+    for a, g in zip(alone, got['per_wavelength']):
+        for key in ('P_sum', 'power_in', 'total_P', 'cone_P'):
+            assert np.array_equal(a[key], g[key], equal_nan=True), key
+    want_eff = (sum(w * a['total_P'].sum() for w, a in zip((0.2, 0.5, 0.3), alone))
+                / sum(w * a['power_in'].sum() for w, a in zip((0.2, 0.5, 0.3), alone)))
+    assert abs(got['efficiency'] - want_eff) <= 1e-15 * want_eff
+    assert np.array_equal(got['P_sum'], sum(w * a['P_sum'] for w, a in zip((0.2, 0.5, 0.3), alone)), equal_nan=True)
+    again = ws.run(sources, cone=0.05, spectrum=(0.2, 0.5, 0.3))
+    assert [(c.tables_token, c.layout_token) for c in ws.contexts] == tokens     # nothing was uploaded again
+    assert np.array_equal(again['P_sum'], got['P_sum'], equal_nan=True)
+    ws.close()
+
+
 @pytest.mark.parametrize('wl_nm,n_glass', [(450, 0), (532, 1.4607), (635, 1.457)])
 def test_rgb_wavelengths_vs_oracle(ma, wl_nm, n_glass):
     """BASELINE config 4 (450 / 532 / 635 nm): 532 and 635 nm are not in the reference's glass
