@@ -313,6 +313,9 @@ def main():
                     help="diffraction orders in the synthetic tables: survey = (0,0), (-1,0), (+1,0) everywhere "
                          "(SURVEY.md 8(d)); physical = what characterize() would record, per collection and "
                          "direction (7 to 11 orders per ring collection of the default lens)")
+    ap.add_argument('--also-physical', type=int, default=1,
+                    help='1 (default, N = 1, --orders survey): after the timed region run the same workload with the '
+                         'physical order lists too and report it as `physical_orders`')
     ap.add_argument('--cold', type=int, default=1,
                     help='1: also time single steps on a sample grid the context has not seen '
                          '(ms_first_step_new_geometry); N = 1 only')
@@ -726,6 +729,42 @@ def main():
                     'second = reads the active-patch count back (one sync) and launches the listed '
                     'patches; third = a steady single step, launch latency included (the timed region '
                     'queues its steps back to back)'}
+    # ---- the same workload with the tables characterize() would really produce (--orders physical: 7 to 11 orders
+    # per ring collection instead of the three SURVEY.md 8(d) prescribes for the synthetic tables), timed after
+    # the timed region: what a lens out of the reference's own flow costs, on the same line
+    if world == 1 and n_pols == 1 and not args.pair_list and args.orders == 'survey' and args.also_physical:
+        lens_p, _, _ = build_workload(side, args.farfield, diameter, na, wavelength, args.zoom, n_glass, 'physical')
+        hp3 = HotPath(source, wavelength, lens_p['lens_periphery_summary'], lens_p['lens_center_summary'],
+                      lens_p['hexgridset'], x, x, ux, uy, ctx=ctx, precision=args.precision,
+                      fuse_modulation=bool(args.fuse_modulation), method=args.method)
+        hp3.step()
+        hp3.sync()
+        hp3.results()                      # (table bounds, nearest-cell ties)
+        # (the GPU has idled while the host built the second lens: the same priming as in front of the timed
+        # region - ~50 ms of steps - before anything is read off the clock)
+        t0 = time.perf_counter()
+        hp3.step()
+        hp3.sync()
+        for _ in range(max(args.warmup, 3, min(200, int(0.05 / max(time.perf_counter() - t0, 1e-5))))):
+            hp3.step()
+        hp3.sync()
+        ctx.profile(True, kernels=('nearfield',), every=1)
+        ctx.profile_reset()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            hp3.step()
+        hp3.sync()
+        dt3 = time.perf_counter() - t0
+        nf3 = ctx.profile_get()['nearfield']
+        ctx.profile(False)
+        line['physical_orders'] = {
+            'orders_per_table': [len(o) for o in getattr(ctx, 'table_orders', [])],
+            'nearfield_kernels': ctx.nearfield_kernels(),
+            'ms_per_step': 1e3 * dt3 / args.steps, 'value': pairs * args.steps / dt3,
+            'nearfield_ms': nf3['total_ms'] / max(nf3['launches'], 1),
+            'note': 'the timed workload once more with the order lists characterize() would record per collection '
+                    'and direction (grating.lua:417-423) instead of (0,0), (-1,0), (+1,0) everywhere: %d steps after '
+                    'the timed region, near field by HIP events on every launch' % args.steps}
     if rank == 0 and world == 1:
         if args.cpu_rows > 0 and not args.pair_list:
             line['cpu_baseline'] = cpu_baseline(lens, x, u, wavelength, min(args.cpu_rows, side),
