@@ -204,9 +204,13 @@ int ml_farfield_download(ml_ctx *ctx, double *Nx, double *Ny, double *Lx, double
  * 1 folded even/odd real-kernel GEMM (centre-symmetric uy grid).                          */
 int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel);
 /* The same for both stages: 0 generic complex GEMM, 1 folded GEMM, 2 output-pruned FFT in LDS
- * (the axis' direction grid is a run of consecutive bins of the aperture's FFT lattice,
- * kappa * step * du = 1 / N_eff with N_eff a multiple of 256 up to 8192 - the reference's own
- * far-field grid, nearfield_farfield.py:35-39, and any window of it).                       */
+ * (the axis' direction grid is a run of consecutive bins of an FFT lattice of the aperture axis,
+ * kappa * step * du = 1 / N with N >= the number of samples - the reference's own far-field grid,
+ * nearfield_farfield.py:35-39, any window of it, and finer ones.  N need not be a multiple of 256:
+ * the reference's default grids are 2^a 3^b 5^c long, nearfield.py:30-36 - 400, 1920, 2000 ... -
+ * and run on the 256 / gcd(N, 256) times finer lattice, the aperture zero-padded, of which every
+ * such bin is wanted; lattices of up to 16 x 8192 samples, in interleaved sub-sequences beyond
+ * 8192; the GEMMs take over where the odd part of N has no divisor that brings it to <= 32).    */
 int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel);
 /* How ml_farfield_plan chooses: ML_METHOD_AUTO (default) takes the FFT on every axis whose grid
  * sits on the lattice and the GEMMs elsewhere; ML_METHOD_GEMM always takes the GEMMs (arbitrary
@@ -228,8 +232,9 @@ int ml_farfield_set_method(ml_ctx *ctx, int method);
  * setting belongs to the context and persists across ml_farfield_plan calls.
  * NORMALISATION of the 1e-4: max |dE| <= 1e-4 max |E| over the direction grid (rounding of an
  * N-term fp32 sum is absolute).  It is NOT a pointwise bound: a direction 1000 x dimmer than the peak
- * carries up to ~1e-3 relative at 16384^2 (tests/test_gpu_parity.py POINTWISE_F32 holds the
- * measured figure); dim side lobes that matter belong to ML_PRECISION_F64 (pointwise 2e-12).   */
+ * carries up to ~1e-3 relative at 16384^2 (tests/test_gpu_parity.py POINTWISE holds the measured
+ * figures per size); dim side lobes that matter belong to ML_PRECISION_F64 (pointwise 0.7e-12 at
+ * 4096^2, 1.6e-12 at 2048^2 against the fp64 oracle).                                         */
 #define ML_PRECISION_F64 0
 #define ML_PRECISION_F32_GEMM 1
 int ml_farfield_set_precision(ml_ctx *ctx, int precision);

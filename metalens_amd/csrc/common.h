@@ -116,8 +116,8 @@ struct TableDesc {
 
 // What the field kernel needs to know about a periphery sample's RING: 32 bytes per ring
 // (ring_rec: two 16-byte loads per lane),
-//   r_center, period | 2 pi / period, bits: offset of the ring's table in ring_tab (bits 0-39),
-//   bit 40 = the period lies outside its table's period range (nearfield.py:302-305)
+//   r_center, period | 2 pi / period, bits: offset of the ring's table in ring_tab (general order
+//   sets: bits 0-39, bit 40 = the period lies outside its table's period range, nearfield.py:302-305)
 // SIMPLE order sets (every table of the lens: orders (ox, 0) with |ox| <= 5 - what characterize()
 // emits for a round lens, grating.lua:417-423; nearfield_simple.hip): ring_tab holds CELL BLOCKS
 // instead, complex [ring][i0 < n0 - 1][i1 < n1 - 1][order slot < n_slots][node 2 x 2][amplitude 4] - the

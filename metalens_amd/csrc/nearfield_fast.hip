@@ -385,8 +385,8 @@ static_assert(16 * CENTER_TYPES <= NF_SLOTS * NF_PITCH && CENTER_TYPES % 4 == 0,
 #endif
 // The kernels of GENERAL order sets (|ox| up to 5, oy != 0: grating.lua:406-423): every order
 // evaluates its own phase argument the reference's way (nearfield.py:268-269,291; order_factors_arg).
-// Lenses whose tables hold ox in {-1, 0, 1}, oy = 0 only - every order of a round lens' rings that
-// propagates in air - run nearfield_simple.hip instead.
+// Lenses whose tables hold orders (ox, 0), |ox| <= 5, only - what characterize() records for the rings of
+// a round lens - run nearfield_simple.hip instead.
 template <int NP>
 __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field_kernel(const NfArgs a) {
     __shared__ double2 s_tab[NF_SLOTS * NF_PITCH];

@@ -11,18 +11,30 @@
 //
 // What the restricted order sets buy (the kernel is bound by fp64 vector ISSUE: every vector
 // instruction holds its SIMD for four cycles, so the budget is instructions per sample):
-//   * CANONICAL order slots per collection - by |ox|, the negative one first: 0, -1, +1, -2, +2, ...,
-//     whichever of them the collection's data holds (CollDesc::ox_list, ctx.hip): the order loop runs
-//     over the slots of the wave's own collection with the order in a SCALAR register - a collection
-//     of three orders pays for three, its neighbour of five for five;
+//   * ORDER SLOTS per collection: slot s of a collection is its order ox = lo + s, lo its lowest
+//     (CollDesc::ox_lo / n_slots / present, ctx.hip), and the order loop runs over the slots of the
+//     wave's OWN collection - a collection of three orders pays for three, its neighbour of eleven
+//     for eleven - with nothing of an order list decoded per order: the loop knows a slot count and
+//     a bit mask of the slots the data really holds;
 //   * the phasor of order (ox, 0) at a sample is exp(i ((k u_x' + ox G) x' + k u_y' y'))
 //     (nearfield.py:268-269,291; centre :391-409) = E0 * X^ox with E0 the order-(0,0) phasor - into
 //     which the propagation phasor exp(i k |grating centre - source|) is folded, its exact ~1e4 rad
 //     argument reduced to [-pi/4, pi/4] + quadrants first - and X = exp(i G x'): two sincos per
-//     sample, then one product per order and one more per |ox| level beyond the first (X^2, X^3, ...);
-//   * k_x' of order (ox, 0) = k u_x' + ox (2 pi / period) in one rounding - the reference's own
-//     expression for |ox| <= 2 (ox*2*pi/grating_period is exactly ox (2 pi / period) there), within an
-//     ulp of it beyond;
+//     sample; the slots are WALKED upwards from the lowest order with the phasor and k_x' carried
+//     along (OrderWalk: ph <- ph X, k_x' <- k_x' + G: one complex product and one addition per
+//     order, whatever |ox|), started at E0 conj(X)^|lo| and k u_x' + lo G;
+//   * k_x' of the lowest order = k u_x' + lo (2 pi / period) in one rounding - the reference's own
+//     expression for |lo| <= 2 (ox*2*pi/grating_period is exactly ox (2 pi / period) there) - and
+//     within an ulp per step of it beyond (amplitude-type: it enters the E-from-H factors and the
+//     propagates-in-air test, not a large phase);
+//   * TWO INSTANTIATIONS of the ring kernel, the collections of a lens dealt to them by order count
+//     (NfArgs::wide_mask) and each launched over the patches that hold samples of its collections:
+//     NARROW (up to SIMPLE_NARROW_SLOTS = 4 orders: the three-order tables SURVEY.md 8(d) prescribes,
+//     the outer collections of a real lens) stages whole blocks, six at a fixed pitch, and unrolls
+//     the order loop over its four possible slots - constant LDS addresses, nothing paid for the
+//     generality of the other; WIDE (up to eleven orders) takes a round's blocks through the buffer
+//     in PASSES of as many order slots as fit - all blocks, some orders - so that every order is
+//     evaluated once per round however many blocks a wave spans;
 //   * CELL BLOCKS (common.h): the 16 n_slots complex a sample in table cell (i0, i1) of its ring
 //     interpolates from are contiguous, so a (ring, cell) block is named by ONE 32-bit number -
 //     the key the lanes of a patch are matched by, and, read back from the lead lane, the scalar
@@ -138,7 +150,7 @@ struct AccS {
     double Exr, Exi, Eyr, Eyi, Hxr, Hxi, Hyr, Hyi;
 };
 
-// what the three orders of a sample share: k u_x', 2 pi / period, k u_y', (k u_y')^2, the order-(0,0)
+// what the orders of a sample share: k u_x', 2 pi / period, k u_y', (k u_y')^2, the order-(0,0)
 // phasor (x the propagation phasor) and exp(i G x')
 struct OrderShared {
     double kx0, G, ky, ky2;

@@ -5,6 +5,9 @@
 // arithmetic, where the folded GEMM (zfold.hip) spends M / 2 real multiply-adds per sample on the
 // matrix cores (4096 -> 512: 0.59 ms at 100 % matrix-pipe rate against ~0.25 ms of HBM time).
 // Direction grids off the lattice (zoomed, shifted by a fraction of a bin, pair lists) keep the GEMMs.
+// A lattice whose length is NOT a multiple of 256 - the reference's default grids, the smallest 2^a 3^b 5^c
+// above a goal: 400, 1920, 2000 ... (nearfield.py:30-36) - runs on the 256 / gcd(N, 256) times finer
+// lattice that is one, the aperture zero-padded and every such bin wanted (zfft_commensurate, Geo::jstep).
 //
 // One workgroup = 16 R3 threads = one row of N_eff = 256 R3 samples at a time:
 //   16 coalesced 16-byte loads per thread -> stage 1 -> LDS -> stage 2 -> LDS -> stage 3 (Horner

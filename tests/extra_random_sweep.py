@@ -3,7 +3,10 @@
 polarisations on the 2 mm NA 0.94 lens and on a 1 mm NA 0.5 lens against the CPU oracle,
 counting discrete-decision flips (ring / sector / nearest cell).
 
-    python tests/extra_random_sweep.py [N_CASES] [SEED]
+    python tests/extra_random_sweep.py [N_CASES] [SEED] [survey|physical]
+
+``physical``: the tables hold the order lists characterize() would record per collection and direction
+(synthetic.propagating_orders: up to eleven orders per ring collection) instead of (0,0), (-1,0), (+1,0).
 """
 import math
 import os
@@ -22,18 +25,19 @@ from oracle import nearfield_oracle            # noqa: E402
 from test_gpu_parity import field_errors       # noqa: E402
 
 
-def lens_of(radius, na, wl):
+def lens_of(radius, na, wl, orders='survey'):
+    extra = {} if orders == 'survey' else {'periphery_orders': 'physical', 'center_orders': 'physical'}
     return synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design,
                                radius=radius, numerical_aperture=na, wavelength=wl,
                                switch_angle=12 * math.pi / 180, num_gratings=20, num_entries=12,
-                               design_kwargs={'wavelength': wl})
+                               design_kwargs={'wavelength': wl}, **extra)
 
 
-def run(n_cases, seed):
+def run(n_cases, seed, orders='survey'):
     """returns (worst relative field error, decision flips, exact-tie samples met)"""
     rng = np.random.default_rng(seed)
     wl = 580e-9
-    lenses = [lens_of(1e-3, 0.94, wl), lens_of(0.5e-3, 0.5, wl)]
+    lenses = [lens_of(1e-3, 0.94, wl, orders), lens_of(0.5e-3, 0.5, wl, orders)]
     worst, flips_total, ties_total = 0.0, 0, 0
     for case in range(n_cases):
         lens = lenses[case % 2]
@@ -82,10 +86,11 @@ def run(n_cases, seed):
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
+    orders = sys.argv[3] if len(sys.argv) > 3 else 'survey'
     t0 = time.time()
-    worst, flips_total, ties_total = run(n_cases, seed)
-    print('%d cases, worst relative field error %.2e, decision flips %d, exact-tie samples met %d, '
-          '%.1f s' % (n_cases, worst, flips_total, ties_total, time.time() - t0))
+    worst, flips_total, ties_total = run(n_cases, seed, orders)
+    print('%s orders: %d cases, worst relative field error %.2e, decision flips %d, exact-tie samples met %d, '
+          '%.1f s' % (orders, n_cases, worst, flips_total, ties_total, time.time() - t0))
 
 
 if __name__ == '__main__':

@@ -1511,13 +1511,14 @@ def test_layout_limits_are_refused(ma):
     packing.upload_layout(ctx, S, cells)   # and the context still takes a good one
 
 
-@pytest.mark.parametrize('seed', [5, 6])
-def test_random_windows_sweep(ma, seed):
+@pytest.mark.parametrize('seed,orders', [(5, 'survey'), (6, 'survey'), (7, 'physical')])
+def test_random_windows_sweep(ma, seed, orders):
     """random windows, sources and polarisations on two lenses against the oracle
     (tests/extra_random_sweep.py; run that script for hundreds of cases): every discrete decision
-    (ring, sector, nearest cell) must agree, fields to 1e-12"""
+    (ring, sector, nearest cell) must agree, fields to 1e-12 - with the three-order tables and with
+    the order lists characterize() would record"""
     import extra_random_sweep
-    worst, flips, _ties = extra_random_sweep.run(16, seed)
+    worst, flips, _ties = extra_random_sweep.run(16, seed, orders)
     assert flips == 0
     assert worst < TOL
 

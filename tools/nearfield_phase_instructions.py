@@ -63,7 +63,10 @@ def main():
     i = s.index('\n' + KERNEL + ':')
     body = s[i:s.index('.Lfunc_end', i)].splitlines()
     ins = [l.split()[0] for l in body if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
-    end = ins.index('s_endpgm')
+    # (the kernel may leave early - a listed launch over all patch numbers, past the list's end - through an
+    # s_endpgm of its own near the top: the end of the main path is the first one behind the last stamp)
+    last_stamp = max(k for k, op in enumerate(ins) if op == 's_memtime')
+    end = ins.index('s_endpgm', last_stamp)
     cold = len(ins) - end - 1              # blocks the compiler moved behind s_endpgm
     ins = ins[:end + 1]
     classes = ['VALU', 'SALU', 'SMEM', 'BRANCH', 'LDS', 'VMEM', 'WAIT']

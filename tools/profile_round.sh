@@ -25,18 +25,32 @@ pmc c4096
 pmc c2048 --aperture 2048 --farfield 256
 pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
 pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
+# ... and with the order lists characterize() would record (7 to 11 orders per ring collection)
+pmc c4096phys --orders physical
+pmc c8192phys --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --orders physical
 # the instruction mix of the synthesis kernels at the north-star size (per-wave figures of DESIGN 4.1)
 SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0"
 $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4096/insts -- $SHORT > $O/c4096.insts.log 2>&1
 $T rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/c4096/active -- $SHORT > $O/c4096.active.log 2>&1
+$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4096phys/insts -- $SHORT --orders physical > $O/c4096phys.insts.log 2>&1
+$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c8192/insts -- $SHORT --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 > $O/c8192.insts.log 2>&1
+$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c2048/insts -- $SHORT --aperture 2048 --farfield 256 > $O/c2048.insts.log 2>&1
 cd $R
 B="python bench.py --cpu-rows 0 --cpu-fft-side 0"
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench.json
 timeout 300 $B --profile all 2>/dev/null | tail -1 > $O/bench_profile_all.json
 timeout 300 $B --profile none 2>/dev/null | tail -1 > $O/bench_profile_none.json
 timeout 300 $B --method gemm --profile all 2>/dev/null | tail -1 > $O/bench_gemm_profile_all.json
-timeout 300 $B --aperture 2048 --farfield 256 --profile all 2>/dev/null | tail -1 > $O/bench_2048x256.json
+# (2048^2: the default kernel timing - two kernels every fourth step; events around EVERY launch, --profile all, cost
+# a 0.17 ms step 15 % in its first block, which is all the "first block off its median" of round 4 was)
+timeout 300 $B --aperture 2048 --farfield 256 2>/dev/null | tail -1 > $O/bench_2048x256.json
+timeout 300 $B --aperture 2048 --farfield 256 --profile all 2>/dev/null | tail -1 > $O/bench_2048x256_profile_all.json
 timeout 300 $B --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --profile all 2>/dev/null | tail -1 > $O/bench_8192x512_na094.json
+timeout 300 $B --orders physical --profile all 2>/dev/null | tail -1 > $O/bench_physical.json
+timeout 300 $B --aperture 2048 --farfield 256 --orders physical 2>/dev/null | tail -1 > $O/bench_2048x256_physical.json
+timeout 300 $B --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --orders physical --profile all 2>/dev/null | tail -1 > $O/bench_8192x512_na094_physical.json
+timeout 300 $B --gpus 1 --scaling strong 2>/dev/null | tail -1 > $O/bench_gpus1_strong_8192.json
+timeout 300 $B --positions 3 --profile all 2>/dev/null | tail -1 > $O/bench_positions3.json
 timeout 300 $B --pols xyz --profile all 2>/dev/null | tail -1 > $O/bench_pols_xyz.json
 timeout 300 $B --precision f32 --profile all 2>/dev/null | tail -1 > $O/bench_f32.json
 timeout 300 $B --zoom 0.5 --profile all 2>/dev/null | tail -1 > $O/bench_zoom05.json
@@ -50,4 +64,7 @@ timeout 300 python tools/dropin_time.py > $O/dropin.log 2>&1
 # (diagnostic build with the phase stamps: make -C metalens_amd/csrc EXTRA=-DML_PHASE_TIMERS BUILD=build_pt TARGET=../../abl_tmp/lib_pt.so,
 # made in the build container - it travels with the snapshot)
 [ -f abl_tmp/lib_pt.so ] && METALENS_HIP_LIB=abl_tmp/lib_pt.so timeout 300 python tools/nearfield_phase_timers.py 4096 > $O/phase_timers_4096.txt 2>&1
+# measured parity figures of the full-size cases (tests/test_gpu_parity.py _record) and the random sweep
+ML_RECORD_PARITY=$O/parity_measured.jsonl timeout 900 python -m pytest tests/test_gpu_parity.py -q -k "north_star_size_properties" > $O/parity_pytest.log 2>&1
+for seed in 5 6 7; do timeout 600 python tests/extra_random_sweep.py 120 $seed survey; timeout 600 python tests/extra_random_sweep.py 120 $seed physical; done > $O/random_sweep.txt 2>&1
 ls $O
