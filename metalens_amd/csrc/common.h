@@ -286,7 +286,7 @@ struct ml_ctx {
     ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
     bool simple_orders = false;   // every table in use: orders (ox, 0), |ox| <= 5 only (refresh_ring_locations)
-    int wide_mask = 0, narrow_exists = 0;   // simple order sets: NfArgs::wide_mask / narrow_exists
+    int wide_mask = 0, narrow_exists = 0, narrow_slots_max = 1;   // simple order sets: NfArgs::wide_mask / narrow_exists; orders of the widest narrow collection
     double ring_bounds_all[4] = {0, 0, 0, 0};   // intersection of the ring tables' (ux', uy') bounds (NfArgs)
 
     // layout

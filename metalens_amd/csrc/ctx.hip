@@ -201,11 +201,14 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     // which ring collections go to the wide instantiation of the ring kernel (nearfield_simple.hip): part of
     // what the patch lists were built for (nearfield.hip geo_key)
     ctx->wide_mask = ctx->narrow_exists = 0;
+    ctx->narrow_slots_max = 1;
     for (int c = 0; simple && c < ctx->n_colls; ++c) {
-        if (canon[c].n > SIMPLE_NARROW_SLOTS)
+        if (canon[c].n > SIMPLE_NARROW_SLOTS) {
             ctx->wide_mask |= 1 << c;
-        else
+        } else {
             ctx->narrow_exists = 1;
+            ctx->narrow_slots_max = std::max(ctx->narrow_slots_max, canon[c].n);
+        }
     }
     int dense_of[MAX_SLOTS];
     for (int c = 0; c < ctx->n_colls; ++c) dense_of[ctx->coll_slot[c]] = c;

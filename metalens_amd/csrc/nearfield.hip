@@ -171,6 +171,9 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.simple_orders = ctx->simple_orders ? 1 : 0;
     a.wide_mask = ctx->wide_mask;
     a.narrow_exists = ctx->narrow_exists;
+    a.narrow_pitch = UNIT * ctx->narrow_slots_max + 1;
+    // (eight blocks of up to three orders or six of four: nearfield_simple.hip RING_LDS_NARROW)
+    a.narrow_cap = std::min(8, (8 * (3 * UNIT + 1)) / a.narrow_pitch);
     a.center_n_slots = ctx->center_n_slots;
     a.center_lo = ctx->center_lo;
     a.center_present = ctx->center_present_mask;

@@ -106,6 +106,7 @@ struct NfArgs {
     // simple order sets: bit c = dense collection c holds more than SIMPLE_NARROW_SLOTS orders (its samples are
     // the wide ring instantiation's); narrow_exists: some collection does not
     int wide_mask, narrow_exists;
+    int narrow_pitch, narrow_cap;   // narrow ring instantiation: complex between staged blocks (16 x its widest collection's orders + 1), blocks per round
     int center_n_slots, center_lo, center_present;   // centre table, simple order sets: as CollDesc::n_slots / ox_lo / present
     // the (ux', uy') range every ring table covers (intersection of their bounds: lo0, hi0, lo1, hi1);
     // a sample inside it cannot trip a table bound, and only the others read their ring's own bounds

@@ -60,7 +60,13 @@ constexpr int SK_SLOTS = 6;                     // distinct (ring, cell) blocks 
 #ifndef ML_RING_LDS_WIDE
 #define ML_RING_LDS_WIDE 448
 #endif
-constexpr int RING_LDS_NARROW = SK_SLOTS * (SIMPLE_NARROW_SLOTS * UNIT + 1), RING_LDS = ML_RING_LDS_WIDE;
+// (narrow: six blocks of four orders, or EIGHT of three - the pitch is the lens' widest narrow collection's,
+// NfArgs::narrow_pitch / narrow_cap: at NA 0.94 a patch spans five to six of the outer rings and more than one
+// table cell, and every block beyond the round's capacity costs the wave a second round - the whole order loop
+// again for a few lanes)
+constexpr int SK_SLOTS_NARROW = 8;
+constexpr int RING_LDS_NARROW = SK_SLOTS_NARROW * (3 * UNIT + 1), RING_LDS = ML_RING_LDS_WIDE;
+static_assert(SK_SLOTS * (SIMPLE_NARROW_SLOTS * UNIT + 1) <= RING_LDS_NARROW, "six blocks of four orders fit");
 // order slots per pass of the wide instantiation: what n blocks leave each other of the buffer,
 // (RING_LDS / n - 1) / 16 for n = 1 ... 6 blocks, four bits each
 constexpr unsigned slots_per_pass(int n) { return (unsigned)((RING_LDS / n - 1) / UNIT < 15 ? (RING_LDS / n - 1) / UNIT : 15); }
@@ -727,17 +733,18 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     unsigned long long todo = __ballot(peri && cell_type == c_cur);      // lanes of the current collection not served yet
     unsigned coll_done = 1u << (c_cur & 31);   // collections whose lanes have been (or are being) served: bit per dense number
     int myslot, n_blocks, upp, pitch;
-    int lead[SK_SLOTS];
-    constexpr int SMALL_SLOTS = SIMPLE_NARROW_SLOTS, SMALL_PITCH = SMALL_SLOTS * UNIT + 1;
-    static_assert(SK_SLOTS * SMALL_PITCH <= RING_LDS_NARROW, "six small blocks fit");
+    constexpr int NSLOT = WIDE ? SK_SLOTS : SK_SLOTS_NARROW;
+    int lead[NSLOT];
+    constexpr int SMALL_SLOTS = SIMPLE_NARROW_SLOTS;
+    const int small_pitch = a.narrow_pitch, small_cap = a.narrow_cap;   // (narrow instantiation: see RING_LDS_NARROW)
     auto match = [&]() {
         myslot = -1;
         n_blocks = 0;
         unsigned long long rest = todo;
 #pragma unroll
-        for (int s = 0; s < SK_SLOTS; ++s) {
+        for (int s = 0; s < NSLOT; ++s) {
             lead[s] = -1;
-            if (rest) {   // wave-uniform
+            if (rest && (WIDE || s < small_cap)) {   // wave-uniform
                 const int kl = __builtin_amdgcn_readlane(blk, __ffsll((long long)rest) - 1);
                 // every lane with this block is served now (so no served lane can match a later
                 // lead, whose block differs); lanes without a block hold -1
@@ -757,7 +764,7 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         for (int m = 0; m * 64 < UNIT * SIMPLE_MAX_SLOTS; ++m)
             if (m * 64 < len && lane < len - m * 64) {   // (the first test is wave-uniform)
 #pragma unroll
-                for (int s = 0; s < SK_SLOTS; ++s)
+                for (int s = 0; s < NSLOT; ++s)
                     if (lead[s] >= 0)
                         stage_block<1>(K.ring_tab + (size_t)(unsigned)(lead[s] + s0) * UNIT + m * 64,
                                        s_tab + s * pitch + m * 64, lane_off);
@@ -769,9 +776,9 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         if constexpr (decltype(small)::value) {
             if (lane < ns * UNIT) {
 #pragma unroll
-                for (int s = 0; s < SK_SLOTS; ++s)
+                for (int s = 0; s < NSLOT; ++s)
                     if (lead[s] >= 0)
-                        stage_block<1>(K.ring_tab + (size_t)(unsigned)lead[s] * UNIT, s_tab + s * SMALL_PITCH, lane_off);
+                        stage_block<1>(K.ring_tab + (size_t)(unsigned)lead[s] * UNIT, s_tab + s * small_pitch, lane_off);
             }
         } else {
             // order slots per pass (UPP_TABLE), capped by the slot count
@@ -835,7 +842,9 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
         walk_start(W, R, lo);
         const bool mine = myslot >= 0;
         if constexpr (decltype(small)::value) {
-            const double2 *b = s_tab + max(myslot, 0) * SMALL_PITCH;
+            int boff;   // the lane's block in the buffer (complex)
+            asm("v_mul_u32_u24 %0, %1, %2" : "=v"(boff) : "v"(max(myslot, 0)), "s"(small_pitch));
+            const double2 *b = s_tab + boff;
             staged_wait<0>();
 #pragma unroll
             for (int sl = 0; sl < SMALL_SLOTS; ++sl) {

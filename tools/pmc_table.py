@@ -51,13 +51,17 @@ def per_class(d):
                 acc[(cls, name.split('(')[0], r['Grid_Size'])][r['Counter_Name']].append(float(r['Counter_Value']))
     out = {}
     for cls, _ in CLASSES:
-        # one steady-state shape per kernel (name before the template arguments) of the class, summed
+        # one steady-state shape per kernel INSTANTIATION of the class (the two ring-kernel instantiations of a
+        # lens with narrow and wide collections both run every step), summed; instantiations that ran only a
+        # few times (the full-grid first pass on a geometry) are not steady state
         by_kernel = collections.defaultdict(list)
         for k, c in acc.items():
             if k[0] == cls:
-                by_kernel[k[1].split('<')[0]].append((max(len(v) for v in c.values()), k))
+                by_kernel[k[1]].append((max(len(v) for v in c.values()), k))
         if not by_kernel:
             continue
+        most = max(max(cands)[0] for cands in by_kernel.values())
+        by_kernel = {n: cands for n, cands in by_kernel.items() if 2 * max(cands)[0] >= most}
         total, names, grid = collections.defaultdict(float), [], 0
         for cands in by_kernel.values():
             _, best = max(cands)
