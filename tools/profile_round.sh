@@ -20,6 +20,8 @@ pmc() {   # pmc NAME <bench args>: the counter passes of one configuration
   $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$name/fetch -- $SHORT > $O/$name.fetch.log 2>&1
   $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/$name/write -- $SHORT > $O/$name.write.log 2>&1
   $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$name/sq -- $SHORT > $O/$name.sq.log 2>&1
+  # the instruction mix of the synthesis kernels (per-wave figures of DESIGN 4.1)
+  $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/$name/insts -- $SHORT > $O/$name.insts.log 2>&1
 }
 pmc c4096
 pmc c2048 --aperture 2048 --farfield 256
@@ -28,13 +30,8 @@ pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
 # ... and with the order lists characterize() would record (7 to 11 orders per ring collection)
 pmc c4096phys --orders physical
 pmc c8192phys --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --orders physical
-# the instruction mix of the synthesis kernels at the north-star size (per-wave figures of DESIGN 4.1)
 SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 --also-physical 0"
-$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4096/insts -- $SHORT > $O/c4096.insts.log 2>&1
 $T rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/c4096/active -- $SHORT > $O/c4096.active.log 2>&1
-$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c4096phys/insts -- $SHORT --orders physical > $O/c4096phys.insts.log 2>&1
-$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c8192/insts -- $SHORT --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 > $O/c8192.insts.log 2>&1
-$T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/c2048/insts -- $SHORT --aperture 2048 --farfield 256 > $O/c2048.insts.log 2>&1
 cd $R
 B="python bench.py --cpu-rows 0 --cpu-fft-side 0"
 timeout 600 python bench.py 2>/dev/null | tail -1 > $O/bench.json
