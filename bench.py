@@ -276,7 +276,7 @@ def main():
     ap.add_argument('--blocks', type=int, default=5,
                     help='K-step blocks run back to back; the FIRST is the timed region `value` '
                          'comes from, the median block is reported beside it')
-    ap.add_argument('--cpu-rows', type=int, default=1024,
+    ap.add_argument('--cpu-rows', type=int, default=2048,
                     help='aperture rows of the CPU-baseline sample (0 = skip)')
     ap.add_argument('--cpu-fft-side', type=int, default=1024,
                     help="side of the window the reference's FFT route is timed on (0 = skip)")

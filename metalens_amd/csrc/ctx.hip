@@ -191,6 +191,10 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     bool simple = true;
     for (int c = 0; c < ctx->n_colls; ++c) simple = canon_orders(ctx->slots[ctx->coll_slot[c]], canon[c]) && simple;
     if (ctx->center.present) simple = canon_orders(ctx->center, canon_center) && simple;
+    // (diagnostic build only: ML_FORCE_GENERAL=1 sends a lens that qualifies through the general kernels - what
+    // the order-list kernels are measured against)
+    static const bool force_general = diag_int("ML_FORCE_GENERAL", 0) != 0;
+    if (force_general) simple = false;
     if (simple != ctx->simple_orders) {
         // which patch lists exist and what a synthesis leaves behind depend on the kernel family
         ctx->geo_key[0] = -1;

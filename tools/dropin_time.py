@@ -44,3 +44,25 @@ for name, a in (('plain objects ', args), ('PreparedLens  ', pargs)):
     print('build_nearfield(download=False) 2048^2, %s: median %.2f ms, min %.2f ms (20 calls)'
           % (name, float(np.median(best)), min(best)))
 assert o[6] == out2[6]
+# ---- the reference's DEFAULT grid (x_pts = y_pts = None: good_fft_number(2 r_max / (lambda / 2.2)) samples,
+# nearfield.py:95-97): a 0.5 mm NA 0.5 lens gets 1920 = 128 x 15 samples - not a multiple of 256.  The resident
+# flow takes the pruned FFT there too (on the twice finer lattice of 3840, every second bin); the folded GEMMs,
+# which that grid fell back to until round 5, beside it
+from metalens_amd import _lib, layout, synthetic
+lens2 = synthetic.make_lens((ma.Grating, ma.GratingCollection, ma.HexGridSet), layout.make_design, radius=250e-6,
+                            numerical_aperture=0.5, wavelength=580e-9, switch_angle=12 * math.pi / 180)
+args2 = (0.0, 0.0, -lens2['source_distance'], 'x', 580e-9, lens2['lens_periphery_summary'],
+         lens2['lens_center_summary'], lens2['hexgridset'])
+ctx = _lib.default_context()
+for method in ('auto', 'gemm', 'auto'):
+    ctx.set_method(method)
+    for k in range(3):
+        t = time.perf_counter()
+        o3 = ma.build_nearfield(*args2, download=False)
+        t1 = time.perf_counter()
+        P3 = ma.farfield_from_resident_nearfield(o3[4], o3[5], 580e-9, o3[7])
+        t2 = time.perf_counter()
+    print('default grid of a 0.5 mm lens (%d^2), method %-4s -> %s: build_nearfield(download=False) %.2f ms + '
+          'farfield_from_resident_nearfield (all lattice directions, P to the host) %.2f ms'
+          % (len(o3[4]), method, ctx.plan_kernels(), (t1 - t) * 1e3, (t2 - t1) * 1e3))
+ctx.set_method('auto')
