@@ -270,6 +270,12 @@ int ml_comm_init(ml_ctx *ctx, const uint8_t id[128], int n_ranks, int rank) {
         ncclConfig_t config = NCCL_CONFIG_INITIALIZER;
         config.maxCTAs = ctx->comm_max_channels;
         rc = g_rccl.CommInitRankConfig(&comm, n_ranks, u, rank, &config);
+        // (a library that does not take this header's config struct refuses it before any rank talks to
+        // another - identically on every rank - so the plain call with the same id is still possible)
+        if (rc == ncclInvalidArgument) {
+            comm = nullptr;
+            rc = g_rccl.CommInitRank(&comm, n_ranks, u, rank);
+        }
     } else {
         rc = g_rccl.CommInitRank(&comm, n_ranks, u, rank);
     }

@@ -307,7 +307,7 @@ struct ml_ctx {
     ml::DevBuf ring_lut;             // uniform-in-r bucket -> first candidate boundary
     ml::DevBuf ring_lutrec;          // fast kernel: coarser buckets that carry the boundaries
     int lutrec_buckets = 0;
-    double lutrec_inv_h = 0, r_outer = 0;
+    double lutrec_inv_h = 0, r_outer = 0, r_centre = 0;   // (r_centre: inner boundary of ring 0 = radius of the centre disc)
     int lut_buckets = 0;
     double lut_inv_h = 0;
     ml::DevBuf cell_x, cell_y, cell_xy, cell_which, cell_index, bin_start;

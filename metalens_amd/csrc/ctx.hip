@@ -778,6 +778,7 @@ int ml_upload_layout(ml_ctx *ctx, int n_rings, const double *B, const double *r_
         ctx->lutrec_buckets = nb;
         ctx->lutrec_inv_h = 1.0 / hb;
         ctx->r_outer = r_max;
+        ctx->r_centre = B[0];
     }
 
     // centre cells -> uniform grid of bins (about one cell per bin), cells stored in bin

@@ -166,6 +166,19 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.use_active = 0;
     a.list_count = nullptr;
     a.first_pass = 0;
+    {
+        // patches with a sample inside the square around the centre disc (the axes' host copies are the grid's)
+        auto span = [&](const std::vector<double> &axis, int n) {
+            int lo = n, hi = -1;
+            for (int i = 0; i < n && i < (int)axis.size(); ++i)
+                if (std::fabs(axis[i]) <= ctx->r_centre) {
+                    lo = std::min(lo, i);
+                    hi = std::max(hi, i);
+                }
+            return hi < lo ? 0 : hi / 8 - lo / 8 + 1;
+        };
+        a.centre_patch_bound = span(ctx->h_x_pts, nx) * span(ctx->h_y_pts, ny);
+    }
     for (int k = 0; k < 4; ++k) a.n_active[k] = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;

@@ -100,6 +100,9 @@ struct NfArgs {
     // the listed centre kernel that the power is not its business this time
     const int *list_count;
     int first_pass;
+    // upper bound on the centre list's length the host can give before it has seen the lists: the patches
+    // that hold a sample with |x| and |y| within the centre disc's radius (first pass only)
+    int centre_patch_bound;
     // every table of the lens holds orders (ox, 0), |ox| <= 5, only: the kernels that build an
     // order's phasor by products run (nearfield_simple.hip), else the general ones
     int simple_orders;
