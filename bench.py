@@ -728,7 +728,8 @@ def main():
         line['ms_first_step_new_geometry'] = 1e3 * (t1 - t0)
         line['cold_step'] = {
             'first_ms': 1e3 * (t1 - t0), 'second_ms': 1e3 * (t2 - t1), 'third_ms': 1e3 * (t3 - t2),
-            'note': 'host-timed single steps (queue + sync) on a sample grid the context has not seen: '
+            'note': 'host-timed single steps (queue + sync) on a sample grid the context has not seen, right after ~50 ms '
+                    'of steps on the old grid (a GPU that has idled for seconds reads 0.12 ms more): '
                     'first = axes upload, plan tables, row extents, geometry kernel + scans, a synthesis '
                     'whose ring kernel visits ALL patches and stores the zeros outside the lens (the centre '
                     'kernel works from its list already), transform, projection; '

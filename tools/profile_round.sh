@@ -58,6 +58,9 @@ for n in 2 4 8; do
   ML_COMM_BACKEND=file timeout 600 python bench.py --gpus $n --cpu-rows 0 --cpu-fft-side 0 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --scaling strong 2>$O/bench_gpus$n.err | tail -1 > $O/bench_gpus${n}_8192_file_comm.json
 done
 timeout 300 python tools/dropin_time.py > $O/dropin.log 2>&1
+timeout 200 python tools/cold_timeline.py > $O/cold_timeline.txt 2>&1
+# every rank's shard of configs[2] run ALONE on this GPU (what the decomposition allows before communication)
+for n in 2 4 8; do timeout 300 python tools/shard_probe.py $n --sharding auto --out $O/shard$n.json > $O/shard$n.txt 2>&1; done
 # (diagnostic build with the phase stamps: make -C metalens_amd/csrc EXTRA=-DML_PHASE_TIMERS BUILD=build_pt TARGET=../../abl_tmp/lib_pt.so,
 # made in the build container - it travels with the snapshot)
 [ -f abl_tmp/lib_pt.so ] && METALENS_HIP_LIB=abl_tmp/lib_pt.so timeout 300 python tools/nearfield_phase_timers.py 4096 > $O/phase_timers_4096.txt 2>&1
