@@ -40,12 +40,13 @@ def fft_direction_cosines(n, step, wavelength, n_glass):
 
 
 def farfield_from_nearfield(fftEx, fftEy, fftHx, fftHy, xp_list, yp_list, wavelength, n_glass,
-                            *, Z0=None, ctx=None):
+                            *, units=None, Z0=None, ctx=None):
     """``fftEx`` is ``fft2(fftshift(Ex))`` and likewise for the others; ``xp_list``,
     ``yp_list`` are the aperture coordinates.  Returns
     ``(P_here_times_r2_over_uz, total_P, ux, uy, dux, duy)`` with the arrays
-    fft-shifted, as the reference does."""
-    Z0 = constants.Z0 if Z0 is None else Z0
+    fft-shifted, as the reference does.  ``units``: the caller's unit system (the reference takes
+    ``nu.Z0``, nearfield_farfield.py:183; ``constants.as_units``), default SI; ``Z0`` overrides it."""
+    Z0 = constants.as_units(units).Z0 if Z0 is None else Z0
     dxp = xp_list[1] - xp_list[0]
     dyp = yp_list[1] - yp_list[0]
     num_x, num_y = len(xp_list), len(yp_list)
@@ -72,7 +73,7 @@ def farfield_from_nearfield(fftEx, fftEy, fftHx, fftHy, xp_list, yp_list, wavele
     return P, total_P, ux, uy, dux, duy
 
 
-def farfield_from_resident_nearfield(xp_list, yp_list, wavelength, n_glass, *, Z0=None, ctx=None):
+def farfield_from_resident_nearfield(xp_list, yp_list, wavelength, n_glass, *, units=None, Z0=None, ctx=None):
     """The reference's whole far-field flow (README.md:27) from the near field that
     ``build_nearfield(..., download=False)`` left on the GPU, without the host round trip:
 
@@ -93,8 +94,9 @@ def farfield_from_resident_nearfield(xp_list, yp_list, wavelength, n_glass, *, Z
     direction transform over all lattice bins (the pruned FFT of csrc/zfft.hip with nothing pruned
     when the axis length is a multiple of 256 up to 8192, the folded GEMMs otherwise), the
     projection is the same kernel the drop-in ``farfield_from_nearfield`` uses, the finite sum is
-    taken on the GPU (fixed-order tree); only ``P`` crosses PCIe."""
-    Z0 = constants.Z0 if Z0 is None else Z0
+    taken on the GPU (fixed-order tree); only ``P`` crosses PCIe.  ``units`` / ``Z0`` as for
+    ``farfield_from_nearfield``."""
+    Z0 = constants.as_units(units).Z0 if Z0 is None else Z0
     ctx = ctx or _lib.default_context()
     dxp = xp_list[1] - xp_list[0]
     dyp = yp_list[1] - yp_list[0]
@@ -175,11 +177,11 @@ class FarfieldTransform:
         _lib.check(self.ctx.lib.ml_farfield_download(self.ctx.handle, *[_lib.dptr(a) for a in out]))
         return dict(zip(('Nx', 'Ny', 'Lx', 'Ly'), out))
 
-    def project(self, Z0=None):
+    def project(self, Z0=None, units=None):
         """-> P (= power x r^2 / uz per unit dux duy, NaN outside the unit circle) and the
         two complex far-field amplitudes ``L_phi + Z N_theta`` (prop. to E_theta) and
         ``L_theta - Z N_phi`` (prop. to -E_phi) of nearfield_farfield.py:184-185."""
-        Z0 = constants.Z0 if Z0 is None else Z0
+        Z0 = constants.as_units(units).Z0 if Z0 is None else Z0
         P = np.empty(self.shape, dtype=np.float64)
         a_theta = np.empty(self.shape, dtype=np.complex128)
         a_phi = np.empty(self.shape, dtype=np.complex128)
@@ -189,7 +191,7 @@ class FarfieldTransform:
 
 
 def farfield_direct(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, uy,
-                    *, pair_list=False, Z0=None, ctx=None, precision=None):
+                    *, pair_list=False, units=None, Z0=None, ctx=None, precision=None):
     """One-shot convenience: far field of host arrays ``Ex..Hy`` (or of the field set
     already resident on the GPU if ``Ex is None``) at the given directions.  Returns a
     dict with ``Nx, Ny, Lx, Ly, P, a_theta, a_phi``.  ``precision``: 'f64' (default, 1e-12)
@@ -209,5 +211,5 @@ def farfield_direct(Ex, Ey, Hx, Hy, xp_list, yp_list, wavelength, n_glass, ux, u
                           pair_list=pair_list, ctx=ctx, precision=precision)
     t.transform()
     out = t.radiation_vectors()
-    out['P'], out['a_theta'], out['a_phi'] = t.project(Z0)
+    out['P'], out['a_theta'], out['a_phi'] = t.project(Z0, units)
     return out

@@ -82,7 +82,7 @@ def test_nearfield_and_farfield_are_covariant_on_the_gpu():
                     lens_center_summary=lens['lens_center_summary'], hexgridset=lens['hexgridset'])
         nf = ma.build_nearfield(**args, units=units)
         ffts = [np.fft.fft2(np.fft.fftshift(F)) for F in nf[:4]]
-        ff = ma.farfield_from_nearfield(*ffts, nf[4], nf[5], lens['wavelength'], nf[7], Z0=un.Z0)
+        ff = ma.farfield_from_nearfield(*ffts, nf[4], nf[5], lens['wavelength'], nf[7], units=units)
         out[name] = (nf, ff)
     (nfa, ffa), (nfb, ffb) = out['si'], out['u']
     H_unit, E_unit, W = U.C / (U.s * U.m), U.V / U.m, U.kg * U.m ** 2 / U.s ** 3
