@@ -343,6 +343,11 @@ struct ml_ctx {
     ml::DevBuf geo_ix, active_list, active_count, active_flag;
     long geo_key[5] = {-1, -1, -1, -1, -1};
     int n_active[4] = {-1, 0, 0, 0};   // entries of the four patch lists (NfArgs::active_list); [0] = -1: not read back yet
+    // the lists' lengths on their way back (page-locked; queued right behind the scans that make them, so that the
+    // second synthesis on a geometry finds them there instead of draining the stream for four integers)
+    int *counts_pinned = nullptr;
+    hipEvent_t counts_ready = nullptr;
+    bool counts_queued = false;
     long ovr_for[2] = {-1, -1};             // (grid_serial, layout_serial) the overrides belong to
     std::vector<int32_t> h_slot_of_cell;   // original cell index -> bin-sorted slot
     int gemm_f32 = 0;   // ml_farfield_set_precision: folded GEMMs on the fp32 matrix cores

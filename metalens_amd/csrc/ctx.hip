@@ -572,6 +572,8 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     comm_release(ctx);
+    if (ctx->counts_pinned) (void)hipHostFree(ctx->counts_pinned);
+    if (ctx->counts_ready) (void)hipEventDestroy(ctx->counts_ready);
     if (ctx->comm_stream) {
         for (int k = 0; k < 2; ++k) {
             (void)hipEventDestroy(ctx->amp_ready[k]);

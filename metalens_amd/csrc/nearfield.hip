@@ -77,6 +77,21 @@ int power_flush(ml_ctx *ctx) {
     return ML_OK;
 }
 
+// upper bound on the centre list's length before the host has seen the lists: the patches with a sample inside
+// the square around the centre disc (the axes' host copies are the grid's)
+static int centre_patch_bound(const ml_ctx *ctx, int nx, int ny) {
+    auto span = [&](const std::vector<double> &axis, int n) {
+        int lo = n, hi = -1;
+        for (int i = 0; i < n && i < (int)axis.size(); ++i)
+            if (std::fabs(axis[i]) <= ctx->r_centre) {
+                lo = std::min(lo, i);
+                hi = std::max(hi, i);
+            }
+        return hi < lo ? 0 : hi / 8 - lo / 8 + 1;
+    };
+    return span(ctx->h_x_pts, nx) * span(ctx->h_y_pts, ny);
+}
+
 void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int ny, NfArgs &a) {
     a.p = p[0];
     a.n_pol = n;
@@ -166,19 +181,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.use_active = 0;
     a.list_count = nullptr;
     a.first_pass = 0;
-    {
-        // patches with a sample inside the square around the centre disc (the axes' host copies are the grid's)
-        auto span = [&](const std::vector<double> &axis, int n) {
-            int lo = n, hi = -1;
-            for (int i = 0; i < n && i < (int)axis.size(); ++i)
-                if (std::fabs(axis[i]) <= ctx->r_centre) {
-                    lo = std::min(lo, i);
-                    hi = std::max(hi, i);
-                }
-            return hi < lo ? 0 : hi / 8 - lo / 8 + 1;
-        };
-        a.centre_patch_bound = span(ctx->h_x_pts, nx) * span(ctx->h_y_pts, ny);
-    }
+    a.centre_patch_bound = 0;   // (nearfield_launch: first pass only)
     for (int k = 0; k < 4; ++k) a.n_active[k] = 0;
     a.patches_x = (ny + 7) / 8;
     a.simple_orders = ctx->simple_orders ? 1 : 0;
@@ -229,6 +232,16 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
         ML_TRY(nearfield_geometry_launch(ctx, a));
         memcpy(ctx->geo_key, geo_key, sizeof geo_key);
         ctx->n_active[0] = -1;
+        // the lists' lengths start their way back now, behind the scans and in front of the synthesis
+        if (!ctx->counts_pinned) {
+            ML_HIP(hipHostMalloc((void **)&ctx->counts_pinned, 4 * sizeof(int), hipHostMallocDefault));
+            ML_HIP(hipEventCreateWithFlags(&ctx->counts_ready, hipEventDisableTiming));
+        }
+        // (one strided copy: the four totals lie count_stride integers apart)
+        ML_HIP(hipMemcpy2DAsync(ctx->counts_pinned, sizeof(int), ctx->active_count.p, (size_t)a.count_stride * sizeof(int),
+                                sizeof(int), 4, hipMemcpyDeviceToHost, ctx->stream));
+        ML_HIP(hipEventRecord(ctx->counts_ready, ctx->stream));
+        ctx->counts_queued = true;
         ctx->zero_key[1] = -1;   // every patch is visited (and its zeros stored) once more
     }
     // samples outside the lens are zero whatever the source: stored by the first synthesis into
@@ -244,11 +257,19 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
         if (ctx->n_active[0] < 0) {
             const int lo = ctx->simple_orders ? 1 : 0, hi = ctx->simple_orders ? 3 : 0;
             for (int k = 0; k < 4; ++k) ctx->n_active[k] = 0;
-            for (int k = lo; k <= hi; ++k)
-                ML_HIP(hipMemcpyAsync(&ctx->n_active[k], ctx->active_count.as<int>() + (size_t)k * a.count_stride,
-                                      sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            ML_HIP(hipMemsetAsync(ctx->partial_power.p, 0, ctx->partial_power.bytes, ctx->stream));
-            ML_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx->counts_queued) {
+                // (queued with the geometry, an earlier call: normally long there - no draining of the stream)
+                ML_HIP(hipEventSynchronize(ctx->counts_ready));
+                for (int k = lo; k <= hi; ++k) ctx->n_active[k] = ctx->counts_pinned[k];
+                ctx->counts_queued = false;
+                ML_HIP(hipMemsetAsync(ctx->partial_power.p, 0, ctx->partial_power.bytes, ctx->stream));
+            } else {
+                for (int k = lo; k <= hi; ++k)
+                    ML_HIP(hipMemcpyAsync(&ctx->n_active[k], ctx->active_count.as<int>() + (size_t)k * a.count_stride,
+                                          sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                ML_HIP(hipMemsetAsync(ctx->partial_power.p, 0, ctx->partial_power.bytes, ctx->stream));
+                ML_HIP(hipStreamSynchronize(ctx->stream));
+            }
         }
         if (ctx->n_active[0] + ctx->n_active[1] + ctx->n_active[2] + ctx->n_active[3] > 0) {
             a.use_active = 1;
@@ -261,6 +282,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     // single calls, so bit-identical to them - before any of them is transformed: geometry, lists and
     // tables are set up once, and the geometry records are still cached when the next member reads
     // them (no stage-1 result in between)
+    if (!a.use_active) a.centre_patch_bound = centre_patch_bound(ctx, nx, ny);
     bool one_position = true;
     for (int m = 1; m < n; ++m)
         one_position = one_position && p[m].source_x == p[0].source_x && p[m].source_y == p[0].source_y &&
@@ -275,6 +297,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
                 fill_nf_args(ctx, p + m, 1, nx, ny, am);
                 am.outside_is_zero = a.outside_is_zero;
                 am.use_active = a.use_active;
+                am.centre_patch_bound = a.centre_patch_bound;
                 for (int k = 0; k < 4; ++k) am.n_active[k] = a.n_active[k];
                 am.fields += (size_t)m * 4 * nx * ny * 2;
                 am.partial_power += (size_t)m * a.n_partials;

@@ -128,6 +128,8 @@ struct NfArgs {
     // plan; the stored fields are F[i][j] * premod[j], which is what the plan's stage 1 needs
     const double2 *premod;
 };
+// kernel arguments travel in a 4 KB segment: the patch-list pointer + this
+static_assert(sizeof(NfArgs) + 8 <= 4096, "NfArgs no longer fits the kernel-argument segment");
 
 // monotone map double -> uint64 (so that integer max == floating max)
 __device__ __forceinline__ unsigned long long ordered_key(double v) {
