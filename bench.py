@@ -733,7 +733,7 @@ def main():
                     'first = axes upload, plan tables, row extents, geometry kernel + scans, a synthesis '
                     'whose ring kernel visits ALL patches and stores the zeros outside the lens (the centre '
                     'kernel works from its list already), transform, projection; '
-                    'second = reads the active-patch count back (one sync) and launches the listed '
+                    'second = takes the lists\' lengths (queued back behind the scans of the first step) and launches the listed '
                     'patches; third = a steady single step, launch latency included (the timed region '
                     'queues its steps back to back)'}
     # ---- the same workload with the tables characterize() would really produce (--orders physical: 7 to 11 orders
