@@ -512,20 +512,28 @@ def main():
             x_pts=x[rows], y_pts=x)
         scale = max(np.abs(w).max() for w in want[:4])
         nf_err = max(np.abs(g[rows] - w).max() for g, w in zip(Ex, want[:4])) / scale
-        sel = np.arange(0, u.size, max(1, u.size // 16))
-        ref = farfield_oracle.farfield_direct(*Ex, x, x, wavelength, hp.n_glass, u[sel], u[sel])
-        ff_err = max(np.abs(res[k][np.ix_(sel, sel)] - ref[k]).max() / np.abs(ref[k]).max()
-                     for k in ('a_theta', 'a_phi'))
+        # a 16 x 16 sample of the direction grid + the 3 x 3 directions around the focus; max|E| = the peak of
+        # the WHOLE map (the GPU's: the sample alone misses the focus by orders of magnitude)
+        amp = np.abs(res['a_theta']) ** 2 + np.abs(res['a_phi']) ** 2
+        pi, pj = np.unravel_index(np.argmax(amp), amp.shape)
+        every = np.arange(0, u.size, max(1, u.size // 16))
+        sel_i = np.unique(np.concatenate((every, np.clip([pi - 1, pi, pi + 1], 0, u.size - 1))))
+        sel_j = np.unique(np.concatenate((every, np.clip([pj - 1, pj, pj + 1], 0, u.size - 1))))
+        ref = farfield_oracle.farfield_direct(*Ex, x, x, wavelength, hp.n_glass, u[sel_i], u[sel_j])
+        peak = {k: float(np.abs(res[k]).max()) for k in ('a_theta', 'a_phi')}
+        ff_err = max(np.abs(res[k][np.ix_(sel_i, sel_j)] - ref[k]).max() / peak[k] for k in ('a_theta', 'a_phi'))
         # ... and pointwise, |dE| / |E| per direction, over the sampled directions that are brighter
-        # than 1e-3 of the brightest (the rounding of an N^2-term sum is absolute, ~1e-15 max|E|,
-        # so a direction 1000 x dimmer than the peak carries ~1e-12 relative)
+        # than 1e-3 of the peak (the rounding of an N^2-term sum is absolute, ~1e-15 max|E|,
+        # so a direction 1000 x dimmer than the peak carries up to ~1e-12 relative)
         pw_err = 0.0
         for k in ('a_theta', 'a_phi'):
-            bright = np.abs(ref[k]) > 1e-3 * np.abs(ref[k]).max()
-            pw_err = max(pw_err, float((np.abs(res[k][np.ix_(sel, sel)] - ref[k])[bright]
-                                        / np.abs(ref[k])[bright]).max()))
+            bright = np.abs(ref[k]) > 1e-3 * peak[k]
+            if bright.any():
+                pw_err = max(pw_err, float((np.abs(res[k][np.ix_(sel_i, sel_j)] - ref[k])[bright]
+                                            / np.abs(ref[k])[bright]).max()))
         rel_err = {'nearfield_vs_oracle': nf_err, 'farfield_E_vs_oracle': ff_err,
-                   'farfield_E_pointwise_above_1e-3_of_peak': pw_err}
+                   'farfield_E_pointwise_above_1e-3_of_peak': pw_err,
+                   'directions_checked': int(sel_i.size * sel_j.size)}
         del Ex
     replica_table = None
     if replicas:

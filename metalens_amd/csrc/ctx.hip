@@ -185,6 +185,15 @@ static int refresh_ring_locations(ml_ctx *ctx) {
             L.idx[s] = o;
             L.present |= 1 << s;
         }
+        // the restricted kernels name an order in a bound report by the number of present slots below it
+        // (nearfield_simple.hip report_orders), i.e. they take the table's own list to be ascending in ox - what
+        // grating.py:1186-1232 and the packers produce.  A caller of the C ABI that lists them otherwise gets the
+        // general kernels, which carry every order's own index.
+        for (int s = 0, last = -1; s < L.n; ++s) {
+            if (L.idx[s] < 0) continue;
+            if (L.idx[s] < last) return false;
+            last = L.idx[s];
+        }
         return true;
     };
     Canon canon[MAX_RING_COLLS], canon_center;
@@ -227,7 +236,18 @@ static int refresh_ring_locations(ml_ctx *ctx) {
                             : (size_t)t.n_orders * t.n0 * t.n1 * 4;
         ok_total += (size_t)t.n_orders * 4;
     }
-    if (simple) ML_REQUIRE(tab_total < (1ull << 27), "ring tables of %zu block units: too large", tab_total);   // (nearfield_simple.hip parks block | collection << 27)
+    // (nearfield_simple.hip: a sample's block = the ring's first unit + its cell, a 31-bit key - `blk`, -1 = none -
+    // and the cell itself a 24-bit product (i0 (n1 - 1) + i1) n_slots: v_mad_u32_u24 / v_mul_u32_u24)
+    if (simple) {
+        ML_REQUIRE(tab_total + SIMPLE_MAX_SLOTS + 1 < (1ull << 31), "ring tables of %zu block units: too large", tab_total);
+        for (int c = 0; c < ctx->n_colls; ++c) {
+            const TableSlot &t = ctx->slots[ctx->coll_slot[c]];
+            ML_REQUIRE((long long)std::max(t.n0 - 1, 1) * std::max(t.n1 - 1, 1) * canon[c].n < (1ll << 24) && t.n0 < (1 << 12) &&
+                           t.n1 < (1 << 12),
+                       "table of collection %d is too large for the 24-bit cell arithmetic (%d x %d nodes, %d orders)",
+                       ctx->coll_slot[c], t.n0, t.n1, canon[c].n);
+        }
+    }
     // (simple: a wave that straddles two collections stages every block at the larger one's size -
     // the tail of the array is padded by a largest block so that the surplus stays inside it)
     std::vector<double> tab((tab_total + (simple ? SIMPLE_MAX_SLOTS + 1 : 0)) * 2 * (simple ? UNIT : 1), 0.0), ok(ok_total);

@@ -1038,7 +1038,6 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.n_valid = n_have;
             c.M = mx;
             c.j0 = pl.fft_x.j0;
-        c.jstep = pl.fft_x.jstep;
             c.jstep = pl.fft_x.jstep;
             c.pad1 = pl.il_pad1;
             c.pad2 = pl.il_pad2;

@@ -270,6 +270,9 @@ class HotPath:
         vec = [np.empty(self.shape, dtype=np.complex128) for _ in range(4)]
         _lib.check(lib.ml_farfield_download(ctx.handle, *[_lib.dptr(v) for v in vec]))
         local_power = power.value * self.dxp * self.dyp
+        # 'tie_breaker': which scipy chose between exactly equidistant centre cells, if any sample needed it
+        # (ties.settle: the reference's own tie-breaker is cKDTree's traversal order) - None: no ties on this grid
         return {'P': P, 'a_theta': a_theta, 'a_phi': a_phi, 'Nx': vec[0], 'Ny': vec[1],
-                'Lx': vec[2], 'Ly': vec[3], 'power_local_rows': local_power}
+                'Lx': vec[2], 'Ly': vec[3], 'power_local_rows': local_power,
+                'tie_breaker': getattr(ctx, 'tie_settlement', None)}
 

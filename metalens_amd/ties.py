@@ -11,15 +11,29 @@ answers back (``ml_nearfield_tie_answers``); the synthesis is then run again.  T
 the grid and the cells only, not on the source, so a sweep pays this once.  No ties (the usual
 case: even sample counts) -> no scipy import, no second run.
 """
+import warnings
+
 import numpy as np
 
 from . import _lib
 
 _tree_cache = {}
+# the scipy the golden fixtures of tests/golden were generated with (tests/golden/gen/make_golden.py META):
+# the tie choice IS that library's tree traversal, so a different version may legitimately choose differently
+FIXTURE_SCIPY = '1.15.3'
+# what settled the ties of the last call: {'scipy': version, 'fixture_scipy': ..., 'samples': n} (None: no ties yet)
+last_settlement = None
+_warned = set()
 
 
 def _tree(lens_center_summary, token):
+    import scipy
     from scipy.spatial import cKDTree   # the reference's own tie-breaker
+    if scipy.__version__ != FIXTURE_SCIPY and scipy.__version__ not in _warned:
+        _warned.add(scipy.__version__)
+        warnings.warn('exact nearest-cell ties are settled by scipy.spatial.cKDTree of scipy %s; the parity fixtures '
+                      'of this package were generated with scipy %s, whose tree may order equidistant cells differently'
+                      % (scipy.__version__, FIXTURE_SCIPY), RuntimeWarning, stacklevel=3)
     hit = _tree_cache.get(token)
     if hit is None:
         _tree_cache.clear()             # one lens at a time is the normal use
@@ -55,6 +69,10 @@ def settle(ctx, lens_center_summary, x_local, y_pts, known=None):
     pts = np.column_stack((np.asarray(x_local, dtype=float)[ids // ny],
                            np.asarray(y_pts, dtype=float)[ids % ny]))
     cells = _tree(lens_center_summary, ctx.layout_token).query(pts)[1].astype(np.int32)
+    import scipy
+    global last_settlement
+    last_settlement = {'scipy': scipy.__version__, 'fixture_scipy': FIXTURE_SCIPY, 'samples': int(ids.size)}
+    ctx.tie_settlement = dict(last_settlement)   # recorded next to the results of this context (HotPath.results())
     if known is not None and known[0].size:
         ids = np.concatenate((known[0], ids))
         cells = np.concatenate((known[1], cells))

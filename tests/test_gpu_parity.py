@@ -588,32 +588,6 @@ def test_position_batch_equals_single_sources(ma):
     assert ctx.lib.ml_nearfield_batch_async(ctx.handle, bad, 2, _lib.dptr(xs), xs.size, _lib.dptr(xs), xs.size) != 0
 
 
-@pytest.mark.parametrize('reduce', ['amplitudes', 'vectors'])
-def test_rccl_path_single_rank(reduce):
-    """the multi-GPU code path (RCCL loaded with dlopen, unique-id exchange through /tmp,
-    communicator, all-reduce of the projected amplitudes or of the radiation vectors, max/sum
-    reductions) run for real with one rank: results must equal the plain single-GPU run"""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', '512', '--farfield', '64',
-           '--diameter', '3e-4', '--steps', '2', '--warmup', '1', '--blocks', '1',
-           '--cpu-rows', '0', '--cpu-fft-side', '0', '--reduce', reduce]
-    env = dict(os.environ, ML_FORCE_RCCL='1', RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
-               MASTER_ADDR='127.0.0.1', MASTER_PORT='29511' if reduce == 'vectors' else '29512')
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    # stdout must be the ONE JSON line and nothing else (RCCL's version banner, which the library
-    # prints to stdout when the first communicator is created, is diverted to stderr)
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1 and lines[0].startswith('{'), out.stdout[-2000:]
-    line = json.loads(lines[0])
-    assert line['n_gpus'] == 1
-    assert line['rel_err']['farfield_E_vs_oracle'] < 1e-12
-    assert line['rel_err']['nearfield_vs_oracle'] < 1e-12
-
-
 def test_full_size_roundtrip_properties(ma):
     """BASELINE config[1] size (2048^2 -> 256^2): size-independent checks - the direct
     transform of a separable field equals the outer product of 1-D transforms, and is
@@ -739,236 +713,6 @@ def test_f32_gemm_hot_path_vs_f64(ma, f32_gemm):
         scale = np.abs(out['f64'][key]).max()
         err = np.abs(out['f32'][key] - out['f64'][key]).max() / scale
         assert 1e-10 < err <= TOL_F32, (key, err)
-
-
-def _run_bench(extra, env, timeout=600, aperture=512, farfield=64, diameter='3e-4'):
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', str(aperture),
-           '--farfield', str(farfield),
-           '--diameter', diameter, '--na', '0.5', '--steps', '2', '--warmup', '1', '--blocks', '1',
-           '--cpu-rows', '0', '--cpu-fft-side', '0', '--scaling', 'strong'] + extra
-    return subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE,
-                            stderr=subprocess.PIPE, text=True)
-
-
-@pytest.mark.parametrize('reduce,aperture,pairs,world', [
-    ('amplitudes', 512, 0, 2), ('vectors', 512, 0, 2), ('amplitudes', 511, 0, 2), ('amplitudes', 512, 300, 2),
-    ('vectors', 512, 300, 2), ('amplitudes', 2048, 0, 4), ('amplitudes', 2048, 0, 8), ('amplitudes', 1000, 0, 4),
-    ('amplitudes-allreduce', 512, 0, 2), ('amplitudes-allreduce', 2048, 0, 4), ('amplitudes', 512, 301, 2)])
-def test_two_ranks_sharing_one_gpu(tmp_path, reduce, aperture, pairs, world):
-    """bench.py --gpus N end to end on ONE GPU: N processes (ranks 0 .. N-1, all on device 0)
-    with the test communicator (ML_COMM_BACKEND=file; RCCL refuses two ranks per GPU): unique-id
-    rendezvous, row shards (interleaved blocks on lattice grids - 512 and 2048 rows -, weighted
-    mirrored pairs at 1000 rows, whose lattice is not a multiple of 256 N), per-rank synthesis and
-    transform, the reduction - a reduce-scatter over blocks of direction rows + each rank's power of its
-    block + results()' all-gather by default; the all-reduce forms; the all-reduce fallback when the
-    directions do not divide by the rank count (301 listed directions over 2 ranks) - max-over-ranks
-    timing - and the far field must equal the one-process result.  The odd aperture takes contiguous row blocks, and only the rank that owns the x = 0
-    row meets nearest-cell ties: results() has to settle them collectively.  ``pairs`` > 0: a LIST
-    of directions instead of the tensor grid (no folded / mirrored form: contiguous row blocks)."""
-    import json
-    more = ['--pair-list', str(pairs)] if pairs else []
-    one = str(tmp_path / 'one.npz')
-    p = _run_bench(['--dump', one] + more, {}, aperture=aperture)
-    out, err = p.communicate(timeout=600)
-    assert p.returncode == 0, err[-2000:]
-    two = str(tmp_path / 'two.npz')
-    env = dict(ML_COMM_BACKEND='file', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-               MASTER_PORT=str(29533 + ('amplitudes', 'vectors', 'amplitudes-allreduce').index(reduce) + 3 * (aperture % 2) +
-                               6 * (pairs > 0) + 12 * (pairs % 2) + 24 * world))
-    procs = [_run_bench(['--gpus', str(world), '--dump', two, '--reduce', reduce] + more,
-                        dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=aperture)
-             for r in range(world)]
-    outs = [q.communicate(timeout=600) for q in procs]
-    for q, (o, e) in zip(procs, outs):
-        assert q.returncode == 0, e[-2000:]
-    lines = [l for l in outs[0][0].splitlines() if l.strip()]
-    assert len(lines) == 1 and not outs[1][0].strip(), (outs[0][0], outs[1][0])
-    line = json.loads(lines[0])
-    assert line['n_gpus'] == world and line['scaling'] == 'strong'
-    # the diagnostics a first real multi-GPU run is read by: the backend's own rank count, every rank's
-    # kernel times, what the main stream waited for the collective, the same shards without it
-    mg = line['multi_gpu']
-    assert mg['ranks_reported_by_backend'] == world and mg['backend'].startswith('file') and mg['reduce'] == reduce
-    assert [r['rank'] for r in mg['per_rank_ms']] == list(range(world))
-    assert all(r['nearfield'] > 0 and r['zgemm_stage1'] > 0 for r in mg['per_rank_ms'])
-    assert mg['ms_per_step_no_collective'] > 0
-    want_sharding = ('interleaved' if not pairs and aperture % (256 * world) == 0 else
-                     'mirrored' if not pairs and aperture % 2 == 0 else 'rows')
-    assert line['config']['sharding'].startswith(want_sharding), line['config']['sharding']
-    a, b = np.load(one), np.load(two)
-    for key in ('a_theta', 'a_phi'):
-        assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), key
-    ok = ~np.isnan(a['P'])
-    assert np.array_equal(np.isnan(b['P']), ~ok)
-    assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
-
-
-@pytest.mark.parametrize('world', [2, 4, 8])
-def test_plain_bench_gpus_n_starts_its_own_ranks(tmp_path, world):
-    """``python bench.py --gpus N`` with NO launcher environment (the way the driver starts the N = 1
-    line): bench.py starts the N ranks itself and rank 0's stdout carries the one JSON line.  Here the
-    ranks share the one GPU through the file communicator; the far field equals the one-process one."""
-    import json
-    one = str(tmp_path / 'one.npz')
-    p = _run_bench(['--dump', one], {}, aperture=2048)
-    out, err = p.communicate(timeout=600)
-    assert p.returncode == 0, err[-2000:]
-    env = {k: v for k, v in os.environ.items()
-           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    many = str(tmp_path / 'many.npz')
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(world), '--aperture', '2048', '--farfield', '64',
-           '--diameter', '3e-4', '--na', '0.5', '--steps', '2', '--warmup', '1', '--blocks', '1', '--cpu-rows', '0',
-           '--cpu-fft-side', '0', '--scaling', 'strong', '--dump', many]
-    q = subprocess.run(cmd, env=dict(env, ML_COMM_BACKEND='file'), capture_output=True, text=True, timeout=900)
-    assert q.returncode == 0, q.stderr[-2000:]
-    lines = [l for l in q.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, q.stdout
-    line = json.loads(lines[0])
-    assert line['n_gpus'] == world and line['multi_gpu']['ranks_reported_by_backend'] == world
-    assert line['config']['sharding'].startswith('interleaved')
-    # the line carries the SAME workload on one GPU (rank 0 alone on the whole aperture): the N = 1 point
-    # of the strong-scaling curve, whatever the driver ran at --gpus 1
-    ref = line['multi_gpu']['one_gpu_same_workload']
-    assert ref['ms_per_step'] > 0 and abs(ref['value'] - 2048.0 ** 2 * 64 ** 2 / (ref['ms_per_step'] * 1e-3)) < 1e-6 * ref['value']
-    a, b = np.load(one), np.load(many)
-    for key in ('a_theta', 'a_phi'):
-        assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), key
-
-
-def test_wavelength_replicas(tmp_path):
-    """BASELINE configs[3] (tri-wavelength sweep, one wavelength per rank, no collective in the data
-    path): ``bench.py --replicas wavelength`` as three single-rank runs, one per wavelength, then as
-    two ranks sharing the GPU through the file communicator.  Every replica checks itself against the
-    oracle and reports the substrate index it ran with - explicit, because none of the three
-    wavelengths is in the reference's table (grating.py:1277-1288, nearfield.py:111-113)."""
-    import json
-    want = {450: 1.4656, 532: 1.4607, 635: 1.4570}
-    extra = ['--replicas', 'wavelength', '--check', '1', '--cold', '0']
-    for k, (nm_, ng) in enumerate(want.items()):
-        p = _run_bench(extra + ['--replica-index', str(k)], {}, aperture=512)
-        out, err = p.communicate(timeout=600)
-        assert p.returncode == 0, err[-2000:]
-        d = json.loads([l for l in out.splitlines() if l.strip()][-1])
-        (rep,) = d['config']['replicas']
-        assert round(rep['wavelength_nm']) == nm_ and rep['n_glass'] == ng
-        assert 0 <= d['rel_err']['nearfield_vs_oracle'] < 1e-12 and 0 <= d['rel_err']['farfield_E_vs_oracle'] < 1e-12
-        assert d['config']['parallelism'].startswith('replicas only')
-    # one wavelength at the north-star aperture (4096^2 -> 512^2 on the 1 mm lens)
-    p = _run_bench(extra + ['--replica-index', '1'], {}, aperture=4096, farfield=512, diameter='1e-3')
-    out, err = p.communicate(timeout=900)
-    assert p.returncode == 0, err[-2000:]
-    d = json.loads([l for l in out.splitlines() if l.strip()][-1])
-    (rep,) = d['config']['replicas']
-    assert round(rep['wavelength_nm']) == 532 and rep['n_glass'] == 1.4607 and d['config']['aperture'] == 4096
-    assert 0 <= d['rel_err']['nearfield_vs_oracle'] < 1e-12 and 0 <= d['rel_err']['farfield_E_vs_oracle'] < 1e-12
-    env = dict(ML_COMM_BACKEND='file', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29611')
-    procs = [_run_bench(['--gpus', '2'] + extra, dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=512)
-             for r in range(2)]
-    outs = [q.communicate(timeout=600) for q in procs]
-    for q, (o, e) in zip(procs, outs):
-        assert q.returncode == 0, e[-2000:]
-    d = json.loads([l for l in outs[0][0].splitlines() if l.strip()][-1])
-    assert d['n_gpus'] == 2 and [round(r['wavelength_nm']) for r in d['config']['replicas']] == [450, 532]
-    assert [r['n_glass'] for r in d['config']['replicas']] == [1.4656, 1.4607]
-    for r in d['config']['replicas']:
-        assert 0 <= r['nearfield_vs_oracle'] < 1e-12 and 0 <= r['farfield_E_vs_oracle'] < 1e-12
-    # twice the work of one replica in the same time: the aggregate counts both apertures
-    assert abs(d['value'] - 2 * 512.0 ** 2 * 64 ** 2 / (d['ms_per_step'] * 1e-3)) < 1e-6 * d['value']
-
-
-def test_bench_line_contract():
-    """bench.py at N = 1 prints exactly one JSON line with the fields the driver reads: the
-    metric, K timed steps, a roofline object with a fraction <= 1 and the per-launch duration it
-    came from, the CPU baseline timed beside it, and the self-check against the oracle."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--aperture', '512', '--farfield', '64',
-           '--diameter', '1.2e-4', '--steps', '3', '--warmup', '1', '--blocks', '2', '--cpu-rows', '32',
-           '--cpu-fft-side', '128']
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, p.stdout
-    d = json.loads(lines[0])
-    assert d['metric'] == 'aperture x far-field pair-evals/sec' and d['unit'] == 'pair-evals/s'
-    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['higher_is_better'] is True
-    assert d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None
-    assert abs(d['value'] - 512.0 ** 2 * 64 ** 2 * 3 / (d['ms_per_step'] * 3e-3)) < 1e-6 * d['value']
-    assert len(d['ms_per_step_blocks']) == 2 and 'workload' in d['config']
-    for key in ('roofline', 'roofline_other'):
-        r = d[key]
-        # the contract's object: algorithmic bytes (or executed flops) per launch / launch time against the peak
-        assert r['bound'] in ('hbm', 'mfma') and 0 < r['frac'] <= 1 and r['peak'] > 0
-        assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['avg_launch_ms'] > 0 and 'traffic' in r
-        if r['kernel'].startswith('nearfield'):
-            # 64 B per sample the launches process - the samples inside the lens circle - written once; the figure
-            # over the whole window beside it; what binds the kernel (vector-instruction issue) rides along where
-            # the configuration has a counter profile
-            n_in = d['config']['samples_in_lens']
-            assert 0.5 * 512 * 512 < n_in < 512 * 512       # (the 120 um lens in its 512^2 window at pitch lambda/2.2)
-            assert r['bound'] == 'hbm' and abs(r['bytes_per_launch'] - 64.0 * n_in) < 1
-            assert abs(r['frac_full_grid'] - r['frac'] * 512 * 512 / n_in) < 1e-9
-            assert 'valu' not in r or 0 < r['valu']['issue_frac'] <= 1
-        else:
-            assert 'traffic_frac' in r
-    assert 0 < d['roofline']['step_hbm_frac'] <= 1
-    assert d['config']['pmc_key'].startswith('gpus=1,aperture=512,farfield=64,precision=f64')
-    # the tables of the timed workload hold the three orders SURVEY.md 8(d) prescribes; the line also carries the
-    # same workload with the order lists characterize() would record, and says which kernels each took
-    assert d['config']['orders'] == 'survey' and d['config']['orders_per_table'] == [3] * len(d['config']['orders_per_table'])
-    assert d['config']['nearfield_kernels']['family'] == 'orders-along-x'
-    ph = d['physical_orders']
-    assert max(ph['orders_per_table']) > 4 and ph['nearfield_kernels']['ring_orders_max'] == max(ph['orders_per_table'])
-    assert ph['ms_per_step'] > 0 and ph['nearfield_ms'] > 0
-    # a single call on a grid the context has not seen (geometry kernel, scans, zeros stored)
-    assert d['ms_first_step_new_geometry'] > 0 and d['cold_step']['first_ms'] >= d['cold_step']['third_ms'] > 0
-    c = d['cpu_baseline']
-    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c
-    assert d['cpu_baseline_reference_route']['value'] > 0
-    assert d['rel_err']['nearfield_vs_oracle'] < 1e-12 and d['rel_err']['farfield_E_vs_oracle'] < 1e-12
-
-
-def test_two_gpus_real_rccl(tmp_path):
-    """bench.py --gpus 2 with REAL RCCL over xGMI, one rank per GPU: runs only where two GPUs are
-    visible (the single-GPU boxes of this pool skip it; the file-communicator test above covers
-    the same flow there).  Rendezvous through the launcher's environment, ncclCommInitRank with
-    two ranks, the all-reduce of the projected amplitudes on the second stream, max-over-ranks
-    timing - and the far field must equal the one-process result."""
-    import json
-    from metalens_amd import _lib
-    n = _lib.c_int(0)
-    _lib.check(_lib.load().ml_device_count(_lib.byref(n)))
-    if n.value < 2:
-        pytest.skip('needs two GPUs (%d visible)' % n.value)
-    one = str(tmp_path / 'one.npz')
-    p = _run_bench(['--dump', one, '--steps', '6'], {}, aperture=512)
-    out, err = p.communicate(timeout=600)
-    assert p.returncode == 0, err[-2000:]
-    for reduce in ('amplitudes', 'vectors'):
-        two = str(tmp_path / ('two_%s.npz' % reduce))
-        env = dict(WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(29571 + (reduce == 'vectors')), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs = [_run_bench(['--gpus', '2', '--dump', two, '--reduce', reduce, '--steps', '6'],
-                            dict(env, RANK=str(r), LOCAL_RANK=str(r)), aperture=512) for r in range(2)]
-        outs = [q.communicate(timeout=600) for q in procs]
-        for q, (o, e) in zip(procs, outs):
-            assert q.returncode == 0, e[-2000:]
-        line = json.loads([l for l in outs[0][0].splitlines() if l.strip()][-1])
-        assert line['n_gpus'] == 2
-        a, b = np.load(one), np.load(two)
-        for key in ('a_theta', 'a_phi'):
-            assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), (reduce, key)
-        ok = ~np.isnan(a['P'])
-        assert np.array_equal(np.isnan(b['P']), ~ok)
-        assert np.abs(a['P'][ok] - b['P'][ok]).max() <= 1e-12 * a['P'][ok].max()
 
 
 def test_full_size_nearfield_rows_and_determinism(ma):
@@ -1532,34 +1276,35 @@ def _record(name, **values):
             f.write(json.dumps(dict(name=name, **values)) + '\n')
 
 
-# |dE| / |E| over the sampled directions above 1e-3 of the peak, GPU against the fp64 oracle, PER SIZE AND
-# PATH: twice what the GPU measures against the oracle there (profiles/r05_parity_measured.jsonl), and never
-# below the oracle's OWN distance from a long-double evaluation of the same sums.  Where everybody stands
-# against those long-double sums (tools/oracle_longdouble.py --gpu-dump, profiles/r05_longdouble.json), a_phi,
-# the worse of the two amplitudes:
-#     size      oracle vs long double   GPU vs long double   GPU vs oracle
-#     2048^2          3.8e-13               1.2e-12             1.6e-12
-#     4096^2          6.0e-13               7.1e-13             6.7e-13      <- the north-star size: below 1e-12
-# (rounding of an N^2-term fp64 sum is absolute, ~1e-15 of max|E| whoever takes it - the GPU's pruned FFT
-# 1.3 ... 1.6e-15, the oracle's BLAS sums 0.7 ... 1.1e-15 - and shows up to 1000 x magnified in the dimmest
-# of these directions; the 2048^2 window cuts the 1 mm lens off, its far field has the stronger side lobes).
+# |dE| / |E| over the directions above 1e-3 of the PEAK of the far field, GPU against the fp64 oracle on the same
+# (GPU-made) near field; north_star: < 1e-12.  The peak is the maximum over the WHOLE direction grid (the GPU's own
+# map), and up to 4096^2 the oracle evaluates the whole grid too; beyond, a 16 x 16 sample plus the 3 x 3 directions
+# around the peak.  (Until round 6 both the floor and the peak came from the 16 x 16 sample alone, which misses the
+# focus: "1e-3 of the peak" then admitted directions ~1e-5 of the true peak and the figures read 1.6e-12 at 2048^2,
+# 7e-13 at 4096^2.  tools/parity_isolate.py, profiles/r06_parity_isolate_{2048,4096}.txt: on the whole grid the pruned
+# FFT is at 5.5e-13 / 1.6e-13, the folded fp64 GEMMs - cos / sin advanced by rotations between table seeds - at
+# 6.2e-13 / 1.3e-12.)  Where everybody stands against long-double sums: tools/oracle_longdouble.py.
+# Bounds: 1e-12 for the default (FFT) path at every size; the folded GEMMs ~1.3 x what they measure.
 # fp32 GEMM mode: twice the value measured at its size; the 1e-4 of BASELINE.json is met relative to max|E|
 # - the normalisation the bench line names.
 POINTWISE = {   # (side, precision, method) -> bound; measured GPU vs oracle in the comment
-    (2048, 'f64', 'auto'): 3.3e-12,     # 1.63e-12
-    (4096, 'f64', 'auto'): 1.5e-12,     # 7.1e-13
-    (4096, 'f64', 'gemm'): 2.1e-12,     # 1.05e-12
-    (8192, 'f64', 'auto'): 1.7e-12,     # 8.3e-13
-    (16384, 'f64', 'auto'): 2.1e-12,    # 1.02e-12
-    (16384, 'f64', 'gemm'): 2.1e-12,    # 1.02e-12
+    (2048, 'f64', 'auto'): 1.0e-12,     # 5.5e-13 (whole grid)
+    (4096, 'f64', 'auto'): 1.0e-12,     # 1.6e-13 (whole grid)
+    (4096, 'f64', 'gemm'): 1.7e-12,     # 1.3e-12 (whole grid)
+    (8192, 'f64', 'auto'): 1.0e-12,
+    (16384, 'f64', 'auto'): 1.0e-12,
+    (16384, 'f64', 'gemm'): 2.1e-12,
     (16384, 'f32', 'auto'): 1.5e-3,     # 7.4e-4
 }
+FULL_GRID_ORACLE_UP_TO = 4096
 
 
-def pointwise_rel_err(got, ref, floor=1e-3):
-    """max |d| / |ref| over the points where |ref| > floor * max|ref| (the far-field tolerance of
-    this suite is otherwise normalised by max|E|, which says little about the dim directions)"""
-    big = np.abs(ref) > floor * np.abs(ref).max()
+def pointwise_rel_err(got, ref, floor=1e-3, peak=None):
+    """max |d| / |ref| over the points where |ref| > floor * peak (default: max|ref|) - the far-field
+    tolerance of this suite is otherwise normalised by max|E|, which says little about the dim directions"""
+    big = np.abs(ref) > floor * (np.abs(ref).max() if peak is None else peak)
+    if not big.any():
+        return 0.0
     return (np.abs(got - ref)[big] / np.abs(ref)[big]).max()
 
 
@@ -1614,19 +1359,28 @@ def test_north_star_size_properties(ma, side, M, diameter, na, precision, method
                                                 x_pts=x[rows], y_pts=x)
         scale = max(np.abs(w).max() for w in want[:4])
         assert max(np.abs(g[rows] - w).max() for g, w in zip(F, want[:4])) <= TOL * scale
-        sel = np.arange(0, M, M // 16)
-        ref = farfield_oracle.farfield_direct(*F, x, x, wl, one.n_glass, u[sel], u[sel])
+        # directions the oracle evaluates: all of them up to 4096^2; else a 16 x 16 sample + the 3 x 3 around the peak
+        amp = np.abs(r1['a_theta']) ** 2 + np.abs(r1['a_phi']) ** 2
+        pi, pj = np.unravel_index(np.argmax(amp), amp.shape)
+        if side <= FULL_GRID_ORACLE_UP_TO:
+            sel_i = sel_j = np.arange(M)
+        else:
+            sel_i = np.unique(np.concatenate((np.arange(0, M, M // 16), np.clip([pi - 1, pi, pi + 1], 0, M - 1))))
+            sel_j = np.unique(np.concatenate((np.arange(0, M, M // 16), np.clip([pj - 1, pj, pj + 1], 0, M - 1))))
+        ref = farfield_oracle.farfield_direct(*F, x, x, wl, one.n_glass, u[sel_i], u[sel_j])
         for key in ('a_theta', 'a_phi'):
-            got = r1[key][np.ix_(sel, sel)]
-            assert np.abs(got - ref[key]).max() <= tol * np.abs(ref[key]).max()
-            # pointwise |dE| / |E| where |E| > 1e-3 max|E|: rounding of an N^2-term sum is absolute
-            # (~1e-15 max|E|), so the dimmest of these directions carries ~1e-12 relative
-            pw = pointwise_rel_err(got, ref[key])
+            got = r1[key][np.ix_(sel_i, sel_j)]
+            peak = np.abs(r1[key]).max()            # of the WHOLE map (the sample alone misses the focus)
+            assert np.abs(got - ref[key]).max() <= tol * peak
+            # pointwise |dE| / |E| where |E| > 1e-3 of the peak: rounding of an N^2-term sum is absolute
+            # (~1e-15 max|E|), so the dimmest of these directions carries up to ~1e-12 relative
+            pw = pointwise_rel_err(got, ref[key], peak=peak)
             _record('north_star_pointwise', side=side, precision=precision, method=method, key=key,
-                    pointwise=float(pw), rel_to_max=float(np.abs(got - ref[key]).max() / np.abs(ref[key]).max()))
+                    pointwise=float(pw), rel_to_max=float(np.abs(got - ref[key]).max() / peak),
+                    directions=int(sel_i.size * sel_j.size))
             assert pw <= POINTWISE[(side, precision, method)], (pw, POINTWISE[(side, precision, method)])
         if precision == 'f32':   # really the fp32 arithmetic: above fp64 round-off
-            assert np.abs(r1['a_theta'][np.ix_(sel, sel)] - ref['a_theta']).max() > 1e-10 * np.abs(ref['a_theta']).max()
+            assert np.abs(r1['a_theta'][np.ix_(sel_i, sel_j)] - ref['a_theta']).max() > 1e-10 * np.abs(ref['a_theta']).max()
         del F, ref, want
         # (b) determinism: the same step again, bit for bit
         one.step()
@@ -1740,8 +1494,12 @@ def test_nearest_cell_ties_follow_ckdtree(ma):
     hp.step()
     hp.sync()
     assert ties.pending(hp.ctx).size > 0
-    hp.results()
+    res = hp.results()
     assert ties.pending(hp.ctx).size == 0
+    # which scipy settled them rides with the result (the choice is that library's tree traversal)
+    import scipy
+    assert res['tie_breaker']['scipy'] == scipy.__version__ and res['tie_breaker']['samples'] > 0
+    assert res['tie_breaker']['fixture_scipy'] == ties.FIXTURE_SCIPY
     F = [np.empty((x.size, x.size), dtype=np.complex128) for _ in range(4)]
     _lib.check(hp.ctx.lib.ml_fields_download(hp.ctx.handle, *[_lib.dptr(a) for a in F]))
     scale = max(np.abs(w).max() for w in want[:4])

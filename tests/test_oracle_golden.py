@@ -174,3 +174,25 @@ def test_farfield_lens_A_lattice():
     assert np.isnan(P).sum() == z['P_nan_count']
     assert abs(total_P - z['total_P']) <= 1e-11 * abs(z['total_P'])
     assert tuple(np.unravel_index(np.nanargmax(P), P.shape)) == tuple(z['P_argmax'])
+
+
+def test_tie_breaker_names_the_fixtures_scipy():
+    """ties.settle asks scipy's cKDTree which of two equidistant cells wins (the reference's own choice,
+    nearfield.py:363-364); the version the fixtures were made with is recorded in every .npz and must be
+    the one ties.py warns against departing from"""
+    import glob
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        '_ties_src', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'metalens_amd', 'ties.py'))
+    src = open(spec.origin).read()
+    here = os.path.dirname(os.path.abspath(__file__))
+    versions = set()
+    for f in glob.glob(os.path.join(here, 'golden', '*.npz')):
+        z = np.load(f, allow_pickle=True)
+        if 'scipy' in z.files:
+            versions.add(str(z['scipy']))
+    assert len(versions) == 1
+    assert "FIXTURE_SCIPY = '%s'" % versions.pop() in src
