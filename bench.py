@@ -516,9 +516,9 @@ def main():
         # the WHOLE map (the GPU's: the sample alone misses the focus by orders of magnitude)
         amp = np.abs(res['a_theta']) ** 2 + np.abs(res['a_phi']) ** 2
         pi, pj = np.unravel_index(np.argmax(amp), amp.shape)
-        every = np.arange(0, u.size, max(1, u.size // 16))
-        sel_i = np.unique(np.concatenate((every, np.clip([pi - 1, pi, pi + 1], 0, u.size - 1))))
-        sel_j = np.unique(np.concatenate((every, np.clip([pj - 1, pj, pj + 1], 0, u.size - 1))))
+        sampled = np.arange(0, u.size, max(1, u.size // 16))
+        sel_i = np.unique(np.concatenate((sampled, np.clip([pi - 1, pi, pi + 1], 0, u.size - 1))))
+        sel_j = np.unique(np.concatenate((sampled, np.clip([pj - 1, pj, pj + 1], 0, u.size - 1))))
         ref = farfield_oracle.farfield_direct(*Ex, x, x, wavelength, hp.n_glass, u[sel_i], u[sel_j])
         peak = {k: float(np.abs(res[k]).max()) for k in ('a_theta', 'a_phi')}
         ff_err = max(np.abs(res[k][np.ix_(sel_i, sel_j)] - ref[k]).max() / peak[k] for k in ('a_theta', 'a_phi'))

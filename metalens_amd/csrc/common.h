@@ -363,6 +363,9 @@ struct ml_ctx {
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see row_extent_kernel; valid only for synthesised fields
     bool row_first_valid = false;
+    // rows of the local aperture that meet the lens circle, [trim_rows[0], trim_rows[1]) - farfield.hip; key: (grid, layout)
+    long trim_key[2] = {-1, -1};
+    int trim_rows[2] = {0, 0};
     // row_first depends on the grid and the lens radius only: recomputed when either changes
     long grid_serial = 0, layout_serial = 0, row_first_key[2] = {-1, -1};
     // bound-violation keys are double-buffered: the synthesis kernel that fills one half clears

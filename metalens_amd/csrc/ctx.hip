@@ -936,6 +936,20 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
     ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
     ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
+#ifdef ML_DIAG
+    {   // (tools/mode_moves.py: ... or the field planes'?)
+        static const int move_every = diag_int("ML_MOVE_FIELDS", 0);
+        static long calls = 0;
+        if (move_every > 0 && ++calls % move_every == 0) {
+            void *q = nullptr;
+            if (hipMalloc(&q, ctx->fields.bytes) == hipSuccess) {
+                // (the old allocation is LEFT in place - leaked, a diagnostic - so that every move lands somewhere new)
+                ctx->fields.p = q;
+                fprintf(stderr, "ML_MOVED fields %p\n", q);
+            }
+        }
+    }
+#endif
     ctx->nx = nx;
     ctx->ny = ny;
     ctx->n_sets = n;

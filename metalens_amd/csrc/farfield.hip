@@ -901,12 +901,70 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     const int64_t g_ld = nxl + 8;
     ML_TRY(pl.stage1.reserve(g_transposed ? (size_t)4 * my * g_ld * 2 * sizeof(double)
                                           : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
+#ifdef ML_DIAG
+    {   // (tools/mode_moves.py: does the row transform's 'mode' follow the stage-1 result's placement?)
+        static const int move_every = diag_int("ML_MOVE_STAGE1", 0);
+        static long calls = 0;
+        if (move_every > 0 && ++calls % move_every == 0 && pl.stage1.p) {
+            void *q = nullptr;
+            if (hipMalloc(&q, pl.stage1.bytes) == hipSuccess) {
+                // (the old allocation is LEFT in place - leaked, a diagnostic - so that every move lands somewhere new)
+                pl.stage1.p = q;
+                fprintf(stderr, "ML_MOVED stage1 %p\n", q);
+            }
+        }
+    }
+#endif
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
     static const long fold2_min_tiles = diag_int("ML_FOLD2_MIN_TILES", 32);
     const bool whole = (row0 == 0 && nxl == pl.nx_total);
     const bool fold2_pays = (long)((4 * my + 31) / 32) * ((pl.fold2_S + 63) / 64) >= fold2_min_tiles;
     const bool fft1 = pl.fft_y.ok, fft2 = pl.fft_x.ok && !pl.pair_list;
+    // Rows of a synthesised field that lie wholly outside the lens circle are zeros, and so are their row transforms:
+    // both FFT stages run on the resident rows [trim_lo, trim_hi) only (7 % fewer of each in a window of the size
+    // good_fft_number hands out, nearfield.py:30-36, 95-97).  Stage 1 neither reads those rows nor writes their part
+    // of G; stage 2 takes them as rows the rank does not hold (FftArgs::a0 / h0: read as zero without a load).
+    // Which rows: the kernels' own inside-the-lens test at the sample nearest y = 0 (row_extent_kernel), on the host's
+    // copies of the axes.
+    int trim_lo = 0, trim_hi = nxl;
+    if (fft1 && fft2 && !mirrored && sh.kind != 2 && ctx->row_first_valid && (int)ctx->h_x_pts.size() == nxl &&
+        (int)ctx->h_y_pts.size() == ny && ctx->r_outer > 0) {
+        if (ctx->trim_key[0] != ctx->grid_serial || ctx->trim_key[1] != ctx->layout_serial) {
+            double ymin = INFINITY;
+            for (double y : ctx->h_y_pts) ymin = std::min(ymin, std::fabs(y));
+            int lo = nxl, hi = 0;
+            for (int i = 0; i < nxl; ++i) {
+                const double x = ctx->h_x_pts[i];
+                if (!(std::sqrt(x * x + ymin * ymin) > ctx->r_outer)) {
+                    lo = std::min(lo, i);
+                    hi = i + 1;
+                }
+            }
+            if (lo >= hi) lo = 0, hi = std::min(nxl, 1);   // (an empty window keeps one row: nothing to gain)
+            ctx->trim_rows[0] = lo;
+            ctx->trim_rows[1] = hi;
+            ctx->trim_key[0] = ctx->grid_serial;
+            ctx->trim_key[1] = ctx->layout_serial;
+        }
+        static const bool no_trim = diag_int("ML_NO_ROW_TRIM", 0) != 0;
+        if (!no_trim) {
+            trim_lo = ctx->trim_rows[0];
+            trim_hi = ctx->trim_rows[1];
+        }
+    }
+    const int nxt = trim_hi - trim_lo;   // rows per field plane the FFT stages work on
+#ifdef ML_DIAG
+    {   // (tools/mode_contexts.py: where this context's buffers lie, once per stage-1 buffer)
+        static const bool print_ptrs = diag_int("ML_PRINT_PTRS", 0) != 0;
+        static const void *seen = nullptr;
+        if (print_ptrs && seen != pl.stage1.p) {
+            seen = pl.stage1.p;
+            fprintf(stderr, "ML_PTRS fields %p stage1 %p vectors %p geo %p\n", (void *)ctx->set_ptr(), pl.stage1.p,
+                    pl.vectors.p, ctx->geo_ix.p);
+        }
+    }
+#endif
     const bool use_fold2 = !fft2 && !pl.pair_list && pl.fold2 && fold2_pays && (mirrored || whole) && sh.kind != 2;
     // both stages folded: stage 1 writes its result already transposed for stage 2
     static const bool no_direct = diag_int("ML_NO_GT_DIRECT", 0) != 0;
@@ -931,61 +989,68 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         fields_premodulated = true;
     }
     const double one[4] = {1.0, 1.0, 1.0, 1.0};
+    // stage 1 as a pruned FFT along y
+    auto launch_fft1 = [&]() -> int {
+        ZfftCall c;
+        const int split1 = pl.fft_y.split;
+        c.passes = pl.fft_y.passes;
+        c.N_eff = pl.fft_y.N_eff / split1;
+        c.n_valid = ny;
+        c.M = my;
+        c.j0 = pl.fft_y.j0;
+        c.jstep = pl.fft_y.jstep;
+        c.pad1 = pl.fft_y.pad1;
+        c.pad2 = pl.fft_y.pad2;
+        // row (f, n1') of the launch = row n1 = trim_lo + n1' of field plane f
+        c.in = ctx->set_ptr() + (size_t)trim_lo * ny * 2;
+        c.rows = 4 * nxt;
+        c.in_rb = nxt;
+        c.in_s1 = (int64_t)nxl * ny;
+        c.in_s2 = ny;
+        c.in_es = 1;
+        c.a0 = 0;
+        c.h0 = ny;
+        c.a1 = c.h1 = 0;
+        c.row_first = ctx->row_first_valid ? ctx->row_first.as<int>() + trim_lo : nullptr;
+        c.rf_mod = nxt;
+        c.out = pl.stage1.as<double>() + (size_t)trim_lo * my * 2;
+        c.out_rb = nxt;
+        c.out_s1 = (int64_t)nxl * my;
+        c.out_s2 = my;
+        c.out_es = 1;
+        if (g_transposed) {   // row (f, n1), bin b -> G[f][b][n1]
+            c.out = pl.stage1.as<double>() + (size_t)trim_lo * 2;
+            c.out_rb = nxt;
+            c.out_s1 = (int64_t)my * g_ld;
+            c.out_s2 = 1;
+            c.out_es = g_ld;
+        }
+        c.tw1 = pl.fft_tw1.as<double>();
+        c.wk = pl.fft_y.wk.as<double>();
+        c.pj = pl.fft_y.pj.as<double>();
+        c.kbin = pl.fft_y.kbin.as<int>();
+        for (int k = 0; k < 4; ++k) c.alpha[k] = 1.0;
+        c.alpha_rb = c.rows;   // (every row: alpha[0])
+        c.accumulate = 0;
+        if (split1 > 1) {
+            // two-level: sub-sequence i of every row adds its bins (zfft.hip zfft_split)
+            for (int i = 0; i < split1; ++i) {
+                c.sub_s = split1;
+                c.sub_i = i;
+                c.pj = pl.fft_y.pj.as<double>() + (size_t)i * my * 2;
+                c.accumulate = i > 0;
+                ML_TRY(zfft_run(ctx->stream, c));
+            }
+        } else {
+            ML_TRY(zfft_run(ctx->stream, c));
+        }
+        return ML_OK;
+    };
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
         if (fft1) {
-            ZfftCall c;
-            const int split1 = pl.fft_y.split;
-            c.passes = pl.fft_y.passes;
-            c.N_eff = pl.fft_y.N_eff / split1;
-            c.n_valid = ny;
-            c.M = my;
-            c.j0 = pl.fft_y.j0;
-            c.jstep = pl.fft_y.jstep;
-            c.pad1 = pl.fft_y.pad1;
-            c.pad2 = pl.fft_y.pad2;
-            c.in = ctx->set_ptr();
-            c.rows = 4 * nxl;
-            c.in_rb = c.rows;
-            c.in_s1 = 0;
-            c.in_s2 = ny;
-            c.in_es = 1;
-            c.a0 = 0;
-            c.h0 = ny;
-            c.a1 = c.h1 = 0;
-            c.row_first = ctx->row_first_valid ? ctx->row_first.as<int>() : nullptr;
-            c.rf_mod = nxl;
-            c.out = pl.stage1.as<double>();
-            c.out_rb = c.rows;
-            c.out_s1 = 0;
-            c.out_s2 = my;
-            c.out_es = 1;
-            if (g_transposed) {   // row (f, n1), bin b -> G[f][b][n1]
-                c.out_rb = nxl;
-                c.out_s1 = (int64_t)my * g_ld;
-                c.out_s2 = 1;
-                c.out_es = g_ld;
-            }
-            c.tw1 = pl.fft_tw1.as<double>();
-            c.wk = pl.fft_y.wk.as<double>();
-            c.pj = pl.fft_y.pj.as<double>();
-            c.kbin = pl.fft_y.kbin.as<int>();
-            for (int k = 0; k < 4; ++k) c.alpha[k] = 1.0;
-            c.alpha_rb = c.rows;
-            c.accumulate = 0;
-            if (split1 > 1) {
-                // two-level: sub-sequence i of every row adds its bins (zfft.hip zfft_split)
-                for (int i = 0; i < split1; ++i) {
-                    c.sub_s = split1;
-                    c.sub_i = i;
-                    c.pj = pl.fft_y.pj.as<double>() + (size_t)i * my * 2;
-                    c.accumulate = i > 0;
-                    ML_TRY(zfft_run(ctx->stream, c));
-                }
-            } else {
-                ML_TRY(zfft_run(ctx->stream, c));
-            }
+            ML_TRY(launch_fft1());
         } else if (pl.fold)
             ML_TRY(zfold_stage1(ctx->stream, 4 * nxl, ny, ctx->set_ptr(), ny,
                                 pl.fold_cm.as<double>(), pl.fold_sm.as<double>(),
@@ -1099,9 +1164,11 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.a1 = pl.nx_total - row0 - nxl / 2;
             c.h1 = nxl / 2;
         } else {
-            c.a0 = row0;
-            c.h0 = nxl;
+            // (resident rows = the rows stage 1 transformed: those outside the lens circle were never written)
+            c.a0 = row0 + trim_lo;
+            c.h0 = nxt;
             c.a1 = c.h1 = 0;
+            c.in = pl.stage1.as<double>() + (size_t)trim_lo * c.in_es * 2;
         }
         c.row_first = nullptr;
         c.rf_mod = 1;

@@ -418,6 +418,21 @@ __device__ unsigned long long g_phase[(size_t)PHASE_SLOTS * PHASE_WAVES];
 // are the ring kernel's where the patch has ring samples (and on its full-grid launch), the centre
 // kernel's otherwise.
 enum { PART_RING = 1, PART_CENTRE = 2 };
+// Wave priority along a ring wave's life.  Among waves of equal priority a SIMD issues the OLDEST first, so a young
+// wave's short instruction runs between its three dependent loads (record -> ring record + rotation -> blocks) queue
+// behind the long vector streams of its elders' order loops.  A ring wave of a single-source listed launch therefore
+// starts at priority 3 and drops to 0 once its round's blocks are requested (ML_PRIO_AT(2, 0)): near field 0.250 ->
+// 0.243 ms at 4096^2, 1.26 -> 1.20 at 8192^2 NA 0.94 (same-box A/B, profiles/r06_ab_runs.txt).  Also measured: high
+// only until the ring record is requested (-1.5 %), high again from the rotation back to the stores (as this), a
+// constant priority per wave slot (nothing).  ML_NF_PRIO = 0: off.
+#ifndef ML_NF_PRIO
+#define ML_NF_PRIO 1
+#endif
+#define ML_PRIO_AT(point, level)                                                                                          \
+    do {                                                                                                                  \
+        if (PART == PART_RING && NP == 1 && LISTED && ML_NF_PRIO == 1 && ((point) == 0 || (point) == 2))                  \
+            __builtin_amdgcn_s_setprio(level);                                                                            \
+    } while (0)
 #ifndef ML_NF_KEEP_ROT
 #define ML_NF_KEEP_ROT 0
 #endif
@@ -426,6 +441,7 @@ template <int NP, int PART, bool LISTED, bool WIDE>
 __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab, double2 *s_tab1, int bx, int by) {
     const int lane = threadIdx.x;
     const unsigned lane_off = (unsigned)lane * 16u;
+    ML_PRIO_AT(0, 3);
     Consts K;
     load_consts(a, K);
     const int i = by * 8 + (lane >> 3);   // x index
@@ -791,6 +807,7 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     ML_MARK(9, blk);     // (ring waves: table cell located, block matching next)
     begin_round(std::integral_constant<bool, !WIDE>());   // the first pass' blocks are on their way during the arithmetic below
     ML_MARK(6, myslot);  // (ring waves: blocks matched, loads issued)
+    ML_PRIO_AT(2, 0);
     OrderShared S;
     double wa[4], wb[4], Hw_x[NP], Hw_y[NP];
     if (peri) {
@@ -1022,7 +1039,10 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
     } else {
         // (resident workgroups walking the lists with the launch's stride - as many as the chip holds at once, to
         // spare the 1.2 us a wave slot stays empty between two 5 us workgroups - measured 25 % SLOWER, 0.302-0.307
-        // against 0.245 ms at 4096^2: DESIGN.md A.1)
+        // against 0.245 ms at 4096^2: DESIGN.md A.1.  Round 6 took the compiler out of that experiment - a wave that,
+        // at the end of its patch, restores the registers a fresh wave arrives with and branches to the kernel's own
+        // entry point: no loop the compiler sees, no spills - and it still lost: two entries per workgroup equal to
+        // noise, 5120 resident workgroups 0.265-0.27 against 0.25.  The empty wave slots are not what the kernel waits for.)
         if (a.n_active[1] > 0)
             hipLaunchKernelGGL((nearfield_ring_kernel<NP, true, false>), dim3(a.n_active[1]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)1 * a.list_stride, a);
