@@ -935,6 +935,12 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
     ML_TRY(grid_axis(ctx->x_pts, ctx->h_x_pts, x_pts, nx));
     ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
+#ifdef ML_DIAG
+    {   // (tools/mode_slab.sh: the field planes and the stage-1 result in ONE allocation, the result ML_SLAB_OFFSET_MB behind the planes)
+        static const int slab_mb = diag_int("ML_SLAB_OFFSET_MB", -1);
+        if (slab_mb >= 0) ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double) + ((size_t)slab_mb << 20) + ((size_t)320 << 20)));
+    }
+#endif
     ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
 #ifdef ML_DIAG
     {   // (tools/mode_moves.py: ... or the field planes'?)

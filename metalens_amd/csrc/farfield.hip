@@ -902,6 +902,17 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     ML_TRY(pl.stage1.reserve(g_transposed ? (size_t)4 * my * g_ld * 2 * sizeof(double)
                                           : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
 #ifdef ML_DIAG
+    {   // (tools/mode_slab.sh: the stage-1 result inside the fields' allocation, ML_SLAB_OFFSET_MB behind the four planes)
+        static const int slab_mb = diag_int("ML_SLAB_OFFSET_MB", -1);
+        const size_t planes = (size_t)4 * nxl * ny * 16, need = (size_t)4 * my * g_ld * 16;
+        if (slab_mb >= 0 && g_transposed && ctx->fields.bytes >= planes + ((size_t)slab_mb << 20) + need) {
+            static void *own = nullptr;
+            if (!own) own = pl.stage1.p;   // (the plan's own allocation stays allocated, unused)
+            pl.stage1.p = (char *)ctx->fields.p + planes + ((size_t)slab_mb << 20);
+        }
+    }
+#endif
+#ifdef ML_DIAG
     {   // (tools/mode_moves.py: does the row transform's 'mode' follow the stage-1 result's placement?)
         static const int move_every = diag_int("ML_MOVE_STAGE1", 0);
         static long calls = 0;
@@ -924,11 +935,12 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // Rows of a synthesised field that lie wholly outside the lens circle are zeros, and so are their row transforms:
     // both FFT stages run on the resident rows [trim_lo, trim_hi) only (7 % fewer of each in a window of the size
     // good_fft_number hands out, nearfield.py:30-36, 95-97).  Stage 1 neither reads those rows nor writes their part
-    // of G; stage 2 takes them as rows the rank does not hold (FftArgs::a0 / h0: read as zero without a load).
+    // of G; stage 2 takes them as rows the rank does not hold (FftArgs::a0 / h0: read as zero without a load; the short
+    // transforms of an interleaved shard likewise, by LOCAL row).
     // Which rows: the kernels' own inside-the-lens test at the sample nearest y = 0 (row_extent_kernel), on the host's
     // copies of the axes.
     int trim_lo = 0, trim_hi = nxl;
-    if (fft1 && fft2 && !mirrored && sh.kind != 2 && ctx->row_first_valid && (int)ctx->h_x_pts.size() == nxl &&
+    if (fft1 && fft2 && !mirrored && ctx->row_first_valid && (int)ctx->h_x_pts.size() == nxl &&
         (int)ctx->h_y_pts.size() == ny && ctx->r_outer > 0) {
         if (ctx->trim_key[0] != ctx->grid_serial || ctx->trim_key[1] != ctx->layout_serial) {
             double ymin = INFINITY;
@@ -1112,8 +1124,9 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.in_s1 = (int64_t)nxl * my;
             c.in_s2 = 1;
             c.in_es = (int64_t)s * my;
-            c.a0 = 0;
-            c.h0 = n_have;
+            // (local rows [a0, a0 + h0) exist in G: stage 1 left out the rows outside the lens circle)
+            c.a0 = trim_lo;
+            c.h0 = nxt;
             c.a1 = c.h1 = 0;
             c.row_first = nullptr;
             c.rf_mod = 1;

@@ -451,7 +451,10 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) {
             const int n = tid + NT * n2, m = n / stuff;   // (stuff is a power of two)
-            v[n2] = (m * stuff == n && m < g.n_valid) ? src[(int64_t)m * a.in_es] : zf::mk(0.0, 0.0);
+            // (sample m of sub-sequence `sub` is local row m s + sub; rows outside [a0, a0 + h0) were never written)
+            const int lrow = m * s + sub;
+            v[n2] = (m * stuff == n && m < g.n_valid && lrow >= a.a0 && lrow < a.a0 + a.h0) ? src[(int64_t)m * a.in_es]
+                                                                                             : zf::mk(0.0, 0.0);
         }
         zf::stage1_inplace(g, tid, v, s_tw, n1, lds);
         __syncthreads();
@@ -477,6 +480,74 @@ __global__ __launch_bounds__(512) void zfft_interleaved_kernel(const FftArgs a, 
     }
 }
 
+// The column pass of an interleaved shard whose short transforms have 128 = 16 x 8 samples - BASELINE configs[2]
+// over 8 ranks: 8192 rows, blocks of 8 rows dealt to 8 ranks - as what it is instead of zero-stuffed to 256: ONE WAVE
+// per column (f, b), lane = (sub-sequence i = lane / 8, t = lane % 8).  Sample m = t + 8 n2 of sub-sequence i, bin
+// k = k2 + 16 k1 of the 128-sample lattice:  W_128^(m k) = W_16^(n2 k2) W_128^(t k2) W_8^(t k1), so
+//   lane (i, t):   A[k2] = DFT16 over its 16 samples n2, times W_128^(t k2)               -> LDS [i][k2][t]
+//   lane (i, t'):  Y_i[k2 + 16 k1] = DFT8 over t of A_t[k2] for its two k2 = t', t' + 8    -> LDS [i][k]
+//   lane l:        the wanted bins o = l, l + 64, ...:  X[o] = sum_i pj[i][o] Y_i[kbin[o] mod 128]
+// (pj carries sub-sequence i's bins to the full lattice as before; kbin is the bin on the STUFFED 256-sample lattice
+// the tables are built for, whose bins are the short lattice's mod 128).  No workgroup barriers (a wave is alone), a
+// sixth of the zero-stuffed form's LDS, 2048 waves instead of 2048 two-wave workgroups at four per CU:
+// 0.040 -> 0.0xx ms per rank at 8 ranks of 8192^2 (tools/shard_probe.py).
+constexpr int C128_PITCH = 9;   // [k2][t] rows of 8 padded to 9: the DFT8 gathers of 16 lanes hit 16 different slots
+__global__ __launch_bounds__(64) void zfft_cols128_kernel(const FftArgs a, int64_t sub_off) {
+    __shared__ cd s_a[8 * 16 * C128_PITCH];   // exchange 1: [i][k2][t]; then Y: [i][k] (8 x 128 <= 8 x 144)
+    __shared__ cd s_tw[8 * 16];               // W_128^(t k2) = W_256^(2 t k2)
+    const int lane = threadIdx.x, i = lane >> 3, t = lane & 7;
+    for (int e = lane; e < 128; e += 64) s_tw[e] = a.tw1[(2 * (e >> 4)) * 16 + (e & 15)];   // e = t * 16 + k2
+    const int M = a.g.M, n_have = a.g.n_valid;
+    const int chunk = (a.rows + 7) / 8, xcd = blockIdx.x & 7, step = gridDim.x >> 3;
+    for (int idx = blockIdx.x >> 3; idx < chunk; idx += step) {
+        const int row = xcd * chunk + idx;   // wave-uniform: the column (f, b)
+        if (row >= a.rows) break;
+        const cd *src = a.in + (row / a.in_rb) * a.in_s1 + (row % a.in_rb) * a.in_s2 + i * sub_off;
+        cd v[16];
+#pragma unroll
+        for (int n2 = 0; n2 < 16; ++n2) {
+            const int m = t + 8 * n2, lrow = 8 * m + i;   // (local row of the sample: rows outside [a0, a0 + h0) were never written)
+            v[n2] = (m < n_have && lrow >= a.a0 && lrow < a.a0 + a.h0) ? src[(int64_t)m * a.in_es] : zf::mk(0.0, 0.0);
+        }
+        zf::dft16(v);
+        __builtin_amdgcn_s_barrier();   // (the previous column's reads of the buffer are done; one wave: no wait)
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            cd x = v[zf::bin16(k2)];
+            if (k2) x = zf::cmul(x, s_tw[t * 16 + k2]);
+            s_a[(i * 16 + k2) * C128_PITCH + t] = x;
+        }
+        __syncthreads();
+        cd y[16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const cd *g8 = s_a + (i * 16 + t + 8 * h) * C128_PITCH;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[8 * h + q] = g8[q];
+            zf::dft8(y + 8 * h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 0; k1 < 8; ++k1) s_a[i * 128 + t + 8 * h + 16 * k1] = y[8 * h + k1];
+        __syncthreads();
+        cd *dst = a.out + (row / a.out_rb) * a.out_s1 + (row % a.out_rb) * a.out_s2;
+        const double al = a.alpha[row / a.alpha_rb];
+        for (int o = lane; o < M; o += 64) {
+            const int k = a.kbin[o] & 127;
+            cd x = zf::mk(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) x = zf::cmac(s_a[q * 128 + k], a.pj[(size_t)q * M + o], x);
+            x.x *= al;
+            x.y *= al;
+            cd *d = dst + o * a.out_es;
+            if (a.accumulate) x = zf::cadd(x, *d);
+            *d = x;
+        }
+    }
+}
+
 int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t sub_off, int stuff) {
     FftArgs a;
     a.g.R3 = c.N_eff / 256;
@@ -492,8 +563,8 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
     a.in_s2 = c.in_s2;
     a.in_es = c.in_es;
     a.in_rb = c.in_rb;
-    a.a0 = 0;
-    a.h0 = c.n_valid;
+    a.a0 = c.a0;       // LOCAL rows that exist in the stage-1 result (interleaved kernels)
+    a.h0 = c.h0;
     a.a1 = a.h1 = 0;
     a.row_first = nullptr;
     a.rf_mod = 1;
@@ -513,6 +584,16 @@ int zfft_run_interleaved(hipStream_t stream, const ZfftCall &c, int s, int64_t s
     a.rows = c.rows;
     a.accumulate = c.accumulate;
     a.chunk = (c.rows + 7) / 8;
+#ifndef ML_NO_COLS128
+    if (stuff == 2 && c.N_eff == 256 && s == 8 && c.n_valid <= 128) {
+        // eight 128-sample transforms per column: one wave each (zfft_cols128_kernel)
+        int grid = std::min(256 * 8, a.chunk * 8);
+        grid = (grid + 7) / 8 * 8;
+        hipLaunchKernelGGL(zfft_cols128_kernel, dim3(grid), dim3(64), 0, stream, a, sub_off);
+        ML_HIP(hipGetLastError());
+        return ML_OK;
+    }
+#endif
     const int threads = 16 * a.g.R3 * s;
     const size_t bytes = ((size_t)s * zf::lds_elems(a.g) + 256) * sizeof(cd);
     ML_REQUIRE(threads <= 512 && bytes <= 160 * 1024, "interleaved column pass: %d transforms of %d points "

@@ -95,6 +95,26 @@ ZF_HD void dft16(cd *v) {
 // register index that holds bin k after dft16
 ZF_HD constexpr int bin16(int k) { return (k >> 2) + 4 * (k & 3); }
 
+// forward 8-point DFT in place, natural order: v[k] <- sum_n v[n] W_8^(n k)   (the column pass of an interleaved
+// row shard whose short transforms have 128 = 16 x 8 samples: zfft.hip zfft_cols128_kernel)
+ZF_HD void dft8(cd *v) {
+    // even / odd halves as 4-point transforms (dft4 returns natural order)
+    cd e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    o1 = mk((o1.x + o1.y) * RH, (o1.y - o1.x) * RH);    // W_8^1 = (1 - i) / sqrt 2
+    o2 = mul_mi(o2);                                    // W_8^2 = -i
+    o3 = mk((o3.y - o3.x) * RH, -(o3.x + o3.y) * RH);   // W_8^3 = (-1 - i) / sqrt 2
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2);
+    v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+}
+
 // ---- geometry of one transform ------------------------------------------------------------
 struct Geo {
     int R3;        // N_eff = 256 R3, threads per workgroup NT = 16 R3

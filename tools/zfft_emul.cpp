@@ -148,6 +148,62 @@ static double run_passes(int R3, int P, int n_valid, int M, int j0) {
     return worst / scale;
 }
 
+// The one-wave column pass of an interleaved shard with 128-sample short transforms (zfft.hip zfft_cols128_kernel):
+// a column of 8 x 128 samples, local row 8 m + i = sample m of sub-sequence i, rank r of G holds the rows
+// n = 8 (G m + r) + i of an aperture of N = 1024 G rows; lane (i, t) runs DFT16 over n2 of its samples m = t + 8 n2,
+// the W_128^(t k2) twiddles, DFT8 over t; the wanted bins are combined with pj[i][o] = W_N^(-(8 r + i - c) k_o).
+static double run_cols128(int G, int r, int M, int j0) {
+    const int N = 1024 * G, c = N - N / 2;
+    std::vector<cd> col(1024);
+    srand(G * 131 + r * 7 + M);
+    for (auto &v : col) v = zf::mk(rand() / (double)RAND_MAX - 0.5, rand() / (double)RAND_MAX - 0.5);
+    std::vector<cd> A(8 * 16 * 8), Y(8 * 128);
+    for (int i = 0; i < 8; ++i)
+        for (int t = 0; t < 8; ++t) {
+            cd v[16];
+            for (int n2 = 0; n2 < 16; ++n2) v[n2] = col[8 * (t + 8 * n2) + i];
+            zf::dft16(v);
+            for (int k2 = 0; k2 < 16; ++k2) {
+                const long double a = -2 * M_PIl * ((2 * t * k2) % 256) / 256;   // the kernel's table: W_256^(2 t k2)
+                cd x = v[zf::bin16(k2)];
+                if (k2) x = zf::cmul(x, zf::mk((double)cosl(a), (double)sinl(a)));
+                A[(i * 16 + k2) * 8 + t] = x;
+            }
+        }
+    for (int i = 0; i < 8; ++i)
+        for (int k2 = 0; k2 < 16; ++k2) {
+            cd y[8];
+            for (int t = 0; t < 8; ++t) y[t] = A[(i * 16 + k2) * 8 + t];
+            zf::dft8(y);
+            for (int k1 = 0; k1 < 8; ++k1) Y[i * 128 + k2 + 16 * k1] = y[k1];
+        }
+    double worst = 0, scale = 0;
+    for (int o = 0; o < M; ++o) {
+        long long kj = ((long long)o + j0) % N;
+        if (kj < 0) kj += N;
+        cd x = zf::mk(0, 0);
+        for (int i = 0; i < 8; ++i) {
+            long long m = ((long long)(c - 8 * r - i) * kj) % N;
+            if (m < 0) m += N;
+            const long double a = 2 * M_PIl * m / N;
+            x = zf::cmac(Y[i * 128 + (int)(kj % 128)], zf::mk((double)cosl(a), (double)sinl(a)), x);
+        }
+        long double re = 0, im = 0;
+        for (int l = 0; l < 1024; ++l) {   // local row l = 8 m + i is row n = 8 (G m + r) + i of the aperture
+            const long long n = 8ll * (G * (l / 8) + r) + l % 8;
+            long long q = ((n - c) * kj) % N;
+            if (q < 0) q += N;
+            const long double a = -2 * M_PIl * q / N;
+            re += col[l].x * cosl(a) - col[l].y * sinl(a);
+            im += col[l].x * sinl(a) + col[l].y * cosl(a);
+        }
+        worst = fmax(worst, fmax(fabs((double)(re - x.x)), fabs((double)(im - x.y))));
+        scale = fmax(scale, fmax(fabsl(re), fabsl(im)));
+    }
+    printf("cols128: G=%d rank=%d N=%5d M=%4d j0=%5d err=%.2e\n", G, r, N, M, j0, worst / scale);
+    return worst / scale;
+}
+
 int main() {
     double worst = 0;
     const int cases[][4] = {{16, 4096, 512, -256}, {8, 2048, 256, -128}, {32, 8192, 512, -256},
@@ -164,6 +220,9 @@ int main() {
     const int pcases[][5] = {{16, 2, 4096, 512, -256}, {32, 2, 8192, 512, -256}, {8, 2, 2048, 256, -128},
                              {16, 4, 4000, 512, -256}, {32, 4, 8192, 300, 4000}, {12, 2, 3072, 100, -50}};
     for (auto &c : pcases) worst = fmax(worst, run_passes(c[0], c[1], c[2], c[3], c[4]));
+    worst = fmax(worst, run_cols128(8, 0, 512, -256));
+    worst = fmax(worst, run_cols128(8, 5, 512, -256));
+    worst = fmax(worst, run_cols128(8, 7, 300, 7000));
     printf("worst relative error %.3e -> %s\n", worst, worst < 1e-13 ? "OK" : "FAIL");
     return worst < 1e-13 ? 0 : 1;
 }
