@@ -390,11 +390,16 @@ int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violatio
  *   *family           1: every table in use holds orders (ox, 0), |ox| <= 5 only - what characterize()
  *                        emits for a round lens (grating.lua:417-423) - and the kernels that build an
  *                        order's phasor as E0 X^ox run, each grating collection over its OWN order list;
- *                     0: some table holds an order with oy != 0 (or |ox| > 5): the general kernels,
- *                        which evaluate every order's phase argument on its own
- *   *ring_orders_max  family 1: order slots of the widest ring collection - its lowest to its highest
+ *                     0: NO table is of that kind (an order with oy != 0 or |ox| > 5 in each): the general
+ *                        kernel, which evaluates every order's phase argument on its own
+ *                     2: MIXED - the decision is per table: the samples of the ring collections (and of the
+ *                        centre table) whose order sets are simple take the kernels of family 1, the others the
+ *                        general kernel, each from the list of the patches that hold its samples
+ *                        (characterize() searches (ox, oy) in [-5, 5]^2, grating.lua:406-423: one collection with
+ *                        an order (ox, +-1) costs its own samples the general kernel, not the whole lens)
+ *   *ring_orders_max  family 1, 2: order slots of the widest SIMPLE ring collection - its lowest to its highest
  *                     order, a hole in the list counted (0 for family 0)
- *   *centre_orders    family 1: order slots of the centre table
+ *   *centre_orders    family 1, 2: order slots of the centre table (0: it is a general one)
  * Any pointer may be NULL.                                                                       */
 int ml_nearfield_kernel_info(ml_ctx *ctx, int *family, int *ring_orders_max, int *centre_orders);
 

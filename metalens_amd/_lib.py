@@ -315,13 +315,14 @@ class Context:
 
     def nearfield_kernels(self):
         """which synthesis kernels the last synthesis took: {'family': 'orders-along-x' (every table holds
-        orders (ox, 0), |ox| <= 5: per-collection order lists, phasors by products) or 'general',
+        orders (ox, 0), |ox| <= 5: per-collection order lists, phasors by products), 'general', or 'mixed' (decided
+        per table: the samples of simple tables as the former, of the others through the general kernel),
         'ring_orders_max', 'centre_orders'}"""
         fam, ring, cen = c_int(0), c_int(0), c_int(0)
         if not hasattr(self.lib, 'ml_nearfield_kernel_info'):   # (A/B runs against an older build)
             return {'family': 'unknown', 'ring_orders_max': None, 'centre_orders': None}
         check(self.lib.ml_nearfield_kernel_info(self.handle, byref(fam), byref(ring), byref(cen)))
-        return {'family': 'orders-along-x' if fam.value else 'general', 'ring_orders_max': ring.value,
+        return {'family': ('general', 'orders-along-x', 'mixed')[fam.value], 'ring_orders_max': ring.value,
                 'centre_orders': cen.value}
 
     def profile(self, on=True, kernels=None, every=1):

@@ -285,7 +285,9 @@ struct ml_ctx {
     ml::DevBuf table_desc;   // TableDesc[MAX_SLOTS + 1], last = centre
     ml::TableDesc h_center_desc;   // the centre entry again: it travels in the kernel arguments
     bool tables_dirty = true;
-    bool simple_orders = false;   // every table in use: orders (ox, 0), |ox| <= 5 only (refresh_ring_locations)
+    bool simple_orders = false;   // SOME table in use holds orders (ox, 0), |ox| <= 5 only: its samples take nearfield_simple.hip (refresh_ring_locations)
+    // ... and the others the general kernel: bit c = dense ring collection c is general; the centre table likewise
+    int general_mask = 0, centre_general = 0, narrow_mask = 0;
     int wide_mask = 0, narrow_exists = 0, narrow_slots_max = 1;   // simple order sets: NfArgs::wide_mask / narrow_exists; orders of the widest narrow collection
     double ring_bounds_all[4] = {0, 0, 0, 0};   // intersection of the ring tables' (ux', uy') bounds (NfArgs)
 

@@ -196,51 +196,83 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         }
         return true;
     };
+    // PER TABLE: the collections (and the centre table) whose order sets are simple take the kernels of
+    // nearfield_simple.hip, the others - an order with oy != 0 (grating.lua:406-423 searches (ox, oy) in [-5, 5]^2), a
+    // list that is not ascending - the general kernel of nearfield_fast.hip, each over the patches that hold its
+    // samples: one table with an order (ox, +-1) no longer sends the whole lens through the general kernel.
     Canon canon[MAX_RING_COLLS], canon_center;
-    bool simple = true;
-    for (int c = 0; c < ctx->n_colls; ++c) simple = canon_orders(ctx->slots[ctx->coll_slot[c]], canon[c]) && simple;
-    if (ctx->center.present) simple = canon_orders(ctx->center, canon_center) && simple;
+    bool simple_c[MAX_RING_COLLS] = {}, centre_simple = false, simple = false;
     // (diagnostic build only: ML_FORCE_GENERAL=1 sends a lens that qualifies through the general kernels - what
-    // the order-list kernels are measured against)
+    // the order-list kernels are measured against; ML_FORCE_GENERAL_COLL = mask of dense collection
+    // numbers, bit 16 = the centre table: those only)
     static const bool force_general = diag_int("ML_FORCE_GENERAL", 0) != 0;
-    if (force_general) simple = false;
-    if (simple != ctx->simple_orders) {
-        // which patch lists exist and what a synthesis leaves behind depend on the kernel family
+    static const int force_general_coll = diag_int("ML_FORCE_GENERAL_COLL", 0);
+    int general_mask = 0;
+    for (int c = 0; c < ctx->n_colls; ++c) {
+        simple_c[c] = canon_orders(ctx->slots[ctx->coll_slot[c]], canon[c]) && !force_general && !((force_general_coll >> c) & 1);
+        simple = simple || simple_c[c];
+        if (!simple_c[c]) general_mask |= 1 << c;
+    }
+    if (ctx->center.present) {
+        centre_simple = canon_orders(ctx->center, canon_center) && !force_general && !((force_general_coll >> 16) & 1);
+        simple = simple || centre_simple;
+    }
+    const int centre_general = ctx->center.present && !centre_simple ? 1 : 0;
+    if (!simple) general_mask = 0;   // (the general kernel alone: nothing to tell apart)
+    if (simple != ctx->simple_orders || general_mask != ctx->general_mask || (simple && centre_general != ctx->centre_general)) {
+        // which patch lists exist and what a synthesis leaves behind depend on who takes which samples
         ctx->geo_key[0] = -1;
         ctx->n_active[0] = -1;
         ctx->zero_key[1] = -1;
     }
     ctx->simple_orders = simple;
+    ctx->general_mask = general_mask;
+    ctx->centre_general = simple ? centre_general : 0;
     // which ring collections go to the wide instantiation of the ring kernel (nearfield_simple.hip): part of
     // what the patch lists were built for (nearfield.hip geo_key)
-    ctx->wide_mask = ctx->narrow_exists = 0;
+    ctx->wide_mask = ctx->narrow_exists = ctx->narrow_mask = 0;
     ctx->narrow_slots_max = 1;
-    for (int c = 0; simple && c < ctx->n_colls; ++c) {
+    for (int c = 0; c < ctx->n_colls; ++c) {
+        if (!simple_c[c]) continue;
         if (canon[c].n > SIMPLE_NARROW_SLOTS) {
             ctx->wide_mask |= 1 << c;
         } else {
             ctx->narrow_exists = 1;
+            ctx->narrow_mask |= 1 << c;
             ctx->narrow_slots_max = std::max(ctx->narrow_slots_max, canon[c].n);
         }
     }
     int dense_of[MAX_SLOTS];
     for (int c = 0; c < ctx->n_colls; ++c) dense_of[ctx->coll_slot[c]] = c;
+    // One array, every ring's table in the form of the kernel that takes its collection: cell blocks, addressed in
+    // UNITS of 16 complex, or [order][n0][n1][4], addressed by the element.  `at` counts complex elements.
     std::vector<long long> tab_off(ctx->n_rings);
     std::vector<int32_t> ok_off(ctx->n_rings);
-    size_t tab_total = 0, ok_total = 0;
+    std::vector<char> ring_simple(ctx->n_rings, 0);
+    size_t at = 0, ok_total = 0, simple_units_end = 0;
     for (int r = 0; r < ctx->n_rings; ++r) {
         const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
-        tab_off[r] = (long long)tab_total;
+        const int c = dense_of[ctx->h_ring_gc[r]];
+        ring_simple[r] = simple_c[c];
         ok_off[r] = (int32_t)ok_total;
-        tab_total += simple ? (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0) * canon[dense_of[ctx->h_ring_gc[r]]].n
-                            : (size_t)t.n_orders * t.n0 * t.n1 * 4;
+        if (simple_c[c]) {
+            at = (at + UNIT - 1) / UNIT * UNIT;
+            tab_off[r] = (long long)(at / UNIT);
+            at += (size_t)std::max(t.n0 - 1, 0) * std::max(t.n1 - 1, 0) * canon[c].n * UNIT;
+            simple_units_end = at / UNIT;
+        } else {
+            tab_off[r] = (long long)at;
+            at += (size_t)t.n_orders * t.n0 * t.n1 * 4;
+        }
         ok_total += (size_t)t.n_orders * 4;
     }
+    const size_t tab_total = at;
     // (nearfield_simple.hip: a sample's block = the ring's first unit + its cell, a 31-bit key - `blk`, -1 = none -
     // and the cell itself a 24-bit product (i0 (n1 - 1) + i1) n_slots: v_mad_u32_u24 / v_mul_u32_u24)
     if (simple) {
-        ML_REQUIRE(tab_total + SIMPLE_MAX_SLOTS + 1 < (1ull << 31), "ring tables of %zu block units: too large", tab_total);
+        ML_REQUIRE(simple_units_end + SIMPLE_MAX_SLOTS + 1 < (1ull << 31), "ring tables of %zu block units: too large", simple_units_end);
         for (int c = 0; c < ctx->n_colls; ++c) {
+            if (!simple_c[c]) continue;
             const TableSlot &t = ctx->slots[ctx->coll_slot[c]];
             ML_REQUIRE((long long)std::max(t.n0 - 1, 1) * std::max(t.n1 - 1, 1) * canon[c].n < (1ll << 24) && t.n0 < (1 << 12) &&
                            t.n1 < (1 << 12),
@@ -250,11 +282,12 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     }
     // (simple: a wave that straddles two collections stages every block at the larger one's size -
     // the tail of the array is padded by a largest block so that the surplus stays inside it)
-    std::vector<double> tab((tab_total + (simple ? SIMPLE_MAX_SLOTS + 1 : 0)) * 2 * (simple ? UNIT : 1), 0.0), ok(ok_total);
+    std::vector<double> tab((tab_total + (simple ? (size_t)(SIMPLE_MAX_SLOTS + 1) * UNIT : 0)) * 2, 0.0), ok(ok_total);
     for (int r = 0; r < ctx->n_rings; ++r) {
         const TableSlot &t = ctx->slots[ctx->h_ring_gc[r]];
         const double w1 = t2[r], w0 = 1 - t2[r];
-        if (simple) {
+        const bool rs = ring_simple[r];
+        if (rs) {
             const Canon &L = canon[dense_of[ctx->h_ring_gc[r]]];
             double *dst = tab.data() + (size_t)tab_off[r] * UNIT * 2;
             for (int c0 = 0; c0 < t.n0 - 1; ++c0)
@@ -274,7 +307,7 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         }
         double *dst = tab.data() + (size_t)tab_off[r] * 2;
         for (int o = 0; o < t.n_orders; ++o) {
-            for (int a = 0; !simple && a < t.n0 * t.n1; ++a) {
+            for (int a = 0; !rs && a < t.n0 * t.n1; ++a) {
                 const double *lo = t.h_values.data() +
                                    ((((size_t)o * t.n0 * t.n1 + a) * t.n2 + i2[r]) * 4) * 2;
                 const double *hi = lo + 8;
@@ -305,9 +338,9 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         C.flags = d.uniform ? 1 : 0;
         C.lim0 = t.n0 - 2;
         C.lim1 = t.n1 - 2;
-        C.n_slots = simple ? canon[c].n : 0;
-        C.ox_lo = simple ? canon[c].lo : 0;
-        C.present = simple ? canon[c].present : 0;
+        C.n_slots = simple_c[c] ? canon[c].n : 0;
+        C.ox_lo = simple_c[c] ? canon[c].lo : 0;
+        C.present = simple_c[c] ? canon[c].present : 0;
         C.pad = 0;
         for (int k = 0; k < 4; k += 2) {   // a NaN bound leaves the range empty: every sample then reads its own
             ctx->ring_bounds_all[k] = t.bounds[k] >= ctx->ring_bounds_all[k] ? t.bounds[k]
@@ -327,7 +360,7 @@ static int refresh_ring_locations(ml_ctx *ctx) {
         // the ring's period outside its table's period range: every evaluated sample of the ring
         // reports (nearfield.py:302-305)
         if (ctx->h_ring_period[r] < t.bounds[4] || ctx->h_ring_period[r] > t.bounds[5])
-            bits |= 1ll << (simple ? 32 : 40);
+            bits |= 1ll << (ring_simple[r] ? 32 : 40);
         memcpy(q + 3, &bits, 8);
     }
     ML_TRY(h2d(ctx, ctx->ring_rec, rec.data(), rec.size() * sizeof(double)));
@@ -342,7 +375,7 @@ static int refresh_ring_locations(ml_ctx *ctx) {
     // complex its samples interpolate from, contiguous (a hole in the list: zeros).
     std::vector<double> cq;
     ctx->center_n_slots = ctx->center_lo = ctx->center_present_mask = 0;
-    if (ctx->center.present && simple) {
+    if (ctx->center.present && centre_simple) {
         const TableSlot &t = ctx->center;
         const Canon &L = canon_center;
         ctx->center_n_slots = L.n;
@@ -1136,7 +1169,7 @@ int ml_nearfield_kernel_info(ml_ctx *ctx, int *family, int *ring_orders_max, int
     }
     int widest = 0;
     for (int c = 0; c < ctx->n_colls; ++c) widest = std::max(widest, ctx->h_coll[c].n_slots);
-    if (family) *family = ctx->simple_orders ? 1 : 0;
+    if (family) *family = ctx->simple_orders ? ((ctx->general_mask || ctx->centre_general) ? 2 : 1) : 0;
     if (ring_orders_max) *ring_orders_max = ctx->simple_orders ? widest : 0;
     if (centre_orders) *centre_orders = ctx->simple_orders ? ctx->center_n_slots : 0;
     return ML_OK;

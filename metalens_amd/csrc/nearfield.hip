@@ -187,6 +187,9 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
     a.simple_orders = ctx->simple_orders ? 1 : 0;
     a.wide_mask = ctx->wide_mask;
     a.narrow_exists = ctx->narrow_exists;
+    a.general_mask = ctx->general_mask;
+    a.narrow_mask = ctx->narrow_mask;
+    a.centre_general = ctx->centre_general;
     a.narrow_pitch = UNIT * ctx->narrow_slots_max + 1;
     // (eight blocks of up to three orders or six of four: nearfield_simple.hip RING_LDS_NARROW)
     a.narrow_cap = std::min(8, (8 * (3 * UNIT + 1)) / a.narrow_pitch);
@@ -225,7 +228,7 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
     // of them changes (the samples the kernel cannot settle are counted from zero each time)
     // (... and, for the lists, on which collections are the wide ring instantiation's)
     const long geo_key[5] = {ctx->grid_serial, ctx->layout_serial, ctx->ovr_serial, (long)nx * ny,
-                             ctx->simple_orders ? (long)ctx->wide_mask : -2};
+                             ctx->simple_orders ? (long)ctx->wide_mask | (long)ctx->general_mask << 20 | (long)ctx->centre_general << 40 : -2};
     if (plan_cache_disabled() || memcmp(geo_key, ctx->geo_key, sizeof geo_key) != 0) {
         ProfScope scope(ctx, ML_K_TWIDDLE);
         ML_HIP(hipMemsetAsync(ctx->tie_count.p, 0, sizeof(int), ctx->stream));
@@ -255,7 +258,10 @@ int nearfield_launch(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, i
         // numbers come back from the GPU once per geometry (three 4-byte copies, one synchronisation);
         // the power partials of the others stay at the zeros written here.
         if (ctx->n_active[0] < 0) {
-            const int lo = ctx->simple_orders ? 1 : 0, hi = ctx->simple_orders ? 3 : 0;
+            // (list 0: the general kernel's - every lens patch of a lens without simple tables, the patches with samples of
+            // general tables of a mixed one)
+            const bool mixed = ctx->simple_orders && (ctx->general_mask || ctx->centre_general);
+            const int lo = ctx->simple_orders && !mixed ? 1 : 0, hi = ctx->simple_orders ? 3 : 0;
             for (int k = 0; k < 4; ++k) ctx->n_active[k] = 0;
             if (ctx->counts_queued) {
                 // (queued with the geometry, an earlier call: normally long there - no draining of the stream)

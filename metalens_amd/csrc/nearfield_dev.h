@@ -109,6 +109,11 @@ struct NfArgs {
     // simple order sets: bit c = dense collection c holds more than SIMPLE_NARROW_SLOTS orders (its samples are
     // the wide ring instantiation's); narrow_exists: some collection does not
     int wide_mask, narrow_exists;
+    int narrow_mask;   // bit c = dense collection c is the narrow instantiation's (simple, at most SIMPLE_NARROW_SLOTS orders)
+    // simple_orders and SOME tables are not simple: bit c = the ring samples of dense collection c are the general
+    // kernel's (nearfield_fast.hip nearfield_field_kernel), centre_general: so are the centre samples; the general kernel
+    // then runs from list 0 = the patches that hold such samples (flag bit 4 of the geometry kernel)
+    int general_mask, centre_general;
     int narrow_pitch, narrow_cap;   // narrow ring instantiation: complex between staged blocks (16 x its widest collection's orders + 1), blocks per round
     int center_n_slots, center_lo, center_present;   // centre table, simple order sets: as CollDesc::n_slots / ox_lo / present
     // the (ux', uy') range every ring table covers (intersection of their bounds: lo0, hi0, lo1, hi1);
@@ -465,6 +470,7 @@ void fill_nf_args(ml_ctx *ctx, const ml_nearfield_params *p, int n, int nx, int 
 int nearfield_fast_launch(ml_ctx *ctx, const NfArgs &a, int *n_partials);
 // nearfield_simple.hip: the kernels of a round lens' order sets (orders (ox, 0), |ox| <= 5, per collection)
 int nearfield_simple_launch(ml_ctx *ctx, const NfArgs &a);
+int nearfield_general_listed_launch(ml_ctx *ctx, const NfArgs &a, int grid);   // nearfield_fast.hip: list 0 of a mixed lens
 // the source-independent records of the current (grid, layout, tie answers)
 int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a);
 

@@ -293,13 +293,19 @@ __global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs 
     // collection - compacted into lists by active_compact_kernel (190 k
     // waves adding to ONE counter took 2 ms)
     // (ring samples by the instantiation of nearfield_simple.hip that takes their collection: NfArgs::wide_mask)
+    // (bit 4: any sample of a table that is NOT simple while others are - the general kernel's patches of a mixed
+    // lens, NfArgs::general_mask / centre_general; such samples count for neither ring instantiation nor the centre kernel)
     const bool ring = idx >= 1 && idx <= a.n_rings;
-    const bool wide = ring && ((a.wide_mask >> a.ring_coll[min(max(idx, 1), a.n_rings) - 1]) & 1);
+    const int coll = a.ring_coll[min(max(idx, 1), a.n_rings) - 1];
+    const bool gen = a.simple_orders && ((ring && ((a.general_mask >> coll) & 1)) || (idx == 0 && a.centre_general));
+    const bool wide = ring && !gen && ((a.wide_mask >> coll) & 1);
     const int any_ring = __any(ring), any_centre = __any(idx == 0);   // all lanes vote
-    const int any_narrow = __any(ring && !wide), any_wide = __any(wide);
+    const int any_narrow = __any(ring && !wide && !gen), any_wide = __any(wide), any_gen = __any(gen);
+    const int any_simple_centre = __any(idx == 0 && !gen);
     if (lane == 0)
         a.active_flag[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
-            ((any_ring | any_centre) ? 1 : 0) | (any_narrow ? 2 : 0) | (any_centre ? 4 : 0) | (any_wide ? 8 : 0);
+            ((any_ring | any_centre) ? 1 : 0) | (any_narrow ? 2 : 0) | (any_simple_centre ? 4 : 0) | (any_wide ? 8 : 0) |
+            (any_gen ? 16 : 0);
 }
 
 // flags -> list of (bx, by) of the patches whose flags meet `mask`, in patch order.  Two small
@@ -396,10 +402,15 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
     // list of patches that hold lens samples
     int bx = blockIdx.x, by = blockIdx.y;
     if (a.use_active) {
+        // (first pass of a mixed lens: the launch covers every patch number, the list's length is on the device)
+        if (a.list_count && (int)blockIdx.x >= *a.list_count) return;
         const int2 pb = a.active_list[blockIdx.x];
         bx = pb.x;
         by = pb.y;
     }
+    // a MIXED lens (some tables simple, some not: NfArgs::general_mask / centre_general): this kernel takes the
+    // samples of the general tables only, from the list of the patches that hold any
+    const bool mixed = a.simple_orders && (a.general_mask || a.centre_general);
     const int i = by * 8 + (lane >> 3);                       // x index
     const int j = bx * 8 + (lane & 7);                        // y index (fastest in memory)
     const bool inb = j < a.ny && i < a.nx;
@@ -450,7 +461,13 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
     const int cell_type = idx >> REC_TYPE_SHIFT;   // (ring samples: the collection)
     idx &= (1 << REC_TYPE_SHIFT) - 1;
     const bool lens = idx <= a.n_rings;
-    const bool peri = lens && idx >= 1;
+    const bool peri_any = lens && idx >= 1;
+    const bool peri = peri_any && (!mixed || ((a.general_mask >> cell_type) & 1));   // a ring sample of THIS kernel's
+    const bool centre_here = !mixed || a.centre_general;                            // the centre samples are this kernel's
+    // who sums a patch's incident power (and, on its full-grid launch, stores the zeros outside the lens): of a mixed
+    // lens the ring instantiations of nearfield_simple.hip where the patch has ring samples of a simple collection,
+    // this kernel otherwise (the simple centre kernel only where there is no ring sample at all)
+    const bool own = !mixed || !a.use_active || (!a.first_pass && !__ballot(peri_any && !peri));   // wave-uniform
     // what the order loop of a periphery sample needs (everything else is re-read afterwards:
     // registers are what limits this kernel to four waves per SIMD)
     // (set and read by ring samples only - lanes with key >= 0 - and deliberately left without initial
@@ -466,10 +483,12 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
     c2 E0;
     {
         const double x = x_ld, y = y_ld;
+        if (own) {
 #pragma unroll
-        for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
+            for (int m = 0; m < NP; ++m) wave_power(a, lens ? power_in[m] : 0.0, bx, by, m);
+        }
 
-        if (__ballot(lens && !peri)) {   // wave-uniform: some lane is a centre sample
+        if (centre_here && __ballot(lens && !peri_any)) {   // wave-uniform: some lane is a centre sample
             // ================= centre: the record holds the nearest hexagonal cell =================
             // The lanes of a patch sit in ~50 cells of up to K types, and (the direction of incidence
             // hardly changes over 2 um) almost always in ONE (ux, uy) cell of the centre table.  Per
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
             // bounded a centre wave (phase timers: 5 000 cycles per order against 1 600 for a
             // periphery order).  A round serves the lanes of one (table cell, group of CENTER_TYPES
             // types); a wave that straddles a table cell, or a table of more types, takes more rounds.
-            const bool cen = lens && !peri && aux >= 0;
+            const bool cen = lens && !peri_any && aux >= 0;
             Acc acc[NP];
 #pragma unroll
             for (int m = 0; m < NP; ++m) acc[m] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
@@ -569,13 +588,13 @@ __global__ __launch_bounds__(64, NP == 1 ? ML_NF_WAVES : 3) void nearfield_field
                     }
                 }
             }
-            if (lens && !peri) {
+            if (lens && !peri_any) {
 #pragma unroll
                 for (int m = 0; m < NP; ++m)
                     store_fields(a, m, i, j, acc[m].Ex, acc[m].Ey, acc[m].Hx, acc[m].Hy);
             }
         }
-        if (inb && !lens && !a.outside_is_zero) {
+        if (inb && !lens && !a.outside_is_zero && own) {
             const c2 zero = {0.0, 0.0};
 #pragma unroll
             for (int m = 0; m < NP; ++m) store_fields(a, m, i, j, zero, zero, zero, zero);
@@ -797,19 +816,36 @@ int nearfield_geometry_launch(ml_ctx *ctx, const NfArgs &a) {
     // (all the lists of the lens in ONE launch of each of the two kernels: blockIdx.y = list.  A list nobody
     // launches from - narrow ring patches of a lens without narrow collections, wide ones of a lens without
     // wide collections - gets the mask 0: nothing listed, count 0)
+    const bool mixed = a.simple_orders && (a.general_mask || a.centre_general);
     CompactLists L;
-    L.first = a.simple_orders ? 1 : 0;
-    L.n = a.simple_orders ? 3 : 1;
+    L.first = a.simple_orders && !mixed ? 1 : 0;
+    L.n = mixed ? 4 : a.simple_orders ? 3 : 1;
     for (int y = 0; y < 4; ++y) L.mask[y] = 0;
     for (int y = 0; y < L.n; ++y) {
         const int k = L.first + y;
         L.mask[y] = ((k == 1 && !a.narrow_exists) || (k == 3 && !a.wide_mask)) ? 0 : 1 << k;
+        if (k == 0 && mixed) L.mask[y] = 16;   // (list 0 of a mixed lens: the patches with samples of general tables)
+        if (k == 2 && a.simple_orders && a.centre_general) L.mask[y] = 0;   // (no centre kernel: the centre table is general)
     }
     hipLaunchKernelGGL(active_count_kernel, dim3(chunks, L.n), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag, L, n_patches,
                        a.active_count, a.count_stride);
     ML_HIP(hipGetLastError());
     hipLaunchKernelGGL(active_compact_kernel, dim3(chunks, L.n), dim3(COMPACT_CHUNK), 0, ctx->stream, a.active_flag, L,
                        n_patches, (int)grid.x, a.active_list, a.list_stride, a.active_count, a.count_stride);
+    ML_HIP(hipGetLastError());
+    return ML_OK;
+}
+
+// the general kernel over list 0 of a MIXED lens (nearfield_simple.hip launch_parts): the samples of the tables whose
+// order sets are not simple; a.use_active = 1, a.list_count set on the first pass (the list's length is on the device)
+int nearfield_general_listed_launch(ml_ctx *ctx, const NfArgs &a, int grid) {
+    if (grid <= 0) return ML_OK;
+    if (a.n_pol == 1)
+        hipLaunchKernelGGL((nearfield_field_kernel<1>), dim3(grid), dim3(64), 0, ctx->stream, a);
+    else if (a.n_pol == 2)
+        hipLaunchKernelGGL((nearfield_field_kernel<2>), dim3(grid), dim3(64), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((nearfield_field_kernel<3>), dim3(grid), dim3(64), 0, ctx->stream, a);
     ML_HIP(hipGetLastError());
     return ML_OK;
 }

@@ -509,13 +509,17 @@ __device__ __forceinline__ void synthesize_patch(const NfArgs &a, double2 *s_tab
     // order count (NfArgs::wide_mask: bit per dense collection number), each launched over the patches
     // that hold samples of its collections - a patch on the border between a narrow and a wide collection
     // is visited by both, each storing its own samples
-    const bool peri = PART == PART_RING ? peri_any && (((a.wide_mask >> cell_type) & 1) != 0) == WIDE : peri_any;
+    // (of a MIXED lens - NfArgs::general_mask: some collections' order sets are not simple - the ring samples of those
+    // collections are neither instantiation's: the general kernel of nearfield_fast.hip takes them from its own list)
+    // (hence ONE mask per instantiation: the collections that are its own)
+    const bool peri = PART == PART_RING ? peri_any && (((WIDE ? a.wide_mask : a.narrow_mask) >> cell_type) & 1) != 0 : peri_any;
     // who sums the patch's incident power and stores its zeros: see above
     // (the full-grid launch - the first synthesis into a buffer - visits every patch with the ring kernel)
     // (ring samples of a narrow collection: the narrow instantiation's patch; else of a wide one: the wide
     // instantiation's; else the centre kernel's.  On the first synthesis into a buffer one ring instantiation
     // - the narrow one if the lens has narrow collections - runs over the whole grid and does it for every patch)
-    const bool mine_too = PART == PART_RING ? (!WIDE || !a.narrow_exists || (LISTED && !a.first_pass && !__ballot(peri_any && !peri)))
+    // (mixed lens: ... else the general kernel's where it has samples of a general table, else the centre kernel's)
+    const bool mine_too = PART == PART_RING ? (!WIDE || !a.narrow_exists || (LISTED && !a.first_pass && !__ballot(peri_any && ((a.narrow_mask >> cell_type) & 1))))
                                             : (LISTED && !a.first_pass && !__ballot(peri_any));   // wave-uniform
     if (mine_too) {
 #pragma unroll
@@ -1033,9 +1037,16 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
         // launch over ALL patch numbers cost 48 us at 4096^2, 262 144 of them)
         c.list_count = a.active_count + (size_t)2 * a.count_stride;
         const int centre_grid = std::min<long>((long)full.x * full.y, a.centre_patch_bound);
-        if (centre_grid > 0)
+        if (centre_grid > 0 && !a.centre_general)
             hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(centre_grid), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)2 * a.list_stride, c);
+        // a mixed lens: the samples of the tables that are not simple, from list 0 (the same trick: every patch
+        // number, the surplus workgroups leave at once)
+        if (a.general_mask || a.centre_general) {
+            c.list_count = a.active_count;
+            c.use_active = 1;
+            ML_TRY(nearfield_general_listed_launch(ctx, c, (int)(full.x * full.y)));
+        }
     } else {
         // (resident workgroups walking the lists with the launch's stride - as many as the chip holds at once, to
         // spare the 1.2 us a wave slot stays empty between two 5 us workgroups - measured 25 % SLOWER, 0.302-0.307
@@ -1052,6 +1063,8 @@ static int launch_parts(ml_ctx *ctx, const NfArgs &a) {
         if (a.n_active[2] > 0)
             hipLaunchKernelGGL((nearfield_centre_kernel<NP, true>), dim3(a.n_active[2]), dim3(64), 0, ctx->stream,
                                a.active_list + (size_t)2 * a.list_stride, a);
+        if ((a.general_mask || a.centre_general) && a.n_active[0] > 0)
+            ML_TRY(nearfield_general_listed_launch(ctx, a, a.n_active[0]));
     }
     ML_HIP(hipGetLastError());
     return ML_OK;

@@ -259,6 +259,8 @@ def test_two_gpus_real_rccl(tmp_path):
             assert q.returncode == 0, e[-2000:]
         line = json.loads([l for l in outs[0][0].splitlines() if l.strip()][-1])
         assert line['n_gpus'] == 2
+        # what RCCL itself says it connected (ncclCommCount), not what the launcher asked for
+        assert line['multi_gpu']['backend'] == 'rccl' and line['multi_gpu']['ranks_reported_by_backend'] == 2, line['multi_gpu']
         a, b = np.load(one), np.load(two)
         for key in ('a_theta', 'a_phi'):
             assert np.abs(a[key] - b[key]).max() <= 1e-13 * np.abs(a[key]).max(), (reduce, key)
