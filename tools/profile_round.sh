@@ -14,7 +14,7 @@ mkdir -p $O
 T="timeout -k 5 ${PMC_TIMEOUT:-240}"
 cd /tmp && export TMPDIR=/tmp
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --cpu-rows 0 --cpu-fft-side 0 > $O/stats.log 2>&1
-pmc() {   # pmc NAME <bench args>: the counter passes of one configuration
+pmc() {   # KEY=<config.pmc_key> pmc NAME <bench args>: the counter passes of one configuration
   name=$1; shift
   SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 --also-physical 0 $@"
   $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$name/fetch -- $SHORT > $O/$name.fetch.log 2>&1
@@ -22,14 +22,20 @@ pmc() {   # pmc NAME <bench args>: the counter passes of one configuration
   $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$name/sq -- $SHORT > $O/$name.sq.log 2>&1
   # the instruction mix of the synthesis kernels (per-wave figures of DESIGN 4.1)
   $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVES --kernel-trace --output-format csv -d $O/$name/insts -- $SHORT > $O/$name.insts.log 2>&1
+  # digested ON THE BOX into the counter table bench.py reads (key = bench.py's config.pmc_key), so that the bench lines
+  # below carry the counters of the kernels they ran; a copy of the table goes home in $O
+  (cd $R && python tools/pmc_table.py "$KEY" $O/$name/fetch $O/$name/write $O/$name/sq > $O/$name.table.log 2>&1)
+  (cd $R && python tools/pmc_digest.py $O/$name/insts > $O/$name.insts.txt 2>&1)
 }
-pmc c4096
-pmc c2048 --aperture 2048 --farfield 256
-pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
-pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
+K0="gpus=1,aperture=%s,farfield=%s,precision=f64,method=auto,zoom=1,pols=1"
+KEY=$(printf $K0 4096 512) pmc c4096
+KEY=$(printf $K0 2048 256) pmc c2048 --aperture 2048 --farfield 256
+KEY=$(printf $K0 8192 512) pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
+KEY=$(printf $K0 512 64) pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
 # ... and with the order lists characterize() would record (7 to 11 orders per ring collection)
-pmc c4096phys --orders physical
-pmc c8192phys --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --orders physical
+KEY=$(printf $K0 4096 512),orders=physical pmc c4096phys --orders physical
+KEY=$(printf $K0 8192 512),orders=physical pmc c8192phys --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --orders physical
+cp $R/profiles/pmc_table.json $O/pmc_table.json
 SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 --also-physical 0"
 $T rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/c4096/active -- $SHORT > $O/c4096.active.log 2>&1
 cd $R
