@@ -81,68 +81,7 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
-class ClockSampler:
-    """The shader / memory clocks the timed region really ran at: a thread reads the amdgpu sysfs files of the card
-    this process keeps busy (pp_dpm_sclk / pp_dpm_mclk: the starred level is the live value on MI300-class parts)
-    every 5 ms while the steps run.  The box shows every card of the node; ours is the one whose shader clock
-    reads highest while our steps are queued.  No GPU-side cost; None where sysfs is not readable."""
-
-    def __init__(self):
-        import glob
-        import re
-        import threading
-        self._re = re.compile(r'(\d+)\s*[Mm][Hh]z')
-        self.cards = sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk'))
-        self.samples = {}          # card -> [sclk]
-        self.mclk = {}
-        self._stop = threading.Event()
-        self._thread = threading.Thread(target=self._run, daemon=True)
-
-    def _level(self, path):
-        try:
-            with open(path) as f:
-                for line in f:
-                    if '*' in line:
-                        m = self._re.search(line)
-                        if m:
-                            return int(m.group(1))
-        except OSError:
-            pass
-        return None
-
-    def _run(self):
-        while not self._stop.is_set():
-            for c in self.cards:
-                v = self._level(c)
-                if v is not None:
-                    self.samples.setdefault(c, []).append(v)
-                    w = self._level(c.replace('pp_dpm_sclk', 'pp_dpm_mclk'))
-                    if w is not None:
-                        self.mclk.setdefault(c, []).append(w)
-            time.sleep(0.005)
-
-    def start(self):
-        if self.cards:
-            self._thread.start()
-        return self
-
-    def stop(self):
-        self._stop.set()
-        if self._thread.is_alive():
-            self._thread.join()
-        if not self.samples:
-            return None
-        card = max(self.samples, key=lambda c: sum(self.samples[c]) / len(self.samples[c]))
-        v = sorted(self.samples[card])
-        out = {'sclk_mhz_median': v[len(v) // 2], 'sclk_mhz_min': v[0], 'sclk_mhz_max': v[-1], 'samples': len(v),
-               'source': card.replace('/pp_dpm_sclk', '')}
-        if card in self.mclk:
-            w = sorted(self.mclk[card])
-            out['mclk_mhz_median'] = w[len(w) // 2]
-        return out
-
-
-def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False, full_grid_bytes=None, clocks=None):
+def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False, full_grid_bytes=None):
     """roofline object of the synthesis: ALGORITHMIC bytes per step - 64 B (the four complex fields
     written once) per sample and source the launches PROCESS, i.e. per sample inside the
     lens circle: the zeros outside it are stored once per geometry, not per step - / the launch time,
@@ -165,12 +104,14 @@ def nearfield_roof(avg_ms, nf_bytes, pmc_nf, stale=False, full_grid_bytes=None, 
     if insts:
         # SQ_INSTS_VALU wave-instructions per launch (counter) x 4 cycles / (1024 SIMDs x 2.4 GHz) = the
         # time the launch needs if every SIMD issues back to back
-        # (at the shader clock MEASURED over the timed region where sysfs shows it - ClockSampler - else 2.4 GHz)
-        hz = clocks['sclk_mhz_median'] * 1e6 if clocks and clocks.get('sclk_mhz_median') else CLOCK_HZ
-        issue_ms = insts * CYCLES_PER_VALU / (SIMDS * hz) * 1e3
+        # (2.4 GHz is the shader clock the step really runs at: tools/clock_probe.py samples the card's sysfs clock
+        # files while the steps run - 2400 MHz median in every one of ten processes, memory 2000, fabric 1250:
+        # profiles/r06_clock_probe.txt.  The benchmark itself does not read them: a read is a message to the card's
+        # power controller, and the K steps that follow one run 5-10 % slower)
+        issue_ms = insts * CYCLES_PER_VALU / (SIMDS * CLOCK_HZ) * 1e3
         roof['valu'] = {'insts': insts, 'issue_ms': issue_ms, 'issue_frac': issue_ms / avg_ms,
-                        'peak_ginst_per_s': SIMDS * hz / CYCLES_PER_VALU / 1e9, 'stale': bool(stale),
-                        'clock_mhz': hz / 1e6, 'clock_measured': bool(clocks and clocks.get('sclk_mhz_median'))}
+                        'peak_ginst_per_s': VALU_PEAK_GINST, 'stale': bool(stale), 'clock_mhz': CLOCK_HZ / 1e6,
+                        'clock_source': 'sysfs sclk sampled while the step runs, tools/clock_probe.py (profiles/r06_clock_probe.txt)'}
     return roof
 
 
@@ -478,7 +419,6 @@ def main():
     timed_kernels = ('nearfield', 'zgemm_stage1') + (('comm_wait', 'collective') if world > 1 and not replicas else ())
     block_ms = []
     prof = None
-    sampler = ClockSampler().start() if rank == 0 else None
     for block in range(max(1, args.blocks)):
         if block == 0:
             ctx.profile(False)
@@ -502,7 +442,6 @@ def main():
             elapsed = dt
             prof = ctx.profile_get()
             ctx.profile(False)
-    clocks = sampler.stop() if sampler else None
     if n_pols > 1:
         hp.step = one_step
         hp.step()
@@ -741,9 +680,7 @@ def main():
         line['config']['samples_in_lens'] = in_lens
         roofs['nearfield'] = nearfield_roof(nf['total_ms'] / nf['launches'], 64.0 * in_lens * n_pols,
                                             pmc.get('nearfield', {}), stale,
-                                            full_grid_bytes=64.0 * local_rows * side * n_pols, clocks=clocks)
-    if clocks:
-        line['clocks'] = clocks   # shader / memory clock over the timed blocks, from sysfs (ClockSampler)
+                                            full_grid_bytes=64.0 * local_rows * side * n_pols)
     if roofs:
         order = sorted(roofs, key=lambda k: -line['kernels_ms_per_step'][k])
         line['roofline'] = roofs[order[0]]
