@@ -369,7 +369,7 @@ def test_interleaved_shards_sum_to_whole(ma, N, world, block, M, diameter, na):
                 x, x, 0.7 * u, u, ctx=ctx, rank=0, world=world, sharding='interleaved')
 
 
-def _synthetic_lens(radius, na, wavelength, n_glass=0, switch_deg=12.0):
+def _synthetic_lens(radius, na, wavelength, n_glass=0, switch_deg=12.0, **more):
     import math
     import metalens_amd as ma_
     from metalens_amd import layout, synthetic
@@ -377,7 +377,7 @@ def _synthetic_lens(radius, na, wavelength, n_glass=0, switch_deg=12.0):
                                layout.make_design, radius=radius, numerical_aperture=na,
                                wavelength=wavelength, switch_angle=switch_deg * math.pi / 180,
                                n_glass=n_glass, num_gratings=20, num_entries=12,
-                               design_kwargs={'wavelength': wavelength})
+                               design_kwargs={'wavelength': wavelength}, **more)
 
 
 @pytest.mark.parametrize('pol', ['x', 'y'])
@@ -517,13 +517,22 @@ def test_source_sweep_incoherent_sum_vs_oracle(ma):
     assert 0 < got['cone_efficiency'] < got['efficiency'] < 10
 
 
-def test_polarisation_batch_equals_single_sources(ma):
+@pytest.mark.parametrize('mixed', [False, True])
+def test_polarisation_batch_equals_single_sources(ma, mixed):
     """the batched synthesis (one pass, three resident field sets) against three single-source
-    calls of the drop-in function, fields and incident power, dipoles and plane waves"""
+    calls of the drop-in function, fields and incident power, dipoles and plane waves; ``mixed``: a lens whose
+    ring collections are a narrow simple one, one with an order (0, 1) and a wide simple one - the batch
+    instantiations (NP = 2, 3) of the order-list kernels AND of the general kernel in one pass"""
+    import math
     from metalens_amd import _lib
     from metalens_amd.nearfield import nearfield_params
     wl = 580e-9
-    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0)
+    more = {}
+    if mixed:
+        more = dict(periphery_orders=(((0, 0), (-1, 0), (1, 0)), ((0, 0), (-1, 0), (0, 1)),
+                                      ((-2, 0), (-1, 0), (0, 0), (1, 0), (2, 0))),
+                    max_collection_span=5 * math.pi / 180)
+    lens = _synthetic_lens(40e-6, 0.4, wl, switch_deg=9.0, **more)
     R = lens['lens_periphery_summary']['r_max_list'][-1]
     r_c = float(lens['lens_periphery_summary']['r_min_list'][0])
     ctx = _lib.default_context()
@@ -549,6 +558,7 @@ def test_polarisation_batch_equals_single_sources(ma):
             for g, w in zip(F, singles[m][:4]):
                 assert np.abs(g - w).max() <= 1e-14 * scale
             assert abs(pw[m] * (x[1] - x[0]) ** 2 - singles[m][6]) <= 1e-13 * abs(singles[m][6])
+        assert ctx.nearfield_kernels()['family'] == ('mixed' if mixed else 'orders-along-x')
 
 
 def test_position_batch_equals_single_sources(ma):
