@@ -238,6 +238,22 @@ struct FarfieldPlan {
     DevBuf tw_x;         // complex [mx][nx_total]   exp(-i k x' ux)   (A operand of stage 2)
     DevBuf tw_y;         // complex [ny][my]         exp(-i k y' uy)   (B operand of stage 1)
     DevBuf stage1;       // complex [4][nx_local][my]
+    // Measured placement of the TRANSPOSED stage-1 result (farfield.hip transform_impl): K allocations of
+    // the result's size made together (position 0 = `stage1` itself); after WARM steps on position 0 every position takes
+    // PER steps, the transform launches of the last TIMED of them bracketed by an event pair; the fastest is kept (and
+    // becomes `stage1`), the others are freed.
+    struct Placement {
+        enum { WARM = 24, PER = 12, TIMED = 8 };
+        int K = 0;
+        size_t need = 0;
+        const void *base = nullptr, *fields = nullptr;   // what the search was made for (a change restarts it)
+        std::vector<DevBuf> others;                       // positions 1 .. K-1 while searching
+        int steps = 0;        // transform calls since then
+        int chosen = -1;      // >= 0: the search is over
+        std::vector<float> ms;                            // per position: fastest timed transform
+        hipEvent_t e0[TIMED] = {}, e1[TIMED] = {};
+        int ev_used = 0, ev_for = -1;                     // pairs recorded for position ev_for, not read yet
+    } placement;
     DevBuf vectors;      // complex [4][mx][my]  (Nx, Ny, Lx, Ly)  or [4][mx] for a pair list
     DevBuf power;        // double  [mx][my]
     // complex [2 slots][2][mx][my]  (a_theta, a_phi).  Two slots: with a communicator the
@@ -365,6 +381,7 @@ struct ml_ctx {
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see row_extent_kernel; valid only for synthesised fields
     bool row_first_valid = false;
+    int placement_candidates = 6;   // ml_farfield_set_placement_search (0, 1: no search)
     // rows of the local aperture that meet the lens circle, [trim_rows[0], trim_rows[1]) - farfield.hip; key: (grid, layout)
     long trim_key[2] = {-1, -1};
     int trim_rows[2] = {0, 0};

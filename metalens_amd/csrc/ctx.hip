@@ -627,6 +627,11 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     comm_release(ctx);
     if (ctx->counts_pinned) (void)hipHostFree(ctx->counts_pinned);
     if (ctx->counts_ready) (void)hipEventDestroy(ctx->counts_ready);
+    for (int q = 0; q < ml::FarfieldPlan::Placement::TIMED; ++q)
+        if (ctx->plan.placement.e0[q]) {
+            (void)hipEventDestroy(ctx->plan.placement.e0[q]);
+            (void)hipEventDestroy(ctx->plan.placement.e1[q]);
+        }
     if (ctx->comm_stream) {
         for (int k = 0; k < 2; ++k) {
             (void)hipEventDestroy(ctx->amp_ready[k]);

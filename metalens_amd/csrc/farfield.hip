@@ -899,8 +899,85 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // (skew sweep at 4096^2 -> 512^2, stage 1: 0 elements 0.220 ms, 16 0.222, 1 0.204, 2 0.212, 24 0.208,
     // 72 0.206, 4 0.190, 8 0.194-0.196, 40 0.196, 136 0.192: anything but a multiple of 256 bytes)
     const int64_t g_ld = nxl + 8;
-    ML_TRY(pl.stage1.reserve(g_transposed ? (size_t)4 * my * g_ld * 2 * sizeof(double)
-                                          : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
+    // MEASURED PLACEMENT of the transposed result.  How fast stage 1's 16-byte scattered stores go depends on where G lies
+    // relative to the field planes the same launch streams - two discrete speeds, 0.183 / 0.200 ms at 4096^2 -> 512^2,
+    // following the ALLOCATION (positions inside one allocation all run alike), not the process and not the clocks
+    //  - and neither virtual addresses nor anything else the library controls predicts which.  So a plan
+    // that is being stepped (24 transforms on the same buffers) makes `placement_candidates` - 1 more allocations of G's
+    // size and measures them IN the step (in isolation all read alike, and fresh allocations run slow for their first
+    // launches): 12 steps on each, the two transform launches of the last 8 between an event pair; the fastest is
+    // kept, the others freed.  Results do not depend on it; ml_farfield_set_placement_search(ctx, 0) turns it off.
+    FarfieldPlan::Placement &pm = pl.placement;
+    const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double);
+    ML_TRY(pl.stage1.reserve(g_transposed ? g_need : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
+    void *g_at = pl.stage1.p;     // G of this call
+    int time_slot = -1;           // >= 0: this call's launches go between event pair `time_slot`
+    if (g_transposed && (pm.base != pl.stage1.p || pm.fields != (const void *)ctx->fields.p || pm.need != g_need)) {
+        for (auto &b : pm.others) b.release();
+        pm.others.clear();
+        pm.base = pl.stage1.p;
+        pm.fields = ctx->fields.p;
+        pm.need = g_need;
+        pm.K = (int)std::min<size_t>(ctx->placement_candidates, ((size_t)2 << 30) / g_need);
+        pm.steps = 0;
+        pm.ev_used = 0;
+        pm.ev_for = -1;
+        pm.chosen = pm.K >= 2 ? -1 : 0;
+        pm.ms.assign(std::max(pm.K, 0), -1.0f);
+    }
+    if (g_transposed && pm.chosen < 0) {
+        typedef FarfieldPlan::Placement P;
+        if (pm.steps == P::WARM) {   // a sweep is running on this plan: the other positions are allocated now
+            pm.others.resize(pm.K - 1);
+            for (auto &b : pm.others)
+                if (b.reserve(pl.stage1.bytes) != ML_OK) {   // (no room: no search)
+                    for (auto &o : pm.others) o.release();
+                    pm.others.clear();
+                    pm.chosen = 0;
+                    (void)hipGetLastError();   // (the failed allocation's: not a later launch's)
+                    break;
+                }
+        }
+    }
+    if (g_transposed && pm.chosen < 0) {
+        typedef FarfieldPlan::Placement P;
+        const int K = pm.K, n = pm.steps - P::WARM, k = n < 0 ? 0 : n / P::PER, j = n < 0 ? 0 : n % P::PER;
+        if (pm.ev_used > 0 && k != pm.ev_for) {   // the previous position's launches: complete long ago
+            ML_HIP(hipEventSynchronize(pm.e1[pm.ev_used - 1]));
+            float best = 1e30f;
+            for (int q = 0; q < pm.ev_used; ++q) {
+                float t = 0;
+                ML_HIP(hipEventElapsedTime(&t, pm.e0[q], pm.e1[q]));
+                best = std::min(best, t);
+            }
+            pm.ms[pm.ev_for] = best;
+            pm.ev_used = 0;
+        }
+        if (k >= K) {
+            int best = 0;
+            for (int c = 1; c < K; ++c)
+                if (pm.ms[c] >= 0 && (pm.ms[best] < 0 || pm.ms[c] < pm.ms[best])) best = c;
+            pm.chosen = best;
+            ML_HIP(hipStreamSynchronize(ctx->stream));   // (once per plan: launches still read the buffers freed here)
+            if (best > 0) std::swap(pl.stage1, pm.others[best - 1]);
+            for (auto &b : pm.others) b.release();
+            pm.others.clear();
+            pm.base = pl.stage1.p;
+            g_at = pl.stage1.p;
+        } else {
+            if (k > 0) g_at = pm.others[k - 1].p;
+            if (n >= 0 && j >= P::PER - P::TIMED) {
+                if (!pm.e0[0])
+                    for (int q = 0; q < P::TIMED; ++q) {
+                        ML_HIP(hipEventCreate(&pm.e0[q]));
+                        ML_HIP(hipEventCreate(&pm.e1[q]));
+                    }
+                time_slot = pm.ev_used;
+                pm.ev_for = k;
+            }
+            ++pm.steps;
+        }
+    }
 #ifdef ML_DIAG
     {   // (tools/mode_slab.sh: the stage-1 result inside the fields' allocation, ML_SLAB_OFFSET_MB behind the four planes)
         static const int slab_mb = diag_int("ML_SLAB_OFFSET_MB", -1);
@@ -909,6 +986,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             static void *own = nullptr;
             if (!own) own = pl.stage1.p;   // (the plan's own allocation stays allocated, unused)
             pl.stage1.p = (char *)ctx->fields.p + planes + ((size_t)slab_mb << 20);
+            g_at = pl.stage1.p;
         }
     }
 #endif
@@ -921,11 +999,13 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             if (hipMalloc(&q, pl.stage1.bytes) == hipSuccess) {
                 // (the old allocation is LEFT in place - leaked, a diagnostic - so that every move lands somewhere new)
                 pl.stage1.p = q;
+                g_at = q;
                 fprintf(stderr, "ML_MOVED stage1 %p\n", q);
             }
         }
     }
 #endif
+    double *const g_buf = static_cast<double *>(g_at);
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
     static const long fold2_min_tiles = diag_int("ML_FOLD2_MIN_TILES", 32);
@@ -1031,7 +1111,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         c.out_s2 = my;
         c.out_es = 1;
         if (g_transposed) {   // row (f, n1), bin b -> G[f][b][n1]
-            c.out = pl.stage1.as<double>() + (size_t)trim_lo * 2;
+            c.out = g_buf + (size_t)trim_lo * 2;
             c.out_rb = nxt;
             c.out_s1 = (int64_t)my * g_ld;
             c.out_s2 = 1;
@@ -1058,6 +1138,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         }
         return ML_OK;
     };
+    if (time_slot >= 0) ML_HIP(hipEventRecord(pm.e0[time_slot], ctx->stream));
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
@@ -1159,7 +1240,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         c.jstep = pl.fft_x.jstep;
         c.pad1 = pl.fft_x.pad1;
         c.pad2 = pl.fft_x.pad2;
-        c.in = pl.stage1.as<double>();
+        c.in = g_buf;
         c.rows = 4 * my;
         c.in_rb = my;
         c.in_s1 = (int64_t)nxl * my;
@@ -1181,7 +1262,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
             c.a0 = row0 + trim_lo;
             c.h0 = nxt;
             c.a1 = c.h1 = 0;
-            c.in = pl.stage1.as<double>() + (size_t)trim_lo * c.in_es * 2;
+            c.in = g_buf + (size_t)trim_lo * c.in_es * 2;
         }
         c.row_first = nullptr;
         c.rf_mod = 1;
@@ -1238,9 +1319,28 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         ML_TRY(zcoldot(ctx->stream, 4, nxl, mx, alpha, pl.tw_x.as<double>(), mx, row0,
                        pl.stage1.as<double>(), pl.vectors.as<double>(), accumulate));
     }
+    if (time_slot >= 0) {
+        ML_HIP(hipEventRecord(pm.e1[time_slot], ctx->stream));
+        pm.ev_used = time_slot + 1;
+    }
     pl.have_vectors = true;
     pl.amplitudes_reduced = false;
     return ML_OK;
+}
+
+int ml_farfield_set_placement_search(ml_ctx *ctx, int candidates) {
+    if (!ctx || candidates < 0 || candidates > 16) return ML_EINVAL;
+    ctx->placement_candidates = candidates;
+    return ML_OK;
+}
+
+int ml_farfield_placement_info(ml_ctx *ctx, int *state, int *chosen, float *ms, int capacity) {
+    if (!ctx) return ML_EINVAL;
+    const FarfieldPlan::Placement &pm = ctx->plan.placement;
+    if (state) *state = pm.K < 2 ? 0 : pm.chosen >= 0 ? 2 : 1;
+    if (chosen) *chosen = pm.chosen;
+    for (int k = 0; ms && k < capacity; ++k) ms[k] = k < (int)pm.ms.size() ? pm.ms[k] : -1.0f;
+    return pm.K;
 }
 
 static Shard block_shard(int row0, int mirrored) {
