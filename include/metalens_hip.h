@@ -213,14 +213,18 @@ int ml_farfield_plan_info(ml_ctx *ctx, int *stage1_kernel);
  * 8192; the GEMMs take over where the odd part of N has no divisor that brings it to <= 32).    */
 int ml_farfield_plan_kernels(ml_ctx *ctx, int *stage1_kernel, int *stage2_kernel);
 /* How ml_farfield_plan chooses: ML_METHOD_AUTO (default) takes the FFT on every axis whose grid
- * sits on the lattice and the GEMMs elsewhere; ML_METHOD_GEMM always takes the GEMMs (arbitrary
- * grids need them anyway; this makes them testable on lattice grids too).  Takes effect at the
- * next ml_farfield_plan.                                                                     */
+ * sits on a lattice that is a multiple of 64 samples long (padded at most 4-fold) and the GEMMs
+ * elsewhere - measured, profiles/r06_padded_fft_sweep.txt: the 2- and 4-fold padded lattices (1920,
+ * 3200, 960, 1600 samples) run 1.1 to 5 times faster as FFTs than as folded GEMMs, the 8-fold padded
+ * ones (800, 1440, 2400) 0.5 to 1.1 times, the 16- to 128-fold padded ones (400, 2000, 3600, 1000,
+ * 250) 0.1 to 0.7 times; ML_METHOD_GEMM always takes the GEMMs (arbitrary grids need them anyway;
+ * this makes them testable on lattice grids too).  Takes effect at the next ml_farfield_plan.    */
 #define ML_METHOD_AUTO 0
 #define ML_METHOD_GEMM 1
-/* ML_METHOD_FFT_STREAMED: as AUTO, and where both axes run as one-level FFTs stage 1 writes its result
- * transposed for a streaming stage 2 whatever the aperture's size (AUTO does so from 96 MiB of
- * geometry records + stage-1 result on: DESIGN.md 4.2)                                           */
+/* ML_METHOD_FFT_STREAMED: the FFT on every axis whose grid sits on a lattice, HOWEVER padded, and where
+ * both axes run as one-level FFTs stage 1 writes its result transposed for a streaming stage 2
+ * whatever the aperture's size (AUTO does so from 96 MiB of geometry records + stage-1 result on:
+ * DESIGN.md 4.2)                                                                                  */
 #define ML_METHOD_FFT_STREAMED 2
 int ml_farfield_set_method(ml_ctx *ctx, int method);
 /* Arithmetic of the aperture -> direction GEMMs (BASELINE.json: "1e-12 (fp64) / 1e-4 (fp32)",

@@ -496,6 +496,13 @@ static int plan_fft_axis(ml_ctx *ctx, ZfftAxis &ax, int n, double step, const do
     int N_eff = 0, j0 = 0, jstep = 1;
     if (!zfft_commensurate(n, step, kappa, u, m, symmetry_tolerance(kappa, p_max, u, m), &N_eff, &j0, &jstep))
         return ML_OK;
+    // A lattice that is not a multiple of 256 long runs jstep-fold padded, at jstep times the arithmetic and (beyond
+    // 8192 padded samples) as many passes over the rows.  Measured against the folded GEMMs on square apertures
+    // (tools/padded_fft_sweep.py, profiles/r06_padded_fft_sweep.txt; M = 64, 256, N directions): jstep 2 (1920, 3200
+    // samples) 1.7-5.3 x faster, 4 (320, 960, 1600) 1.1-2.5 x, 8 (800, 1440, 2400) 0.5-1.1 x, 16 (400, 2000, 3600)
+    // 0.1-0.7 x, 32 (1000, 3000) 0.1-0.2 x, 128 (250) 0.1 x.  `auto` leaves the lattices padded more than 4-fold to
+    // the GEMMs; `fft-streamed` takes the FFT wherever there is one
+    if (pl.method == ML_METHOD_AUTO && jstep > 4) return ML_OK;
     int split = zfft_split(N_eff);
     // 8192 < N_eff <= 16384 with at most 1024 wanted bins: one launch in two residue passes (every
     // row read once, whole 128-byte lines, no accumulating store) instead of two sub-sequences

@@ -274,7 +274,10 @@ __device__ __forceinline__ void sample_geometry(const NfArgs &a, double x, doubl
 }
 
 
-__global__ __launch_bounds__(64, 4) void nearfield_geometry_kernel(const NfArgs a) {
+#ifndef ML_GEO_OCC
+#define ML_GEO_OCC 8   // (8: 64 registers, the spills sit in nearest_cell_fast's cold search; 102 us against 117 at 4 on 4096^2)
+#endif
+__global__ __launch_bounds__(64, ML_GEO_OCC) void nearfield_geometry_kernel(const NfArgs a) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.y * 8 + (lane >> 3);
     const int j = blockIdx.x * 8 + (lane & 7);

@@ -6,6 +6,8 @@ Needs an MI355X."""
 import os
 import sys
 
+import math
+
 import numpy as np
 import pytest
 
@@ -61,9 +63,10 @@ def test_reference_flow_on_the_default_grid_golden():
     assert out[0] is None and len(out[4]) == 400
     P, total_P, ux, uy, dux, duy = ma.farfield_from_resident_nearfield(
         out[4], out[5], float(z['wavelength']), out[7], Z0=float(z['Z0']), ctx=ctx)
-    # the reference's default grid of this lens has 400 = 16 x 25 samples: the pruned FFT on the
-    # sixteen times finer lattice of 6400, every sixteenth bin
-    assert ctx.plan_kernels() == ('fft', 'fft')
+    # the reference's default grid of this lens has 400 = 16 x 25 samples: its lattice would take sixteen-fold
+    # padding to run as the pruned FFT, and `auto` leaves those to the folded GEMMs (measured 1.5 x faster here,
+    # profiles/r06_padded_fft_sweep.txt; test_whole_lattice_vs_oracle_flow runs the padded FFT too)
+    assert ctx.plan_kernels() == ('folded', 'folded')
     s = int(z['stride'])
     sub = P[3::s, 2::s]
     ok = ~np.isnan(z['P'])
@@ -76,15 +79,18 @@ def test_reference_flow_on_the_default_grid_golden():
     assert dux == z['dux'] and duy == z['duy']
 
 
-@pytest.mark.parametrize('N', [512, 768, 500, 1024, 400, 384, 960, 729])
-def test_whole_lattice_vs_oracle_flow(N):
+@pytest.mark.parametrize('N,method', [(512, 'auto'), (768, 'auto'), (1024, 'auto'), (384, 'auto'), (960, 'auto'),
+                                      (400, 'auto'), (500, 'auto'), (729, 'auto'),
+                                      (400, 'fft-streamed'), (500, 'fft-streamed'), (960, 'fft-streamed')])
+def test_whole_lattice_vs_oracle_flow(N, method):
     """a lens window of N x N samples: every lattice direction against the oracle's restatement of the
     reference flow (numpy.fft on the host) - ALL N^2 directions, not a sample.  512, 768, 1024:
-    multiples of 256 -> both axes run as the pruned FFT with nothing pruned; 400, 384, 960, 500: what
+    multiples of 256 -> both axes run as the pruned FFT with nothing pruned; 384, 960, 400, 500: what
     good_fft_number hands out (nearfield.py:30-36: 2^a 3^b 5^c, not multiples of 256) -> the same FFT on
-    the 16 / 2 / 4 / 64 times finer lattice that is one, every 16th / 2nd / 4th / 64th bin wanted (500:
-    in five interleaved sub-sequences of 6400 samples); 729 = 3^6 has no factor of two to build on
-    and keeps the folded GEMMs"""
+    the 2 / 4 / 16 / 64 times finer lattice that is one, every 2nd / 4th / 16th / 64th bin wanted (500:
+    in five interleaved sub-sequences of 6400 samples) - which `auto` takes up to four-fold padding (beyond that
+    the folded GEMMs are faster, metalens_hip.h ML_METHOD_AUTO) and `fft-streamed` always; 729 = 3^6 has no factor
+    of two to build on and keeps the folded GEMMs"""
     import metalens_amd as ma
     from metalens_amd import _lib
     from oracle import farfield_oracle
@@ -99,8 +105,13 @@ def test_whole_lattice_vs_oracle_flow(N):
     ctx = _lib.default_context()
     fields = ma.build_nearfield(ctx=ctx, **args)          # host copies for the oracle flow
     ma.build_nearfield(ctx=ctx, download=False, **args)   # and the resident set
-    P, total_P, ux, uy, dux, duy = ma.farfield_from_resident_nearfield(x, x, wl, fields[7], ctx=ctx)
-    assert ctx.plan_kernels() == (('folded', 'folded') if N == 729 else ('fft', 'fft'))
+    ctx.set_method(method)
+    try:
+        P, total_P, ux, uy, dux, duy = ma.farfield_from_resident_nearfield(x, x, wl, fields[7], ctx=ctx)
+    finally:
+        ctx.set_method('auto')
+    padding = 256 // math.gcd(N, 256)
+    assert ctx.plan_kernels() == (('fft', 'fft') if padding <= (4 if method == 'auto' else 64) else ('folded', 'folded'))
     ffts = [np.fft.fft2(np.fft.fftshift(F)) for F in fields[:4]]
     want = farfield_oracle.farfield_from_nearfield(*ffts, x, x, wl, fields[7])
     assert np.array_equal(np.isnan(P), np.isnan(want[0]))
