@@ -905,7 +905,8 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
                                (size_t)nxl * ny * 8 + (size_t)4 * nxl * my * 16 > (size_t)96 << 20);
     // (skew sweep at 4096^2 -> 512^2, stage 1: 0 elements 0.220 ms, 16 0.222, 1 0.204, 2 0.212, 24 0.208,
     // 72 0.206, 4 0.190, 8 0.194-0.196, 40 0.196, 136 0.192: anything but a multiple of 256 bytes)
-    const int64_t g_ld = nxl + 8;
+    static const int g_skew = diag_int("ML_G_SKEW", 8);   // (diagnostic builds: the pitch's skew in elements)
+    const int64_t g_ld = nxl + g_skew;
     // MEASURED PLACEMENT of the transposed result.  How fast stage 1's 16-byte scattered stores go depends on where G lies
     // relative to the field planes the same launch streams - two discrete speeds, 0.183 / 0.200 ms at 4096^2 -> 512^2,
     // following the ALLOCATION (positions inside one allocation all run alike), not the process and not the clocks
@@ -915,7 +916,14 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // launches): 12 steps on each, the two transform launches of the last 8 between an event pair; the fastest is
     // kept, the others freed.  Results do not depend on it; ml_farfield_set_placement_search(ctx, 0) turns it off.
     FarfieldPlan::Placement &pm = pl.placement;
-    const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double);
+#ifdef ML_DIAG
+    // (does the row transform's speed follow the result's position WITHIN its allocation at sub-2-MiB granularity?  The
+    // buffer is made ML_G_OFFSET_KB larger and G starts that far in)
+    static const size_t g_shift = (size_t)diag_int("ML_G_OFFSET_KB", 0) << 10;
+#else
+    constexpr size_t g_shift = 0;
+#endif
+    const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double) + g_shift;
     ML_TRY(pl.stage1.reserve(g_transposed ? g_need : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
     void *g_at = pl.stage1.p;     // G of this call
     int time_slot = -1;           // >= 0: this call's launches go between event pair `time_slot`
@@ -1012,7 +1020,7 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         }
     }
 #endif
-    double *const g_buf = static_cast<double *>(g_at);
+    double *const g_buf = reinterpret_cast<double *>(static_cast<char *>(g_at) + (g_transposed ? g_shift : 0));
     // the folded stage 2 pays once its grid (32-row x 64-half-direction tiles over the 4*my
     // transposed rows) fills the chip; below that the generic GEMM with 32 x 32 tiles is faster
     static const long fold2_min_tiles = diag_int("ML_FOLD2_MIN_TILES", 32);
