@@ -252,8 +252,6 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--placement', type=int, default=-1,
-                    help='positions of the measured placement of the row transform result (0: no search; -1: the library default)')
     ap.add_argument('--aperture', type=int, default=None,
                     help='aperture samples per side (default 4096; 8192 for N > 1)')
     ap.add_argument('--farfield', type=int, default=512, help='far-field directions per side')
@@ -337,8 +335,6 @@ def main():
     if world != args.gpus:
         args.gpus = world
     ctx = _lib.Context(local_rank)
-    if args.placement >= 0:
-        ctx.placement_search(args.placement)
     dist.init_comm(ctx, rank, world)
 
     replicas = args.replicas == 'wavelength'
@@ -405,15 +401,6 @@ def main():
     for _ in range(prime):
         hp.step()
     hp.sync()
-    # (the plan times the positions of the row transform's result over its first 24 + 12 * positions transforms and
-    # keeps the fastest, DESIGN.md 4.2: a one-time cost of the plan, over before anything is read off the clock)
-    for _ in range(30):
-        if ctx.placement_info()['state'] != 'searching':
-            break
-        for _ in range(10):
-            hp.step()
-        hp.sync()
-        prime += 10
     # ... and then until two consecutive K-step blocks agree to 3 % (at most eight more): `value` comes
     # from the FIRST timed block, which must not be the one that is still warming up
     last = None
@@ -515,7 +502,6 @@ def main():
     if args.dump and rank == 0:
         np.savez(args.dump, P=res['P'], a_theta=res['a_theta'], a_phi=res['a_phi'])
     stage_kernels = ctx.plan_kernels()
-    placement = ctx.placement_info()   # (of the plan the timed steps ran on)
 
     # ---- correctness of what was just timed (rank 0, N=1): a sample of directions against
     # the CPU oracle evaluated from the GPU's own near field rows
@@ -604,7 +590,7 @@ def main():
                    'centre_cells': int(len(lens['lens_center_summary'])),
                    'parallelism': par, 'sharding': hp.sharding, 'sources_per_step': n_pols,
                    'replicas': replica_table,
-                   'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1], 'placement': placement},
+                   'transform': {'stage1': stage_kernels[0], 'stage2': stage_kernels[1]},
                    # the table's order sets and the synthesis kernels they select (ml_nearfield_kernel_info)
                    'orders': args.orders,
                    'orders_per_table': [len(o) for o in getattr(ctx, 'table_orders', [])],

@@ -407,20 +407,6 @@ int ml_nearfield_result(ml_ctx *ctx, double *power, ml_bound_violation *violatio
  * Any pointer may be NULL.                                                                       */
 int ml_nearfield_kernel_info(ml_ctx *ctx, int *family, int *ring_orders_max, int *centre_orders);
 
-/* Measured placement of the row transform's result (no counterpart in the reference: it allocates per call,
- * nearfield_farfield.py:62-70).  With the pruned FFT on a large aperture the transposed stage-1 result runs at one of
- * two speeds depending on where its buffer lies relative to the field planes, which nothing but a
- * measurement tells.  The plan therefore holds `candidates` positions in one allocation and the first
- * 24 + 12 * candidates transforms time them in place; the fastest is kept for the life of the plan.  Results are the
- * same at every position.
- *   ml_farfield_set_placement_search  candidates 0 or 1: no search, one position (before the first transform of a
- *                                     plan); default 6; at most 16
- *   ml_farfield_placement_info        returns the number of positions (0: the plan has no slab); *state 0 none,
- *                                     1 searching, 2 settled; *chosen the kept position or -1; ms[0..capacity) the
- *                                     fastest timed transform per position in ms (-1: not measured)             */
-int ml_farfield_set_placement_search(ml_ctx *ctx, int candidates);
-int ml_farfield_placement_info(ml_ctx *ctx, int *state, int *chosen, float *ms, int capacity);
-
 #ifdef __cplusplus
 }
 #endif

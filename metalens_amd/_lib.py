@@ -45,7 +45,7 @@ SYMBOLS = (
     'ml_nearfield_batch_async', 'ml_fields_select', 'ml_nearfield_powers',
     'ml_farfield_accumulate', 'ml_farfield_sums', 'ml_farfield_total_power', 'ml_host_alloc', 'ml_host_free',
     'ml_comm_info', 'ml_comm_set_reduce', 'ml_farfield_gather', 'ml_nearfield_kernel_info',
-    'ml_comm_set_max_channels', 'ml_farfield_set_placement_search', 'ml_farfield_placement_info',
+    'ml_comm_set_max_channels',
 )
 
 
@@ -148,9 +148,6 @@ def load():
         lib.ml_farfield_gather.argtypes = [c_void_p]
     if hasattr(lib, 'ml_comm_set_max_channels'):
         lib.ml_comm_set_max_channels.argtypes = [c_void_p, c_int]
-    if hasattr(lib, 'ml_farfield_set_placement_search'):
-        lib.ml_farfield_set_placement_search.argtypes = [c_void_p, c_int]
-        lib.ml_farfield_placement_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(ctypes.c_float), c_int]
     if hasattr(lib, 'ml_nearfield_kernel_info'):
         lib.ml_nearfield_kernel_info.argtypes = [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int)]
     lib.ml_profile_enable.argtypes = [c_void_p, c_int]
@@ -327,23 +324,6 @@ class Context:
         check(self.lib.ml_nearfield_kernel_info(self.handle, byref(fam), byref(ring), byref(cen)))
         return {'family': ('general', 'orders-along-x', 'mixed')[fam.value], 'ring_orders_max': ring.value,
                 'centre_orders': cen.value}
-
-    def placement_search(self, candidates):
-        """positions the row transform's result buffer may take (0, 1: no search); before the first transform of a plan"""
-        check(self.lib.ml_farfield_set_placement_search(self.handle, int(candidates)))
-
-    def placement_info(self):
-        """{'positions', 'state' ('none' | 'searching' | 'settled'), 'chosen', 'ms' per position} of the measured
-        placement of the row transform's result (include/metalens_hip.h ml_farfield_placement_info)"""
-        if not hasattr(self.lib, 'ml_farfield_placement_info'):   # (A/B runs against an older build)
-            return {'positions': 0, 'state': 'none', 'chosen': -1, 'ms': []}
-        st, ch = c_int(0), c_int(-1)
-        ms = (ctypes.c_float * 16)()
-        n = self.lib.ml_farfield_placement_info(self.handle, byref(st), byref(ch), ms, 16)
-        if n < 0:
-            check(n)
-        return {'positions': n, 'state': ('none', 'searching', 'settled')[st.value], 'chosen': ch.value,
-                'ms': [round(float(ms[k]), 4) for k in range(n)]}
 
     def profile(self, on=True, kernels=None, every=1):
         """time kernel launches with HIP events; ``kernels`` = names to time (default all),

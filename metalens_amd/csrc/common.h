@@ -56,16 +56,24 @@ constexpr int diag_int(const char *, int dflt) { return dflt; }
 #endif
 
 // A device allocation that only grows.
+// `piece` > 0: the allocation is made of PHYSICAL pieces of that many bytes, each an allocation of its own
+// (hipMemCreate), mapped side by side into one reserved address range (hipMemMap).  What that is for: how fast
+// 16-byte stores a fixed large stride apart go (the row transform's transposed result, farfield.hip) depends on the
+// physical layout behind the buffer, which hipMalloc leaves to the driver's free lists - measured at 4096^2 -> 512^2,
+// stage 1 (profiles/r06_ab_runs.txt): one physically contiguous allocation 0.33 ms, pieces of 16 KB 1.28, 512 KB 0.8-1.0,
+// 1 MB 0.51 (address translation: the 2 MB fragment is lost), 2 MB 0.180, 4 MB 0.180, 8 MB 0.180, 32 MB 0.186; plain
+// hipMalloc 0.183 or 0.200 depending on what the process was handed.  Falls back to hipMalloc where the virtual-memory
+// API is not available.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    size_t piece = 0;                                      // 0: one hipMalloc
+    std::vector<hipMemGenericAllocationHandle_t> handles;  // the pieces behind p
+    bool reserved = false;                                 // p is a reserved address range with the pieces mapped into it
     int reserve(size_t want) {
         if (want <= bytes) return ML_OK;
-        if (p) {
-            (void)hipFree(p);
-            p = nullptr;
-            bytes = 0;
-        }
+        release();
+        if (piece > 0 && reserve_pieces(want)) return ML_OK;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -75,8 +83,61 @@ struct DevBuf {
         bytes = want;
         return ML_OK;
     }
+    bool reserve_pieces(size_t want) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran ||
+            piece % gran) {
+            (void)hipGetLastError();
+            return false;
+        }
+        const size_t total = (want + piece - 1) / piece * piece;
+        void *base = nullptr;
+        if (hipMemAddressReserve(&base, total, piece, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        bool ok = true;
+        for (size_t off = 0; ok && off < total; off += piece) {
+            hipMemGenericAllocationHandle_t h;
+            ok = hipMemCreate(&h, piece, &prop, 0) == hipSuccess;
+            if (!ok) break;
+            handles.push_back(h);
+            ok = hipMemMap(static_cast<char *>(base) + off, piece, 0, h, 0) == hipSuccess;
+        }
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = ok && hipMemSetAccess(base, total, &acc, 1) == hipSuccess;
+        p = base;
+        bytes = total;
+        reserved = true;
+        if (!ok) {
+            (void)hipGetLastError();
+            release();
+            return false;
+        }
+        return true;
+    }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && reserved) {
+            // (a piece that was created but not mapped - a failed reserve_pieces - makes its unmap fail: ignored)
+            for (size_t k = 0; k < handles.size(); ++k) {
+                (void)hipMemUnmap(static_cast<char *>(p) + k * piece, piece);
+                (void)hipMemRelease(handles[k]);
+            }
+            (void)hipMemAddressFree(p, bytes);
+            (void)hipGetLastError();
+        } else if (p) {
+            (void)hipFree(p);
+        }
+        handles.clear();
+        reserved = false;
         p = nullptr;
         bytes = 0;
     }
@@ -238,22 +299,6 @@ struct FarfieldPlan {
     DevBuf tw_x;         // complex [mx][nx_total]   exp(-i k x' ux)   (A operand of stage 2)
     DevBuf tw_y;         // complex [ny][my]         exp(-i k y' uy)   (B operand of stage 1)
     DevBuf stage1;       // complex [4][nx_local][my]
-    // Measured placement of the TRANSPOSED stage-1 result (farfield.hip transform_impl): K allocations of
-    // the result's size made together (position 0 = `stage1` itself); after WARM steps on position 0 every position takes
-    // PER steps, the transform launches of the last TIMED of them bracketed by an event pair; the fastest is kept (and
-    // becomes `stage1`), the others are freed.
-    struct Placement {
-        enum { WARM = 24, PER = 12, TIMED = 8 };
-        int K = 0;
-        size_t need = 0;
-        const void *base = nullptr, *fields = nullptr;   // what the search was made for (a change restarts it)
-        std::vector<DevBuf> others;                       // positions 1 .. K-1 while searching
-        int steps = 0;        // transform calls since then
-        int chosen = -1;      // >= 0: the search is over
-        std::vector<float> ms;                            // per position: fastest timed transform
-        hipEvent_t e0[TIMED] = {}, e1[TIMED] = {};
-        int ev_used = 0, ev_for = -1;                     // pairs recorded for position ev_for, not read yet
-    } placement;
     DevBuf vectors;      // complex [4][mx][my]  (Nx, Ny, Lx, Ly)  or [4][mx] for a pair list
     DevBuf power;        // double  [mx][my]
     // complex [2 slots][2][mx][my]  (a_theta, a_phi).  Two slots: with a communicator the
@@ -381,7 +426,6 @@ struct ml_ctx {
     std::vector<double> h_x_pts, h_y_pts;   // what x_pts / y_pts hold (re-uploaded only on change)
     ml::DevBuf row_first;          // see row_extent_kernel; valid only for synthesised fields
     bool row_first_valid = false;
-    int placement_candidates = 6;   // ml_farfield_set_placement_search (0, 1: no search)
     // rows of the local aperture that meet the lens circle, [trim_rows[0], trim_rows[1]) - farfield.hip; key: (grid, layout)
     long trim_key[2] = {-1, -1};
     int trim_rows[2] = {0, 0};

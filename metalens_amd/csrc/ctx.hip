@@ -627,11 +627,6 @@ void ml_ctx_destroy(ml_ctx *ctx) {
     comm_release(ctx);
     if (ctx->counts_pinned) (void)hipHostFree(ctx->counts_pinned);
     if (ctx->counts_ready) (void)hipEventDestroy(ctx->counts_ready);
-    for (int q = 0; q < ml::FarfieldPlan::Placement::TIMED; ++q)
-        if (ctx->plan.placement.e0[q]) {
-            (void)hipEventDestroy(ctx->plan.placement.e0[q]);
-            (void)hipEventDestroy(ctx->plan.placement.e1[q]);
-        }
     if (ctx->comm_stream) {
         for (int k = 0; k < 2; ++k) {
             (void)hipEventDestroy(ctx->amp_ready[k]);
@@ -974,26 +969,15 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
     ML_TRY(grid_axis(ctx->y_pts, ctx->h_y_pts, y_pts, ny));
     const size_t plane = (size_t)nx * ny;
 #ifdef ML_DIAG
-    {   // (tools/mode_slab.sh: the field planes and the stage-1 result in ONE allocation, the result ML_SLAB_OFFSET_MB behind the planes)
-        static const int slab_mb = diag_int("ML_SLAB_OFFSET_MB", -1);
-        if (slab_mb >= 0) ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double) + ((size_t)slab_mb << 20) + ((size_t)320 << 20)));
-    }
-#endif
-    ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
-#ifdef ML_DIAG
-    {   // (tools/mode_moves.py: ... or the field planes'?)
-        static const int move_every = diag_int("ML_MOVE_FIELDS", 0);
-        static long calls = 0;
-        if (move_every > 0 && ++calls % move_every == 0) {
-            void *q = nullptr;
-            if (hipMalloc(&q, ctx->fields.bytes) == hipSuccess) {
-                // (the old allocation is LEFT in place - leaked, a diagnostic - so that every move lands somewhere new)
-                ctx->fields.p = q;
-                fprintf(stderr, "ML_MOVED fields %p\n", q);
-            }
+    {   // (tools/ab_goffset.sh: the field planes in physical pieces, as the row transform's result is - common.h DevBuf::piece)
+        static const size_t f_piece = (size_t)diag_int("ML_F_PIECE_KB", 0) << 10;
+        if (f_piece && ctx->fields.piece != f_piece) {
+            ctx->fields.release();
+            ctx->fields.piece = f_piece;
         }
     }
 #endif
+    ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
     ctx->n_sets = n;
@@ -1021,6 +1005,15 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
         ctx->n_ovr = 0;
         ++ctx->ovr_serial;
     }
+#ifdef ML_DIAG
+    {   // (... and the geometry records)
+        static const size_t r_piece = (size_t)diag_int("ML_R_PIECE_KB", 0) << 10;
+        if (r_piece && ctx->geo_ix.piece != r_piece) {
+            ctx->geo_ix.release();
+            ctx->geo_ix.piece = r_piece;
+        }
+    }
+#endif
     ML_TRY(ctx->geo_ix.reserve((size_t)blocks * 64 * 2 * sizeof(int)));   // patch-major, 64 per patch
     ML_TRY(ctx->active_list.reserve((size_t)4 * blocks * 2 * sizeof(int)));           // four lists (NfArgs::active_list)
     ML_TRY(ctx->active_count.reserve((size_t)4 * (blocks / 1024 + 4) * sizeof(int)));   // each: total + one per chunk of 1024 patches

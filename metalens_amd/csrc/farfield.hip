@@ -907,117 +907,37 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // 72 0.206, 4 0.190, 8 0.194-0.196, 40 0.196, 136 0.192: anything but a multiple of 256 bytes)
     static const int g_skew = diag_int("ML_G_SKEW", 8);   // (diagnostic builds: the pitch's skew in elements)
     const int64_t g_ld = nxl + g_skew;
-    // MEASURED PLACEMENT of the transposed result.  How fast stage 1's 16-byte scattered stores go depends on where G lies
-    // relative to the field planes the same launch streams - two discrete speeds, 0.183 / 0.200 ms at 4096^2 -> 512^2,
-    // following the ALLOCATION (positions inside one allocation all run alike), not the process and not the clocks
-    //  - and neither virtual addresses nor anything else the library controls predicts which.  So a plan
-    // that is being stepped (24 transforms on the same buffers) makes `placement_candidates` - 1 more allocations of G's
-    // size and measures them IN the step (in isolation all read alike, and fresh allocations run slow for their first
-    // launches): 12 steps on each, the two transform launches of the last 8 between an event pair; the fastest is
-    // kept, the others freed.  Results do not depend on it; ml_farfield_set_placement_search(ctx, 0) turns it off.
-    FarfieldPlan::Placement &pm = pl.placement;
+    // The TRANSPOSED result lies in physical pieces of 8 MB, each an allocation of its own, mapped side by side
+    // (common.h DevBuf::piece).  Stage 1 stores it in 16-byte pieces one pitch (65 KB at 4096 samples) apart, and how
+    // fast those go is decided by the physical layout behind the buffer: 0.33 ms when it is one contiguous stretch (the
+    // strided stores pile up on few DRAM channels), 0.5-1.3 ms in pieces below the 2 MB translation fragment, 0.180 in
+    // pieces of 2 to 8 MB - and 0.183 or 0.200, per process and per allocation, from hipMalloc, whose layout is whatever
+    // the driver's free lists hold: the two 'modes' of rounds 4-6 (profiles/r06_ab_runs.txt)
 #ifdef ML_DIAG
-    // (does the row transform's speed follow the result's position WITHIN its allocation at sub-2-MiB granularity?  The
-    // buffer is made ML_G_OFFSET_KB larger and G starts that far in)
-    static const size_t g_shift = (size_t)diag_int("ML_G_OFFSET_KB", 0) << 10;
+    static const size_t g_piece = (size_t)diag_int("ML_G_PIECE_KB", 8192) << 10;   // (0: hipMalloc)
+    static const size_t g_shift = (size_t)diag_int("ML_G_OFFSET_KB", 0) << 10;     // (G that far into a larger buffer)
 #else
-    constexpr size_t g_shift = 0;
+    constexpr size_t g_piece = (size_t)8 << 20, g_shift = 0;
 #endif
     const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double) + g_shift;
+    if (g_transposed && g_piece && pl.stage1.piece != g_piece) {
+        pl.stage1.release();
+        pl.stage1.piece = g_piece;
+    }
     ML_TRY(pl.stage1.reserve(g_transposed ? g_need : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
     void *g_at = pl.stage1.p;     // G of this call
-    int time_slot = -1;           // >= 0: this call's launches go between event pair `time_slot`
-    if (g_transposed && (pm.base != pl.stage1.p || pm.fields != (const void *)ctx->fields.p || pm.need != g_need)) {
-        for (auto &b : pm.others) b.release();
-        pm.others.clear();
-        pm.base = pl.stage1.p;
-        pm.fields = ctx->fields.p;
-        pm.need = g_need;
-        pm.K = (int)std::min<size_t>(ctx->placement_candidates, ((size_t)2 << 30) / g_need);
-        pm.steps = 0;
-        pm.ev_used = 0;
-        pm.ev_for = -1;
-        pm.chosen = pm.K >= 2 ? -1 : 0;
-        pm.ms.assign(std::max(pm.K, 0), -1.0f);
-    }
-    if (g_transposed && pm.chosen < 0) {
-        typedef FarfieldPlan::Placement P;
-        if (pm.steps == P::WARM) {   // a sweep is running on this plan: the other positions are allocated now
-            pm.others.resize(pm.K - 1);
-            for (auto &b : pm.others)
-                if (b.reserve(pl.stage1.bytes) != ML_OK) {   // (no room: no search)
-                    for (auto &o : pm.others) o.release();
-                    pm.others.clear();
-                    pm.chosen = 0;
-                    (void)hipGetLastError();   // (the failed allocation's: not a later launch's)
-                    break;
-                }
-        }
-    }
-    if (g_transposed && pm.chosen < 0) {
-        typedef FarfieldPlan::Placement P;
-        const int K = pm.K, n = pm.steps - P::WARM, k = n < 0 ? 0 : n / P::PER, j = n < 0 ? 0 : n % P::PER;
-        if (pm.ev_used > 0 && k != pm.ev_for) {   // the previous position's launches: complete long ago
-            ML_HIP(hipEventSynchronize(pm.e1[pm.ev_used - 1]));
-            float best = 1e30f;
-            for (int q = 0; q < pm.ev_used; ++q) {
-                float t = 0;
-                ML_HIP(hipEventElapsedTime(&t, pm.e0[q], pm.e1[q]));
-                best = std::min(best, t);
-            }
-            pm.ms[pm.ev_for] = best;
-            pm.ev_used = 0;
-        }
-        if (k >= K) {
-            int best = 0;
-            for (int c = 1; c < K; ++c)
-                if (pm.ms[c] >= 0 && (pm.ms[best] < 0 || pm.ms[c] < pm.ms[best])) best = c;
-            pm.chosen = best;
-            ML_HIP(hipStreamSynchronize(ctx->stream));   // (once per plan: launches still read the buffers freed here)
-            if (best > 0) std::swap(pl.stage1, pm.others[best - 1]);
-            for (auto &b : pm.others) b.release();
-            pm.others.clear();
-            pm.base = pl.stage1.p;
-            g_at = pl.stage1.p;
-        } else {
-            if (k > 0) g_at = pm.others[k - 1].p;
-            if (n >= 0 && j >= P::PER - P::TIMED) {
-                if (!pm.e0[0])
-                    for (int q = 0; q < P::TIMED; ++q) {
-                        ML_HIP(hipEventCreate(&pm.e0[q]));
-                        ML_HIP(hipEventCreate(&pm.e1[q]));
-                    }
-                time_slot = pm.ev_used;
-                pm.ev_for = k;
-            }
-            ++pm.steps;
-        }
-    }
 #ifdef ML_DIAG
-    {   // (tools/mode_slab.sh: the stage-1 result inside the fields' allocation, ML_SLAB_OFFSET_MB behind the four planes)
-        static const int slab_mb = diag_int("ML_SLAB_OFFSET_MB", -1);
-        const size_t planes = (size_t)4 * nxl * ny * 16, need = (size_t)4 * my * g_ld * 16;
-        if (slab_mb >= 0 && g_transposed && ctx->fields.bytes >= planes + ((size_t)slab_mb << 20) + need) {
-            static void *own = nullptr;
-            if (!own) own = pl.stage1.p;   // (the plan's own allocation stays allocated, unused)
-            pl.stage1.p = (char *)ctx->fields.p + planes + ((size_t)slab_mb << 20);
-            g_at = pl.stage1.p;
+    {   // (tools/ab_goffset.sh: ONE physically contiguous allocation behind the result)
+        static const int contiguous = diag_int("ML_G_CONTIGUOUS", 0);
+        static void *c_ptr = nullptr;
+        static size_t c_bytes = 0;
+        if (contiguous && g_transposed && c_bytes < g_need) {
+            const hipError_t e = hipExtMallocWithFlags(&c_ptr, g_need, hipDeviceMallocContiguous);
+            fprintf(stderr, "ML_G_CONTIGUOUS %zu bytes: %s at %p\n", g_need, hipGetErrorString(e), c_ptr);
+            if (e == hipSuccess) c_bytes = g_need;
+            else (void)hipGetLastError();
         }
-    }
-#endif
-#ifdef ML_DIAG
-    {   // (tools/mode_moves.py: does the row transform's 'mode' follow the stage-1 result's placement?)
-        static const int move_every = diag_int("ML_MOVE_STAGE1", 0);
-        static long calls = 0;
-        if (move_every > 0 && ++calls % move_every == 0 && pl.stage1.p) {
-            void *q = nullptr;
-            if (hipMalloc(&q, pl.stage1.bytes) == hipSuccess) {
-                // (the old allocation is LEFT in place - leaked, a diagnostic - so that every move lands somewhere new)
-                pl.stage1.p = q;
-                g_at = q;
-                fprintf(stderr, "ML_MOVED stage1 %p\n", q);
-            }
-        }
+        if (contiguous && g_transposed && c_bytes >= g_need) g_at = c_ptr;
     }
 #endif
     double *const g_buf = reinterpret_cast<double *>(static_cast<char *>(g_at) + (g_transposed ? g_shift : 0));
@@ -1153,7 +1073,6 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         }
         return ML_OK;
     };
-    if (time_slot >= 0) ML_HIP(hipEventRecord(pm.e0[time_slot], ctx->stream));
     {
         // stage 1: G[(f, n1)][b] = sum_n2 F_f[n1][n2] * exp(-i k y'_n2 uy_b)
         ProfScope scope(ctx, ML_K_ZGEMM_STAGE1);
@@ -1334,28 +1253,9 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
         ML_TRY(zcoldot(ctx->stream, 4, nxl, mx, alpha, pl.tw_x.as<double>(), mx, row0,
                        pl.stage1.as<double>(), pl.vectors.as<double>(), accumulate));
     }
-    if (time_slot >= 0) {
-        ML_HIP(hipEventRecord(pm.e1[time_slot], ctx->stream));
-        pm.ev_used = time_slot + 1;
-    }
     pl.have_vectors = true;
     pl.amplitudes_reduced = false;
     return ML_OK;
-}
-
-int ml_farfield_set_placement_search(ml_ctx *ctx, int candidates) {
-    if (!ctx || candidates < 0 || candidates > 16) return ML_EINVAL;
-    ctx->placement_candidates = candidates;
-    return ML_OK;
-}
-
-int ml_farfield_placement_info(ml_ctx *ctx, int *state, int *chosen, float *ms, int capacity) {
-    if (!ctx) return ML_EINVAL;
-    const FarfieldPlan::Placement &pm = ctx->plan.placement;
-    if (state) *state = pm.K < 2 ? 0 : pm.chosen >= 0 ? 2 : 1;
-    if (chosen) *chosen = pm.chosen;
-    for (int k = 0; ms && k < capacity; ++k) ms[k] = k < (int)pm.ms.size() ? pm.ms[k] : -1.0f;
-    return pm.K;
 }
 
 static Shard block_shard(int row0, int mirrored) {

@@ -179,46 +179,3 @@ def test_hot_path_fft_equals_gemm(ma, ctx):
         assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max(), key
     assert out['auto']['power_local_rows'] == out['gemm']['power_local_rows']
 
-
-def test_measured_placement_of_the_row_transform_result_changes_no_bit(ma):
-    """a plan that is being stepped times several allocations for the transposed stage-1 result and keeps the fastest
-    (farfield.hip transform_impl, include/metalens_hip.h ml_farfield_placement_info): every step of the search - on the
-    first buffer, on each candidate, after the others are freed - returns the same bits, and the search ends"""
-    from metalens_amd import _lib
-    c = _lib.default_context()
-    c.set_method('fft-streamed')
-    c.set_precision('f64')
-    c.placement_search(4)
-    try:
-        n, m = 768, 96
-        p = WL / 2.2
-        x = (np.arange(n) - (n - 1) / 2) * p
-        u = lattice(n, x[1] - x[0], m, -(m // 2))
-        ny = 1024
-        F = fields(n, ny, 5)
-        y = (np.arange(ny) - (ny - 1) / 2) * p
-        uy = lattice(ny, y[1] - y[0], m, -(m // 2))
-        first, states = None, []
-        for step in range(24 + 4 * 12 + 6):
-            got = ma.farfield_direct(*F, x, y, WL, N_GLASS, u, uy, ctx=c)
-            assert c.plan_kernels() == ('fft', 'fft')
-            info = c.placement_info()
-            states.append(info['state'])
-            if first is None:
-                first = got
-                assert info['positions'] == 4 and info['chosen'] == -1
-            for key in ('Nx', 'Ny', 'Lx', 'Ly', 'a_theta', 'a_phi'):
-                assert np.array_equal(got[key], first[key]), (step, key, info)
-        assert states[0] == 'searching' and states[-1] == 'settled'
-        info = c.placement_info()
-        assert 0 <= info['chosen'] < 4 and all(t > 0 for t in info['ms']), info
-        # ... and without the search: one position, nothing measured
-        c.placement_search(0)
-        F2 = fields(512, ny, 6)
-        x2 = (np.arange(512) - 255.5) * p
-        ma.farfield_direct(*F2, x2, y, WL, N_GLASS, lattice(512, x2[1] - x2[0], m, -(m // 2)), uy, ctx=c)
-        assert c.plan_kernels() == ('fft', 'fft')
-        assert c.placement_info()['state'] in ('none', 'settled') and c.placement_info()['positions'] < 2
-    finally:
-        c.placement_search(6)
-        c.set_method('auto')
