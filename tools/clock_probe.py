@@ -113,9 +113,9 @@ def main():
             if args.only == 'step':
                 hp.step()
             elif args.only == 'nearfield':
-                hp.nearfield_only() if hasattr(hp, 'nearfield_only') else hp.step()
+                hp.queue_synthesis()
             else:
-                hp.transform_only() if hasattr(hp, 'transform_only') else hp.step()
+                hp.queue_transform()
         hp.sync()
         steps += 50
     dt = time.perf_counter() - t0
