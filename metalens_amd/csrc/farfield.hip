@@ -907,17 +907,17 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // 72 0.206, 4 0.190, 8 0.194-0.196, 40 0.196, 136 0.192: anything but a multiple of 256 bytes)
     static const int g_skew = diag_int("ML_G_SKEW", 8);   // (diagnostic builds: the pitch's skew in elements)
     const int64_t g_ld = nxl + g_skew;
-    // The TRANSPOSED result lies in physical pieces of 8 MB, each an allocation of its own, mapped side by side
+    // The TRANSPOSED result lies in physical pieces of 4 MB, each an allocation of its own, mapped side by side
     // (common.h DevBuf::piece).  Stage 1 stores it in 16-byte pieces one pitch (65 KB at 4096 samples) apart, and how
     // fast those go is decided by the physical layout behind the buffer: 0.33 ms when it is one contiguous stretch (the
     // strided stores pile up on few DRAM channels), 0.5-1.3 ms in pieces below the 2 MB translation fragment, 0.180 in
-    // pieces of 2 to 8 MB - and 0.183 or 0.200, per process and per allocation, from hipMalloc, whose layout is whatever
+    // pieces of 2 to 8 MB (8192 samples, pitch 131 KB: 0.75 in 2 MB pieces, 0.70 in 4 MB, 0.72 in 8 MB) - and 0.183 or 0.200, per process and per allocation, from hipMalloc, whose layout is whatever
     // the driver's free lists hold: the two 'modes' of rounds 4-6 (profiles/r06_ab_runs.txt)
 #ifdef ML_DIAG
-    static const size_t g_piece = (size_t)diag_int("ML_G_PIECE_KB", 8192) << 10;   // (0: hipMalloc)
+    static const size_t g_piece = (size_t)diag_int("ML_G_PIECE_KB", 4096) << 10;   // (0: hipMalloc)
     static const size_t g_shift = (size_t)diag_int("ML_G_OFFSET_KB", 0) << 10;     // (G that far into a larger buffer)
 #else
-    constexpr size_t g_piece = (size_t)8 << 20, g_shift = 0;
+    constexpr size_t g_piece = (size_t)4 << 20, g_shift = 0;
 #endif
     const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double) + g_shift;
     if (g_transposed && g_piece && pl.stage1.piece != g_piece) {

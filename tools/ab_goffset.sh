@@ -2,7 +2,7 @@
 # How does the physical layout behind the big buffers decide the kernels' times?  Diagnostic build (common.h diag_int),
 # alternating processes of the default bench; one line per process.
 #     tools/ab_goffset.sh OUT ROUNDS "VARIANT ..."     VARIANT = NAME=VALUE[,NAME=VALUE...] or `default`
-# knobs: ML_G_PIECE_KB (stage-1 result in physical pieces of that size; 0: hipMalloc; product: 8192), ML_G_CONTIGUOUS=1,
+# knobs: ML_G_PIECE_KB (stage-1 result in physical pieces of that size; 0: hipMalloc; product: 4096), ML_G_CONTIGUOUS=1,
 #        ML_G_OFFSET_KB, ML_G_SKEW (pitch skew in elements), ML_F_PIECE_KB (field planes), ML_R_PIECE_KB (geometry records)
 OUT=$1; ROUNDS=$2; VARS=$3; shift 3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
