@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdint>
@@ -63,17 +64,22 @@ constexpr int diag_int(const char *, int dflt) { return dflt; }
 // stage 1 (profiles/r06_ab_runs.txt): one physically contiguous allocation 0.33 ms, pieces of 16 KB 1.28, 512 KB 0.8-1.0,
 // 1 MB 0.51 (address translation: the 2 MB fragment is lost), 2 MB 0.180, 4 MB 0.180, 8 MB 0.180, 32 MB 0.186; plain
 // hipMalloc 0.183 or 0.200 depending on what the process was handed.  Falls back to hipMalloc where the virtual-memory
-// API is not available.
+// API is not available.  (The two-pass kernel of rows beyond 8192 samples is the other way round and keeps hipMalloc.)
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
     size_t piece = 0;                                      // 0: one hipMalloc
     std::vector<hipMemGenericAllocationHandle_t> handles;  // the pieces behind p
     bool reserved = false;                                 // p is a reserved address range with the pieces mapped into it
+    size_t va_bytes = 0;                                   // ... of this many bytes (the buffer grows inside it)
     int reserve(size_t want) {
         if (want <= bytes) return ML_OK;
-        release();
-        if (piece > 0 && reserve_pieces(want)) return ML_OK;
+        if (piece > 0) {
+            if (p && !reserved) release();
+            if (grow_pieces(want)) return ML_OK;
+        } else {
+            release();
+        }
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -83,7 +89,14 @@ struct DevBuf {
         bytes = want;
         return ML_OK;
     }
-    bool reserve_pieces(size_t want) {
+    // ADDRESS RANGES ARE NEVER GIVEN BACK.  On this runtime (ROCm 7.2) an address range that has been unmapped, freed
+    // (hipMemAddressFree) and handed out again by a later hipMemAddressReserve reads back wrong data: a stand-alone
+    // program that fills and checks a freshly mapped buffer fails from the first round whose range overlaps an earlier
+    // one (19 008 ... 644 992 mismatching words; none when the old ranges stay reserved) - translations of the old
+    // mapping survive.  So a buffer reserves four times what it needs and GROWS by mapping more pieces behind the ones
+    // it has; a buffer that outgrows its range, or is released, unmaps and releases its physical pieces and leaves the
+    // range reserved for the life of the process (address space, not memory: 128 TB of it).
+    bool grow_pieces(size_t want) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         hipMemAllocationProp prop = {};
@@ -97,47 +110,64 @@ struct DevBuf {
             return false;
         }
         const size_t total = (want + piece - 1) / piece * piece;
-        void *base = nullptr;
-        if (hipMemAddressReserve(&base, total, piece, nullptr, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        bool ok = true;
-        for (size_t off = 0; ok && off < total; off += piece) {
-            hipMemGenericAllocationHandle_t h;
-            ok = hipMemCreate(&h, piece, &prop, 0) == hipSuccess;
-            if (!ok) break;
-            handles.push_back(h);
-            ok = hipMemMap(static_cast<char *>(base) + off, piece, 0, h, 0) == hipSuccess;
+        if (!reserved || total > va_bytes) {
+            drop_pieces();
+            const size_t va = std::max(4 * total, (size_t)256 << 20);
+            void *base = nullptr;
+            if (hipMemAddressReserve(&base, va, piece, nullptr, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return false;
+            }
+            p = base;
+            va_bytes = va;
+            reserved = true;
         }
         hipMemAccessDesc acc = {};
         acc.location = prop.location;
         acc.flags = hipMemAccessFlagsProtReadWrite;
-        ok = ok && hipMemSetAccess(base, total, &acc, 1) == hipSuccess;
-        p = base;
-        bytes = total;
-        reserved = true;
-        if (!ok) {
+        while (bytes < total) {
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, piece, &prop, 0) != hipSuccess) break;
+            void *at = static_cast<char *>(p) + bytes;
+            if (hipMemMap(at, piece, 0, h, 0) != hipSuccess) {
+                (void)hipMemRelease(h);
+                break;
+            }
+            handles.push_back(h);
+            bytes += piece;
+            if (hipMemSetAccess(at, piece, &acc, 1) != hipSuccess) break;
+        }
+        if (bytes < total) {   // (out of memory or an API that is not there: the caller falls back to hipMalloc)
             (void)hipGetLastError();
-            release();
+            drop_pieces();
             return false;
         }
         return true;
     }
-    void release() {
+    // unmap and release the physical pieces; the address range stays reserved (see above)
+    void drop_pieces() {
         if (p && reserved) {
-            // (a piece that was created but not mapped - a failed reserve_pieces - makes its unmap fail: ignored)
+            (void)hipDeviceSynchronize();   // (as hipFree would: launches still in flight may use the range)
             for (size_t k = 0; k < handles.size(); ++k) {
                 (void)hipMemUnmap(static_cast<char *>(p) + k * piece, piece);
                 (void)hipMemRelease(handles[k]);
             }
-            (void)hipMemAddressFree(p, bytes);
             (void)hipGetLastError();
-        } else if (p) {
-            (void)hipFree(p);
         }
         handles.clear();
-        reserved = false;
+        if (reserved) {
+            reserved = false;
+            p = nullptr;
+            bytes = 0;
+            va_bytes = 0;
+        }
+    }
+    void release() {
+        if (reserved) {
+            drop_pieces();
+            return;
+        }
+        if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
     }

@@ -913,14 +913,19 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     // strided stores pile up on few DRAM channels), 0.5-1.3 ms in pieces below the 2 MB translation fragment, 0.180 in
     // pieces of 2 to 8 MB (8192 samples, pitch 131 KB: 0.75 in 2 MB pieces, 0.70 in 4 MB, 0.72 in 8 MB) - and 0.183 or 0.200, per process and per allocation, from hipMalloc, whose layout is whatever
     // the driver's free lists hold: the two 'modes' of rounds 4-6 (profiles/r06_ab_runs.txt)
+    // ... for rows of up to 8192 samples.  The two-pass kernel of longer rows (one 152 KB workgroup per CU, whole lines
+    // stored) is the other way round: 16384^2 -> 1024^2 stage 1 4.01-4.16 ms over hipMalloc, 4.95 in 4 MB pieces, 4.32
+    // in 8, 4.45 in 16, 4.13 in 32, 4.03 in 64 - it keeps hipMalloc
 #ifdef ML_DIAG
-    static const size_t g_piece = (size_t)diag_int("ML_G_PIECE_KB", 4096) << 10;   // (0: hipMalloc)
+    static const long g_piece_kb = diag_int("ML_G_PIECE_KB", -1);                   // (0: hipMalloc; -1: the rule)
+    const size_t g_piece = g_piece_kb >= 0 ? (size_t)g_piece_kb << 10 : nxl <= 8192 ? (size_t)4 << 20 : 0;
     static const size_t g_shift = (size_t)diag_int("ML_G_OFFSET_KB", 0) << 10;     // (G that far into a larger buffer)
 #else
-    constexpr size_t g_piece = (size_t)4 << 20, g_shift = 0;
+    const size_t g_piece = nxl <= 8192 ? (size_t)4 << 20 : 0;
+    constexpr size_t g_shift = 0;
 #endif
     const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double) + g_shift;
-    if (g_transposed && g_piece && pl.stage1.piece != g_piece) {
+    if (g_transposed && pl.stage1.piece != g_piece) {
         pl.stage1.release();
         pl.stage1.piece = g_piece;
     }

@@ -179,3 +179,28 @@ def test_hot_path_fft_equals_gemm(ma, ctx):
         assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max(), key
     assert out['auto']['power_local_rows'] == out['gemm']['power_local_rows']
 
+
+
+def test_transposed_result_buffer_grows_and_moves_without_changing_results(ma):
+    """the transposed stage-1 result lives in physical pieces mapped into a reserved address range (common.h
+    DevBuf::piece): it GROWS inside the range, and a result that outgrows the range moves to a new one (the old
+    range is never handed back: on this runtime a re-used range reads stale data).  Sizes chosen to walk that path -
+    16, 67 and 269 MB of result, then small again - each against the GEMMs on the same fields"""
+    from metalens_amd import _lib
+    c = _lib.default_context()
+    c.set_precision('f64')
+    try:
+        for n, seed in ((512, 1), (1024, 2), (2048, 3), (768, 4), (512, 5)):
+            p = WL / 2.2
+            x = (np.arange(n) - (n - 1) / 2) * p
+            u = lattice(n, x[1] - x[0], n, -(n // 2))
+            F = fields(n, n, seed)
+            c.set_method('fft-streamed')
+            a = ma.farfield_direct(*F, x, x, WL, N_GLASS, u, u, ctx=c)
+            assert c.plan_kernels() == ('fft', 'fft')
+            c.set_method('gemm')
+            b = ma.farfield_direct(*F, x, x, WL, N_GLASS, u, u, ctx=c)
+            for key in ('Nx', 'Ny', 'Lx', 'Ly'):
+                assert np.abs(a[key] - b[key]).max() <= 1e-12 * np.abs(b[key]).max(), (n, key)
+    finally:
+        c.set_method('auto')
