@@ -924,10 +924,13 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     const size_t g_piece = nxl <= 8192 ? (size_t)4 << 20 : 0;
     constexpr size_t g_shift = 0;
 #endif
+    // (METALENS_HIP_PIECES=0 in the environment: plain hipMalloc - the way out should a driver's virtual-memory API misbehave)
+    static const bool pieces_off = [] { const char *e = getenv("METALENS_HIP_PIECES"); return e && e[0] == '0'; }();
     const size_t g_need = (size_t)4 * my * g_ld * 2 * sizeof(double) + g_shift;
-    if (g_transposed && pl.stage1.piece != g_piece) {
+    const size_t g_piece_now = pieces_off ? 0 : g_piece;
+    if (g_transposed && pl.stage1.piece != g_piece_now) {
         pl.stage1.release();
-        pl.stage1.piece = g_piece;
+        pl.stage1.piece = g_piece_now;
     }
     ML_TRY(pl.stage1.reserve(g_transposed ? g_need : (size_t)pl.stage1_splits * 4 * nxl * my * 2 * sizeof(double)));
     void *g_at = pl.stage1.p;     // G of this call
