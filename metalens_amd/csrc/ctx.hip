@@ -977,6 +977,24 @@ static int nearfield_prepare(ml_ctx *ctx, const ml_nearfield_params *p, int n, c
         }
     }
 #endif
+#ifdef ML_DIAG
+    {   // (... or as ONE physically contiguous allocation)
+        static const int f_contig = diag_int("ML_F_CONTIGUOUS", 0);
+        const size_t want = (size_t)n * 4 * plane * 2 * sizeof(double);
+        if (f_contig && ctx->fields.bytes < want) {
+            ctx->fields.release();
+            void *q = nullptr;
+            const hipError_t e = hipExtMallocWithFlags(&q, want, hipDeviceMallocContiguous);
+            fprintf(stderr, "ML_F_CONTIGUOUS %zu bytes: %s\n", want, hipGetErrorString(e));
+            if (e == hipSuccess) {
+                ctx->fields.p = q;
+                ctx->fields.bytes = want;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+#endif
     ML_TRY(ctx->fields.reserve((size_t)n * 4 * plane * 2 * sizeof(double)));
     ctx->nx = nx;
     ctx->ny = ny;
