@@ -610,7 +610,22 @@ int ml_ctx_create(int device, ml_ctx **out) {
     snprintf(ctx->arch, sizeof ctx->arch, "%s", prop.gcnArchName);
     ctx->cu_count = prop.multiProcessorCount;
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+#ifdef ML_DIAG
+    // (tools/cu_split_probe.py: this context's stream on the compute units [lo, hi) only - ML_STREAM_CUS="lo:hi", or
+    // "lo:hi:k" = every k-th of them - read when the context is made)
+    if (const char *m = getenv("ML_STREAM_CUS")) {
+        int lo = 0, hi = 0, k = 1;
+        if (sscanf(m, "%d:%d:%d", &lo, &hi, &k) >= 2 && hi > lo && k >= 1) {
+            uint32_t mask[8] = {0};
+            for (int c = lo; c < hi && c < 256; c += k) mask[c >> 5] |= 1u << (c & 31);
+            e = hipExtStreamCreateWithCUMask(&ctx->stream, 8, mask);
+            fprintf(stderr, "ML_STREAM_CUS %d:%d:%d -> %s\n", lo, hi, k, hipGetErrorString(e));
+        }
+    }
+    if (!ctx->stream)
+#endif
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
         delete ctx;
