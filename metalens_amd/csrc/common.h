@@ -62,8 +62,8 @@ constexpr int diag_int(const char *, int dflt) { return dflt; }
 // 16-byte stores a fixed large stride apart go (the row transform's transposed result, farfield.hip) depends on the
 // physical layout behind the buffer, which hipMalloc leaves to the driver's free lists - measured at 4096^2 -> 512^2,
 // stage 1 (profiles/r06_ab_runs.txt): one physically contiguous allocation 0.33 ms, pieces of 16 KB 1.28, 512 KB 0.8-1.0,
-// 1 MB 0.51 (address translation: the 2 MB fragment is lost), 2 MB 0.180, 4 MB 0.180, 8 MB 0.180, 32 MB 0.186; plain
-// hipMalloc 0.183 or 0.200 depending on what the process was handed.  Falls back to hipMalloc where the virtual-memory
+// 1 MB 0.51 (address translation: the 2 MB fragment is lost), 2 / 4 / 8 MB 0.178-0.190 in three processes of four (else
+// 0.195-0.20), 32 MB 0.186; plain hipMalloc 0.183 or 0.200, one of two each, depending on what the process was handed.  Falls back to hipMalloc where the virtual-memory
 // API is not available.  (The two-pass kernel of rows beyond 8192 samples is the other way round and keeps hipMalloc.)
 struct DevBuf {
     void *p = nullptr;

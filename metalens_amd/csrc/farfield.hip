@@ -909,10 +909,11 @@ static int transform_impl(ml_ctx *ctx, const Shard &sh, int accumulate) {
     const int64_t g_ld = nxl + g_skew;
     // The TRANSPOSED result lies in physical pieces of 4 MB, each an allocation of its own, mapped side by side
     // (common.h DevBuf::piece).  Stage 1 stores it in 16-byte pieces one pitch (65 KB at 4096 samples) apart, and how
-    // fast those go is decided by the physical layout behind the buffer: 0.33 ms when it is one contiguous stretch (the
-    // strided stores pile up on few DRAM channels), 0.5-1.3 ms in pieces below the 2 MB translation fragment, 0.180 in
-    // pieces of 2 to 8 MB (8192 samples, pitch 131 KB: 0.75 in 2 MB pieces, 0.70 in 4 MB, 0.72 in 8 MB) - and 0.183 or 0.200, per process and per allocation, from hipMalloc, whose layout is whatever
-    // the driver's free lists hold: the two 'modes' of rounds 4-6 (profiles/r06_ab_runs.txt)
+    // fast those go is decided by the physical layout behind the buffer: 0.33 ms over one physically contiguous
+    // allocation (whatever the pitch), 0.5-1.3 ms in pieces below the 2 MB translation fragment, 0.178-0.190 in pieces
+    // of 2 to 8 MB in three processes of four (8192 samples, pitch 131 KB: 0.75 in 2 MB pieces, 0.70 in 4 MB, 0.72 in 8 MB)
+    // - and 0.183 or 0.200, one of two each, from hipMalloc, whose layout is whatever the driver's free lists hold: the
+    // two 'modes' of rounds 4-6 (profiles/r06_ab_runs.txt)
     // ... for rows of up to 8192 samples.  The two-pass kernel of longer rows (one 152 KB workgroup per CU, whole lines
     // stored) is the other way round: 16384^2 -> 1024^2 stage 1 4.01-4.16 ms over hipMalloc, 4.95 in 4 MB pieces, 4.32
     // in 8, 4.45 in 16, 4.13 in 32, 4.03 in 64 - it keeps hipMalloc
