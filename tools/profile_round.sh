@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --cpu-rows 0 --cpu-fft-side 0 > $O/stats.log 2>&1
 pmc() {   # KEY=<config.pmc_key> pmc NAME <bench args>: the counter passes of one configuration
   name=$1; shift
-  SHORT="python $R/bench.py --steps 7 --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 --also-physical 0 $@"
+  SHORT="python $R/bench.py --steps ${PMC_STEPS:-7} --warmup 2 --blocks 1 --cpu-rows 0 --cpu-fft-side 0 --check 0 --cold 0 --also-physical 0 $@"
   $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/$name/fetch -- $SHORT > $O/$name.fetch.log 2>&1
   $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/$name/write -- $SHORT > $O/$name.write.log 2>&1
   $T rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/$name/sq -- $SHORT > $O/$name.sq.log 2>&1
@@ -32,6 +32,8 @@ KEY=$(printf $K0 4096 512) pmc c4096
 KEY=$(printf $K0 2048 256) pmc c2048 --aperture 2048 --farfield 256
 KEY=$(printf $K0 8192 512) pmc c8192 --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94
 KEY=$(printf $K0 512 64) pmc c512 --aperture 512 --farfield 64 --diameter 1.2e-4
+# configs[4]'s size on one GPU (the two-pass row transform): its counters too, so that its bench line quotes its own
+KEY=$(printf $K0 16384 1024) PMC_STEPS=3 pmc c16384 --aperture 16384 --farfield 1024 --diameter 4e-3
 # ... and with the order lists characterize() would record (7 to 11 orders per ring collection)
 KEY=$(printf $K0 4096 512),orders=physical pmc c4096phys --orders physical
 KEY=$(printf $K0 8192 512),orders=physical pmc c8192phys --aperture 8192 --farfield 512 --diameter 2e-3 --na 0.94 --orders physical
